@@ -1,0 +1,126 @@
+/*
+ * regnet_hip.h -- C ABI of libregnet_hip.so: the MI355X (gfx950) replacement for the native part
+ * of REGNet's PointNet++ hot path (the reference's CUDA extensions `pn2_ext` and `dgcnn_ext`).
+ *
+ * Conventions (all entry points):
+ *   - plain device pointers + int64 sizes/element-strides, no torch types, no allocation, no
+ *     global state; re-entrant; the caller owns every buffer (the Python binding allocates the
+ *     outputs exactly like the reference does with at::zeros);
+ *   - `stream` is a hipStream_t passed as void* (NULL = the legacy default stream, which is what
+ *     the reference launches on);
+ *   - return value: 0 on success, REGNET_ERR_* (<0) for an argument the reference would have
+ *     rejected with TORCH_CHECK / CHECK_EQ / CHECK_GT / CHECK_GE, or a positive hipError_t from
+ *     the launch (the reference's THCudaCheck(cudaGetLastError())).  Never throws.
+ *   - float data is fp32, indices are int64, xyz tensors are the reference's channel-first
+ *     (B,3,N) views addressed through explicit element strides (sb, sc, sn), so the
+ *     non-contiguous views ScoreNet passes (score_network.py:46, pointnet2.py:89-90) need no copy.
+ *
+ * Reference interface each function replaces is cited as file:line relative to
+ * /root/reference/multi_model/utils/pn2_utils/.
+ */
+#ifndef REGNET_HIP_H_
+#define REGNET_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define REGNET_OK 0
+#define REGNET_ERR_SHAPE (-1)       /* CHECK_EQ / CHECK_GT / CHECK_GE style violation            */
+#define REGNET_ERR_NULL (-2)        /* NULL pointer for a non-empty tensor                        */
+#define REGNET_ERR_UNSUPPORTED (-3) /* size outside what this build supports (reported, not UB)  */
+
+/* Library / build identification. */
+int regnet_abi_version(void);
+const char* regnet_build_info(void);
+/* Human-readable text for a code returned by any entry point (static storage). */
+const char* regnet_strerror(int code);
+
+/* ---- pn2_ext.farthest_point_sample  (csrc/sampling.h:7-9, sampling_kernel.cu:126-170) --------
+ * xyz (B,3,N) strided -> index (B,M) int64 contiguous.  index[b,0]=0; tie order is the
+ * reference's (lane = j mod block, shared-memory tree).
+ * Errors: M<=0 or N<M -> REGNET_ERR_SHAPE (CHECK_GT/CHECK_GE :136-137).                        */
+int regnet_fps_f32(const float* xyz, int64_t sb, int64_t sc, int64_t sn, int64_t B, int64_t N,
+                   int64_t M, int64_t* index, float* workspace, void* stream);
+/* Scratch bytes regnet_fps_f32 needs for (B,N,M) -- 0 while the scene fits the register-resident
+ * kernel (N <= 25600), else B*N*4 (the reference's `temp` tensor, sampling_kernel.cu:142).
+ * `workspace` may be NULL when this returns 0.                                                   */
+int64_t regnet_fps_workspace_bytes(int64_t B, int64_t N, int64_t M);
+
+/* ---- pn2_ext.ball_query  (csrc/ball_query.h:7-11, ball_query_kernel.cu:87-131) ---------------
+ * xyz (B,3,N1) strided, centroids (B,3,N2) strided -> index (B,N2,K) int64, count (B,N2) int64.
+ * First K points in index order with d2 < radius*radius (fp32, strict); first hit pre-fills all
+ * K slots; a ball with no hit keeps index 0 / count 0 (the reference's at::zeros).              */
+int regnet_ball_query_f32(const float* xyz, int64_t sb, int64_t sc, int64_t sn,
+                          const float* centroids, int64_t cb, int64_t cc, int64_t cn, int64_t B,
+                          int64_t N1, int64_t N2, float radius, int64_t K, int64_t* index,
+                          int64_t* count, void* stream);
+
+/* ---- pn2_ext.group_points_forward / backward  (csrc/grouping.h:7-14) ------------------------
+ * forward : input (B,C,N1) strided, index (B,N2,K) contiguous -> out (B,C,N2,K) contiguous.
+ * backward: grad_out (B,C,N2,K) strided -> grad_in (B,C,N1) contiguous, zero-filled by callee. */
+int regnet_group_points_fwd_f32(const float* input, int64_t sb, int64_t sc, int64_t sn,
+                                const int64_t* index, int64_t B, int64_t C, int64_t N1, int64_t N2,
+                                int64_t K, float* out, void* stream);
+int regnet_group_points_bwd_f32(const float* grad_out, int64_t sb, int64_t sc, int64_t sn2,
+                                int64_t sk, const int64_t* index, int64_t B, int64_t C, int64_t N1,
+                                int64_t N2, int64_t K, float* grad_in, void* stream);
+
+/* ---- pn2_ext.point_search (3-NN)  (csrc/interpolate.h:8-11, interpolate_kernel.cu:88-128) ----
+ * query (B,3,N1), key (B,3,N2) strided -> index (B,N1,3) int64, dist2 (B,N1,3) fp32 ascending
+ * SQUARED distances, earlier key wins ties.  N2<3 -> REGNET_ERR_SHAPE (CHECK_GE :102).          */
+int regnet_three_nn_f32(const float* query, int64_t qb, int64_t qc, int64_t qn, const float* key,
+                        int64_t kb, int64_t kc, int64_t kn, int64_t B, int64_t N1, int64_t N2,
+                        int64_t* index, float* dist2, void* stream);
+
+/* ---- pn2_ext.interpolate_forward / backward  (csrc/interpolate.h:13-22) ----------------------
+ * forward : input (B,C,M) strided, index/weight (B,N,3) contiguous -> out (B,C,N) contiguous.
+ * backward: grad_out (B,C,N) strided -> grad_in (B,C,M) contiguous, zero-filled by callee.      */
+int regnet_interpolate_fwd_f32(const float* input, int64_t sb, int64_t sc, int64_t sm,
+                               const int64_t* index, const float* weight, int64_t B, int64_t C,
+                               int64_t M, int64_t N, float* out, void* stream);
+int regnet_interpolate_bwd_f32(const float* grad_out, int64_t sb, int64_t sc, int64_t sn,
+                               const int64_t* index, const float* weight, int64_t B, int64_t C,
+                               int64_t M, int64_t N, float* grad_in, void* stream);
+
+/* ---- dgcnn_ext.gather_knn_forward / backward  (functions/csrc/gather_knn.h) ------------------
+ * Same gather / scatter-add as group_points with N2 == number of index rows.                    */
+int regnet_gather_knn_fwd_f32(const float* input, int64_t sb, int64_t sc, int64_t sn,
+                              const int64_t* index, int64_t B, int64_t C, int64_t N, int64_t NI,
+                              int64_t K, float* out, void* stream);
+int regnet_gather_knn_bwd_f32(const float* grad_out, int64_t sb, int64_t sc, int64_t sn2,
+                              int64_t sk, const int64_t* index, int64_t B, int64_t C, int64_t N,
+                              int64_t NI, int64_t K, float* grad_in, void* stream);
+
+/* ---- region grouping (host Python loops in the reference) -----------------------------------
+ * regnet_radius_group_f32: dataset_utils/get_regiondataset.py:279-295,:311-352.
+ * pc (B,N,*) rows with xyz first (strides pb,pn in floats), centres (B,NC,*) likewise ->
+ * cand (B,NC,cap) int32 = ascending indices of the points with d2 <= d2_threshold (inclusive),
+ * count (B,NC) int32 = number of members (may exceed cap; only the first cap are stored).
+ * The caller derives d2_threshold from the reference's `sqrt(d2) <= R` test (see
+ * region_ops.sqrt_le_threshold).                                                                 */
+int regnet_radius_group_f32(const float* pc, int64_t pb, int64_t pn, const float* centres,
+                            int64_t cb, int64_t cn, int64_t B, int64_t N, int64_t NC,
+                            float d2_threshold, int64_t cap, int32_t* cand, int32_t* count,
+                            void* stream);
+
+/* regnet_box_crop_f32: multi_model/gripper_region_network.py:508-544 (the per-grasp torch.nonzero
+ * loop).  group_points (n,G,*) rows with xyz first (strides gb,gn), centre (n,3), rot (n,3,3)
+ * row-major = [approach; axis_y; minor_normal], xlim/ylim (n) per-grasp half extents, zlim
+ * scalar -> cand (n,G) int32 ascending in-box positions, count (n) int32.                       */
+int regnet_box_crop_f32(const float* group_points, int64_t gb, int64_t gn, const float* centre,
+                        const float* rot, const float* xlim, const float* ylim, float zlim,
+                        int64_t n, int64_t G, int32_t* cand, int32_t* count, void* stream);
+
+/* regnet_gather_max_f32: multi_model/gripper_region_network.py:388-395 + utils/pointnet2.py:167
+ * (and :334-343 + pointnet2.py:232 for the refine stage): out[r,:] = max_g feat[rows[r,g],:].
+ * feat (num_rows,F) row-major, rows (R,G) int64 -> out (R,F).                                    */
+int regnet_gather_max_f32(const float* feat, int64_t num_rows, int64_t F, const int64_t* rows,
+                          int64_t R, int64_t G, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* REGNET_HIP_H_ */

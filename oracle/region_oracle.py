@@ -1,0 +1,57 @@
+"""CPU ORACLE for the region-grouping helper ops (test infrastructure, NOT product code).
+
+numpy / torch-CPU restatements of what the reference computes with dense torch masks and
+``torch.nonzero`` in Python loops; same call signatures as ``regnet_for_3d_grasping_amd.region_ops``
+so tests can swap them in.  Citations are relative to /root/reference.
+"""
+import numpy as np
+import torch
+
+from . import pn2_ext_oracle
+
+
+def radius_candidates(pc, centres, radius):
+    """dataset_utils/get_regiondataset.py:279-295: members = sqrt(d2) <= R, ascending order
+    (torch.nonzero, :332).  pc (B,N,C), centres (B,Nc,C) -> cand (B,Nc,N) int32, count (B,Nc) int32."""
+    B, N, _ = pc.shape
+    Nc = centres.shape[1]
+    cand = torch.zeros((B, Nc, max(N, 1)), dtype=torch.int32)
+    count = torch.zeros((B, Nc), dtype=torch.int32)
+    for b in range(B):
+        mask = pn2_ext_oracle.radius_mask(pc[b], centres[b], radius)  # C: sqrtf(d2) <= R
+        for c in range(Nc):
+            members = torch.nonzero(mask[c]).view(-1)
+            count[b, c] = members.numel()
+            cand[b, c, :members.numel()] = members.to(torch.int32)
+    return cand, count
+
+
+def box_candidates(group_points, centre, rot, xlim, ylim, zlim):
+    """multi_model/gripper_region_network.py:508-528: t = R (p - c), six strict box tests;
+    products summed left to right in fp32 (numpy float32 ops round individually)."""
+    p = group_points[:, :, :3].float().numpy().astype(np.float32)
+    c = centre.float().numpy().astype(np.float32)
+    m = rot.float().numpy().astype(np.float32)
+    xl = xlim.float().numpy().astype(np.float32)
+    yl = ylim.float().numpy().astype(np.float32)
+    zl = np.float32(zlim)
+    n, G, _ = p.shape
+    d = p - c[:, None, :]
+    t = np.empty((n, G, 3), np.float32)
+    for r in range(3):
+        t[:, :, r] = (m[:, None, r, 0] * d[:, :, 0] + m[:, None, r, 1] * d[:, :, 1]) + m[:, None, r, 2] * d[:, :, 2]
+    inside = ((t[:, :, 0] > 0) & (t[:, :, 0] < xl[:, None]) & (t[:, :, 1] > -yl[:, None]) & (t[:, :, 1] < yl[:, None])
+              & (t[:, :, 2] > -zl) & (t[:, :, 2] < zl))
+    cand = np.zeros((n, max(G, 1)), np.int32)
+    count = np.zeros((n,), np.int32)
+    for i in range(n):
+        members = np.nonzero(inside[i])[0]
+        count[i] = len(members)
+        cand[i, :len(members)] = members
+    return torch.from_numpy(cand), torch.from_numpy(count)
+
+
+def gather_max(feature_rows, rows):
+    """gripper_region_network.py:388-395 + utils/pointnet2.py:167: gather rows then max over the group."""
+    R, G = rows.shape
+    return feature_rows[rows.reshape(-1)].view(R, G, -1).max(dim=1)[0]

@@ -1,0 +1,59 @@
+"""ctypes loader for ``csrc/libregnet_hip.so`` (the C ABI declared in include/regnet_hip.h).
+
+Fails loudly: a missing library raises ImportError at import time and a non-zero status from
+any entry point raises RuntimeError (the reference's TORCH_CHECK / THCudaCheck convention,
+e.g. csrc/sampling_kernel.cu:134-137,167).
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libregnet_hip.so")
+
+_i64, _f32, _vp, _int = ctypes.c_int64, ctypes.c_float, ctypes.c_void_p, ctypes.c_int
+
+# name -> (restype, argtypes); mirrors include/regnet_hip.h one to one.
+SIGNATURES = {
+    "regnet_abi_version": (_int, []),
+    "regnet_build_info": (ctypes.c_char_p, []),
+    "regnet_strerror": (ctypes.c_char_p, [_int]),
+    "regnet_fps_f32": (_int, [_vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp]),
+    "regnet_fps_workspace_bytes": (_i64, [_i64, _i64, _i64]),
+    "regnet_ball_query_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _f32, _i64,
+                                     _vp, _vp, _vp]),
+    "regnet_group_points_fwd_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp]),
+    "regnet_group_points_bwd_f32": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _i64, _i64, _vp,
+                                           _vp]),
+    "regnet_three_nn_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp]),
+    "regnet_interpolate_fwd_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
+    "regnet_interpolate_bwd_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
+    "regnet_gather_knn_fwd_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp]),
+    "regnet_gather_knn_bwd_f32": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp]),
+    "regnet_radius_group_f32": (_int, [_vp, _i64, _i64, _vp, _i64, _i64, _i64, _i64, _i64, _f32, _i64, _vp, _vp,
+                                       _vp]),
+    "regnet_box_crop_f32": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _f32, _i64, _i64, _vp, _vp, _vp]),
+    "regnet_gather_max_f32": (_int, [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _vp]),
+}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "libregnet_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `python regnet_for_3d_grasping_amd/csrc/build.py`; there is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here == header/library mismatch: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+def check(status, what):
+    """Raise RuntimeError for a non-zero status code of entry point ``what``."""
+    if status != 0:
+        msg = lib.regnet_strerror(int(status)).decode()
+        raise RuntimeError("%s failed: %s (code %d)" % (what, msg, status))

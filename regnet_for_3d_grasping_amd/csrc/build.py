@@ -1,0 +1,82 @@
+"""Builds libregnet_hip.so for gfx950 with hipcc (cross-compiles without a GPU).
+
+One shared object, in-tree (regnet_for_3d_grasping_amd/csrc/libregnet_hip.so) so it travels to the
+GPU box with the repo snapshot.  geometry.hip is compiled with -ffp-contract=off: the indices it
+emits depend on individually rounded fp32 distance arithmetic.
+"""
+import hashlib
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.join(HERE, "libregnet_hip.so")
+ARCH = "gfx950"
+
+# (source, extra flags)
+SOURCES = [
+    ("api.hip", []),
+    ("geometry.hip", ["-ffp-contract=off"]),
+    ("gather.hip", []),
+    ("region.hip", ["-ffp-contract=off"]),
+    ("mlp.hip", []),
+]
+COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+          "-fno-gpu-rdc"]
+
+
+def _hipcc():
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+            return cand
+    raise RuntimeError("hipcc not found")
+
+
+def _stamp():
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(HERE)):
+        if name.endswith((".hip", ".h", ".py")):
+            with open(os.path.join(HERE, name), "rb") as f:
+                h.update(name.encode()); h.update(f.read())
+    inc = os.path.join(HERE, "..", "..", "include", "regnet_hip.h")
+    with open(inc, "rb") as f:
+        h.update(f.read())
+    return h.hexdigest()
+
+
+def build(force=False, verbose=False):
+    stamp_file = os.path.join(HERE, ".build_stamp")
+    stamp = _stamp()
+    if not force and os.path.exists(OUT) and os.path.exists(stamp_file):
+        with open(stamp_file) as f:
+            if f.read().strip() == stamp:
+                return OUT
+    hipcc = _hipcc()
+    objs = []
+    procs = []
+    for src, extra in SOURCES:
+        path = os.path.join(HERE, src)
+        if not os.path.exists(path):
+            continue
+        obj = os.path.join(HERE, src.replace(".hip", ".o"))
+        cmd = [hipcc] + COMMON + extra + ["-c", path, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+        objs.append(obj)
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            sys.stderr.write(out.decode())
+            raise RuntimeError("hipcc failed on %s" % src)
+        if verbose and out:
+            print(out.decode())
+    cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", OUT] + objs
+    subprocess.check_call(cmd)
+    with open(stamp_file, "w") as f:
+        f.write(stamp)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

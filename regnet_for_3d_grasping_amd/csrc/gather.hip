@@ -1,0 +1,172 @@
+// gather.hip -- group_points / interpolate forward+backward, gather_knn (gfx950).
+//
+// These are HBM-bound gathers / scatter-adds at the reference's operator granularity (the fused
+// set-abstraction path in fused_mlp.hip never materialises them).  Layout: consecutive threads
+// walk the innermost (n,k) axis of the contiguous output so stores coalesce; each thread reads
+// its int64 index once and loops over a slab of channels.
+//
+// Reference behaviour restated (relative to multi_model/utils/pn2_utils/):
+//   group fwd   csrc/grouping_kernel.cu:29-51     group bwd   csrc/grouping_kernel.cu:54-93
+//   interp fwd  csrc/interpolate_kernel.cu:134-177 interp bwd csrc/interpolate_kernel.cu:239-282
+//   gather_knn  functions/csrc/gather_knn_kernel.cu:27-92
+#include "common.h"
+
+#define GT 256
+#define CH_PER_BLOCK 16
+
+__global__ __launch_bounds__(GT) void group_fwd_kernel(const float* __restrict__ in, int64_t sb, int64_t sc,
+                                                       int64_t sn, const int64_t* __restrict__ index, int C, int N1,
+                                                       int64_t NK, float* __restrict__ out) {
+  const int b = blockIdx.z;
+  const int64_t e = (int64_t)blockIdx.x * GT + threadIdx.x;
+  if (e >= NK) return;
+  const int64_t j = index[(int64_t)b * NK + e];
+  const bool ok = j >= 0 && j < N1;  // the reference asserts; out-of-range rows read as 0
+  const int cbeg = blockIdx.y * CH_PER_BLOCK, cend = min(C, cbeg + CH_PER_BLOCK);
+  const float* src = in + (int64_t)b * sb + (ok ? j : 0) * sn;
+  float* dst = out + ((int64_t)b * C) * NK + e;
+  for (int c = cbeg; c < cend; ++c) dst[(int64_t)c * NK] = ok ? src[(int64_t)c * sc] : 0.f;
+}
+
+__global__ __launch_bounds__(GT) void group_bwd_kernel(const float* __restrict__ go, int64_t sb, int64_t sc,
+                                                       int64_t sn2, int64_t sk, const int64_t* __restrict__ index,
+                                                       int C, int N1, int N2, int K, float* __restrict__ gi) {
+  const int b = blockIdx.z;
+  const int64_t NK = (int64_t)N2 * K;
+  const int64_t e = (int64_t)blockIdx.x * GT + threadIdx.x;
+  if (e >= NK) return;
+  const int64_t j = index[(int64_t)b * NK + e];
+  if (j < 0 || j >= N1) return;
+  const int64_t n = e / K, k = e - n * K;
+  const int cbeg = blockIdx.y * CH_PER_BLOCK, cend = min(C, cbeg + CH_PER_BLOCK);
+  const float* src = go + (int64_t)b * sb + n * sn2 + k * sk;
+  float* dst = gi + ((int64_t)b * C) * N1 + j;
+  for (int c = cbeg; c < cend; ++c) atomicAdd(dst + (int64_t)c * N1, src[(int64_t)c * sc]);
+}
+
+__global__ __launch_bounds__(GT) void interp_fwd_kernel(const float* __restrict__ in, int64_t sb, int64_t sc,
+                                                        int64_t sm, const int64_t* __restrict__ index,
+                                                        const float* __restrict__ weight, int C, int M, int N,
+                                                        float* __restrict__ out) {
+  const int b = blockIdx.z;
+  const int n = blockIdx.x * GT + threadIdx.x;
+  if (n >= N) return;
+  const int64_t o = ((int64_t)b * N + n) * 3;
+  const int64_t j0 = index[o], j1 = index[o + 1], j2 = index[o + 2];
+  const float w0 = weight[o], w1 = weight[o + 1], w2 = weight[o + 2];
+  const int cbeg = blockIdx.y * CH_PER_BLOCK, cend = min(C, cbeg + CH_PER_BLOCK);
+  const float* src = in + (int64_t)b * sb;
+  float* dst = out + ((int64_t)b * C) * N + n;
+  for (int c = cbeg; c < cend; ++c) {
+    const float* s = src + (int64_t)c * sc;
+    float acc = 0.f;  // accumulate from 0 in k order (interpolate_kernel.cu:165-170)
+    acc += s[j0 * sm] * w0;
+    acc += s[j1 * sm] * w1;
+    acc += s[j2 * sm] * w2;
+    dst[(int64_t)c * N] = acc;
+  }
+}
+
+__global__ __launch_bounds__(GT) void interp_bwd_kernel(const float* __restrict__ go, int64_t sb, int64_t sc,
+                                                        int64_t sn, const int64_t* __restrict__ index,
+                                                        const float* __restrict__ weight, int C, int M, int N,
+                                                        float* __restrict__ gi) {
+  const int b = blockIdx.z;
+  const int n = blockIdx.x * GT + threadIdx.x;
+  if (n >= N) return;
+  const int64_t o = ((int64_t)b * N + n) * 3;
+  const int64_t j0 = index[o], j1 = index[o + 1], j2 = index[o + 2];
+  const float w0 = weight[o], w1 = weight[o + 1], w2 = weight[o + 2];
+  const int cbeg = blockIdx.y * CH_PER_BLOCK, cend = min(C, cbeg + CH_PER_BLOCK);
+  const float* src = go + (int64_t)b * sb + (int64_t)n * sn;
+  float* dst = gi + ((int64_t)b * C) * M;
+  for (int c = cbeg; c < cend; ++c) {
+    const float g = src[(int64_t)c * sc];
+    float* d = dst + (int64_t)c * M;
+    atomicAdd(d + j0, g * w0);
+    atomicAdd(d + j1, g * w1);
+    atomicAdd(d + j2, g * w2);
+  }
+}
+
+static inline bool dims_ok(int64_t B, int64_t C) { return B <= 65535 && (C + CH_PER_BLOCK - 1) / CH_PER_BLOCK <= 65535; }
+
+extern "C" int regnet_group_points_fwd_f32(const float* input, int64_t sb, int64_t sc, int64_t sn,
+                                           const int64_t* index, int64_t B, int64_t C, int64_t N1, int64_t N2,
+                                           int64_t K, float* out, void* stream) {
+  if (B < 0 || C < 0 || N1 < 0 || N2 < 0 || K < 0) return REGNET_ERR_SHAPE;
+  const int64_t NK = N2 * K;
+  if (B == 0 || C == 0 || NK == 0) return REGNET_OK;
+  if (!dims_ok(B, C) || N1 >= (int64_t)1 << 31) return REGNET_ERR_UNSUPPORTED;
+  if (!input || !index || !out) return REGNET_ERR_NULL;
+  dim3 grid((unsigned)((NK + GT - 1) / GT), (unsigned)((C + CH_PER_BLOCK - 1) / CH_PER_BLOCK), (unsigned)B);
+  hipLaunchKernelGGL(group_fwd_kernel, grid, dim3(GT), 0, as_stream(stream), input, sb, sc, sn, index, (int)C,
+                     (int)N1, NK, out);
+  REGNET_LAUNCH_CHECK();
+  return REGNET_OK;
+}
+
+extern "C" int regnet_group_points_bwd_f32(const float* grad_out, int64_t sb, int64_t sc, int64_t sn2, int64_t sk,
+                                           const int64_t* index, int64_t B, int64_t C, int64_t N1, int64_t N2,
+                                           int64_t K, float* grad_in, void* stream) {
+  if (B < 0 || C < 0 || N1 < 0 || N2 < 0 || K < 0) return REGNET_ERR_SHAPE;
+  if (B == 0 || C == 0 || N1 == 0) return REGNET_OK;
+  if (!grad_in) return REGNET_ERR_NULL;
+  hipError_t e = hipMemsetAsync(grad_in, 0, sizeof(float) * (size_t)(B * C * N1), as_stream(stream));
+  if (e != hipSuccess) return (int)e;
+  const int64_t NK = N2 * K;
+  if (NK == 0) return REGNET_OK;
+  if (!dims_ok(B, C) || N1 >= (int64_t)1 << 31 || N2 >= (int64_t)1 << 31 || K >= (int64_t)1 << 31)
+    return REGNET_ERR_UNSUPPORTED;
+  if (!grad_out || !index) return REGNET_ERR_NULL;
+  dim3 grid((unsigned)((NK + GT - 1) / GT), (unsigned)((C + CH_PER_BLOCK - 1) / CH_PER_BLOCK), (unsigned)B);
+  hipLaunchKernelGGL(group_bwd_kernel, grid, dim3(GT), 0, as_stream(stream), grad_out, sb, sc, sn2, sk, index, (int)C,
+                     (int)N1, (int)N2, (int)K, grad_in);
+  REGNET_LAUNCH_CHECK();
+  return REGNET_OK;
+}
+
+extern "C" int regnet_interpolate_fwd_f32(const float* input, int64_t sb, int64_t sc, int64_t sm,
+                                          const int64_t* index, const float* weight, int64_t B, int64_t C, int64_t M,
+                                          int64_t N, float* out, void* stream) {
+  if (B < 0 || C < 0 || M < 0 || N < 0) return REGNET_ERR_SHAPE;
+  if (B == 0 || C == 0 || N == 0) return REGNET_OK;
+  if (M == 0) return REGNET_ERR_SHAPE;
+  if (!dims_ok(B, C) || N >= (int64_t)1 << 31 || M >= (int64_t)1 << 31) return REGNET_ERR_UNSUPPORTED;
+  if (!input || !index || !weight || !out) return REGNET_ERR_NULL;
+  dim3 grid((unsigned)((N + GT - 1) / GT), (unsigned)((C + CH_PER_BLOCK - 1) / CH_PER_BLOCK), (unsigned)B);
+  hipLaunchKernelGGL(interp_fwd_kernel, grid, dim3(GT), 0, as_stream(stream), input, sb, sc, sm, index, weight,
+                     (int)C, (int)M, (int)N, out);
+  REGNET_LAUNCH_CHECK();
+  return REGNET_OK;
+}
+
+extern "C" int regnet_interpolate_bwd_f32(const float* grad_out, int64_t sb, int64_t sc, int64_t sn,
+                                          const int64_t* index, const float* weight, int64_t B, int64_t C, int64_t M,
+                                          int64_t N, float* grad_in, void* stream) {
+  if (B < 0 || C < 0 || M < 0 || N < 0) return REGNET_ERR_SHAPE;
+  if (B == 0 || C == 0 || M == 0) return REGNET_OK;
+  if (!grad_in) return REGNET_ERR_NULL;
+  hipError_t e = hipMemsetAsync(grad_in, 0, sizeof(float) * (size_t)(B * C * M), as_stream(stream));
+  if (e != hipSuccess) return (int)e;
+  if (N == 0) return REGNET_OK;
+  if (!dims_ok(B, C) || N >= (int64_t)1 << 31 || M >= (int64_t)1 << 31) return REGNET_ERR_UNSUPPORTED;
+  if (!grad_out || !index || !weight) return REGNET_ERR_NULL;
+  dim3 grid((unsigned)((N + GT - 1) / GT), (unsigned)((C + CH_PER_BLOCK - 1) / CH_PER_BLOCK), (unsigned)B);
+  hipLaunchKernelGGL(interp_bwd_kernel, grid, dim3(GT), 0, as_stream(stream), grad_out, sb, sc, sn, index, weight,
+                     (int)C, (int)M, (int)N, grad_in);
+  REGNET_LAUNCH_CHECK();
+  return REGNET_OK;
+}
+
+extern "C" int regnet_gather_knn_fwd_f32(const float* input, int64_t sb, int64_t sc, int64_t sn, const int64_t* index,
+                                         int64_t B, int64_t C, int64_t N, int64_t NI, int64_t K, float* out,
+                                         void* stream) {
+  return regnet_group_points_fwd_f32(input, sb, sc, sn, index, B, C, N, NI, K, out, stream);
+}
+
+extern "C" int regnet_gather_knn_bwd_f32(const float* grad_out, int64_t sb, int64_t sc, int64_t sn2, int64_t sk,
+                                         const int64_t* index, int64_t B, int64_t C, int64_t N, int64_t NI,
+                                         int64_t K, float* grad_in, void* stream) {
+  return regnet_group_points_bwd_f32(grad_out, sb, sc, sn2, sk, index, B, C, N, NI, K, grad_in, stream);
+}

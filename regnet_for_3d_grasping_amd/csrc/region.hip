@@ -1,0 +1,142 @@
+// region.hip -- region grouping between ScoreNet and the grasp-region network (gfx950).
+//
+// Built with -ffp-contract=off (membership tests are discontinuous in the fp32 arithmetic).
+// Reference behaviour restated (paths relative to /root/reference):
+//   radius grouping   dataset_utils/get_regiondataset.py:279-295, :311-352
+//   gripper box crop  multi_model/gripper_region_network.py:508-544
+//   feature gather+max multi_model/gripper_region_network.py:388-395 + utils/pointnet2.py:167
+//
+// The reference builds dense (centres x N) masks with torch and calls torch.nonzero per centre
+// from a Python loop (one device sync each).  Here one wavefront owns one centre / grasp, walks
+// the points 64 at a time and appends the members in ascending index order with a ballot +
+// prefix-popcount, so the host receives every candidate list and count with a single sync and
+// only has to draw the numpy random positions.
+#include "common.h"
+
+#define RG_WAVES 4
+
+// cand[(b*NC + c)*cap + pos] = pos-th point (ascending) of scene b with d2(point, centre c) <= thr.
+__global__ __launch_bounds__(RG_WAVES * 64) void radius_group_kernel(
+    const float* __restrict__ pc, int64_t pb, int64_t pn, const float* __restrict__ ctr, int64_t cb, int64_t cn,
+    int N, int NC, float thr, int64_t cap, int32_t* __restrict__ cand, int32_t* __restrict__ count) {
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * RG_WAVES + (threadIdx.x >> 6);
+  const int b = blockIdx.y;
+  if (c >= NC) return;
+  const float* p = pc + (int64_t)b * pb;
+  const float* q = ctr + (int64_t)b * cb + (int64_t)c * cn;
+  const float cx = q[0], cy = q[1], cz = q[2];
+  int32_t* out = cand + ((int64_t)b * NC + c) * cap;
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  int cnt = 0;
+  for (int j0 = 0; j0 < N; j0 += 64) {
+    const int j = j0 + lane;
+    bool hit = false;
+    if (j < N) {
+      const float* r = p + (int64_t)j * pn;
+      hit = sqdist3(r[0], r[1], r[2], cx, cy, cz) <= thr;  // point minus centre, inclusive
+    }
+    const unsigned long long mask = __ballot(hit);
+    if (hit) {
+      const int pos = cnt + (int)__popcll(mask & lt_mask);
+      if (pos < cap) out[pos] = j;
+    }
+    cnt += (int)__popcll(mask);
+  }
+  if (lane == 0) count[(int64_t)b * NC + c] = cnt;
+}
+
+extern "C" int regnet_radius_group_f32(const float* pc, int64_t pb, int64_t pn, const float* centres, int64_t cb,
+                                       int64_t cn, int64_t B, int64_t N, int64_t NC, float d2_threshold,
+                                       int64_t cap, int32_t* cand, int32_t* count, void* stream) {
+  if (B < 0 || N < 0 || NC < 0 || cap < 0) return REGNET_ERR_SHAPE;
+  if (N >= (int64_t)1 << 31 || B > 65535) return REGNET_ERR_UNSUPPORTED;
+  if (B == 0 || NC == 0) return REGNET_OK;
+  if (!centres || !count || (cap > 0 && !cand) || (N > 0 && !pc)) return REGNET_ERR_NULL;
+  dim3 grid((unsigned)((NC + RG_WAVES - 1) / RG_WAVES), (unsigned)B);
+  hipLaunchKernelGGL(radius_group_kernel, grid, dim3(RG_WAVES * 64), 0, as_stream(stream), pc, pb, pn, centres, cb,
+                     cn, (int)N, (int)NC, d2_threshold, cap, cand, count);
+  REGNET_LAUNCH_CHECK();
+  return REGNET_OK;
+}
+
+// Gripper closing-box membership.  For grasp i: t = R_i * (p - c_i) with rows of R_i =
+// [approach; axis_y; minor_normal] (gripper_region_network.py:506-509); member iff
+// 0 < t.x < xlim_i, |t.y| < ylim_i, |t.z| < zlim (all strict, :523-528).
+__global__ __launch_bounds__(RG_WAVES * 64) void box_crop_kernel(
+    const float* __restrict__ pts, int64_t gb, int64_t gn, const float* __restrict__ centre,
+    const float* __restrict__ rot, const float* __restrict__ xlim, const float* __restrict__ ylim, float zlim,
+    int n, int G, int32_t* __restrict__ cand, int32_t* __restrict__ count) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * RG_WAVES + (threadIdx.x >> 6);
+  if (i >= n) return;
+  const float* p = pts + (int64_t)i * gb;
+  const float cx = centre[i * 3 + 0], cy = centre[i * 3 + 1], cz = centre[i * 3 + 2];
+  float m[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) m[k] = rot[(int64_t)i * 9 + k];
+  const float xl = xlim[i], yl = ylim[i];
+  int32_t* out = cand + (int64_t)i * G;
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  int cnt = 0;
+  for (int j0 = 0; j0 < G; j0 += 64) {
+    const int j = j0 + lane;
+    bool hit = false;
+    if (j < G) {
+      const float* r = p + (int64_t)j * gn;
+      const float dx = r[0] - cx, dy = r[1] - cy, dz = r[2] - cz;
+      const float tx = (m[0] * dx + m[1] * dy) + m[2] * dz;
+      const float ty = (m[3] * dx + m[4] * dy) + m[5] * dz;
+      const float tz = (m[6] * dx + m[7] * dy) + m[8] * dz;
+      hit = tx > 0.f && tx < xl && ty > -yl && ty < yl && tz > -zlim && tz < zlim;
+    }
+    const unsigned long long mask = __ballot(hit);
+    if (hit) out[cnt + (int)__popcll(mask & lt_mask)] = j;
+    cnt += (int)__popcll(mask);
+  }
+  if (lane == 0) count[i] = cnt;
+}
+
+extern "C" int regnet_box_crop_f32(const float* group_points, int64_t gb, int64_t gn, const float* centre,
+                                   const float* rot, const float* xlim, const float* ylim, float zlim, int64_t n,
+                                   int64_t G, int32_t* cand, int32_t* count, void* stream) {
+  if (n < 0 || G < 0) return REGNET_ERR_SHAPE;
+  if (G >= (int64_t)1 << 31 || n >= (int64_t)1 << 31) return REGNET_ERR_UNSUPPORTED;
+  if (n == 0) return REGNET_OK;
+  if (!centre || !rot || !xlim || !ylim || !count || (G > 0 && (!group_points || !cand))) return REGNET_ERR_NULL;
+  dim3 grid((unsigned)((n + RG_WAVES - 1) / RG_WAVES));
+  hipLaunchKernelGGL(box_crop_kernel, grid, dim3(RG_WAVES * 64), 0, as_stream(stream), group_points, gb, gn, centre,
+                     rot, xlim, ylim, zlim, (int)n, (int)G, cand, count);
+  REGNET_LAUNCH_CHECK();
+  return REGNET_OK;
+}
+
+// out[r, ch] = max_g feat[rows[r, g], ch]: the grouped-feature gather fused with MaxPool1d(G).
+// feat is (num_rows, F) row-major (= all_feature.view(B*N, F)); one workgroup per output row,
+// threads across channels so every gathered row is one coalesced F*4-byte read.
+__global__ __launch_bounds__(256) void gather_max_kernel(const float* __restrict__ feat, int64_t num_rows, int F,
+                                                        const int64_t* __restrict__ rows, int G,
+                                                        float* __restrict__ out) {
+  const int64_t r = blockIdx.x;
+  const int64_t* idx = rows + r * G;
+  for (int ch = threadIdx.x; ch < F; ch += 256) {
+    float m = -__builtin_inff();
+    for (int g = 0; g < G; ++g) {
+      const int64_t row = idx[g];
+      if (row >= 0 && row < num_rows) m = fmaxf(m, feat[row * F + ch]);
+    }
+    out[r * F + ch] = m;
+  }
+}
+
+extern "C" int regnet_gather_max_f32(const float* feat, int64_t num_rows, int64_t F, const int64_t* rows, int64_t R,
+                                     int64_t G, float* out, void* stream) {
+  if (num_rows < 0 || F < 0 || R < 0 || G <= 0) return REGNET_ERR_SHAPE;
+  if (F >= (int64_t)1 << 31 || G >= (int64_t)1 << 31 || R >= (int64_t)1 << 31) return REGNET_ERR_UNSUPPORTED;
+  if (R == 0 || F == 0) return REGNET_OK;
+  if (!feat || !rows || !out) return REGNET_ERR_NULL;
+  hipLaunchKernelGGL(gather_max_kernel, dim3((unsigned)R), dim3(256), 0, as_stream(stream), feat, num_rows, (int)F,
+                     rows, (int)G, out);
+  REGNET_LAUNCH_CHECK();
+  return REGNET_OK;
+}

@@ -1,0 +1,255 @@
+"""Grasp-region network + refine stage, forward path (mirror of
+multi_model/gripper_region_network.py:10-44, :361-434, :311-359, :436-610).
+
+Same class / function names, constructor and ``forward`` signatures and the same 16-tuple
+result as the reference.  The data-parallel pieces run on MI355X kernels:
+  * grouped-feature gather + MaxPool1d  -> ``region_ops.gather_max``   (reference :388-395, :334-343)
+  * gripper closing-box membership      -> ``region_ops.box_candidates`` (reference :508-544)
+while the host only draws numpy's random positions in the reference's call order.
+
+Reference quirks that are reproduced on purpose (SURVEY.md §7 "hard parts"):
+  * anchor templates are rounded through fp16 (``.half()``, :586);
+  * the refine stage re-views the pooled (n,256,1) region feature as 128-wide rows (:343);
+  * ``gripper_pc`` / index tensors are created by ``torch.full(..., -1)`` as int64 (:517-520).
+
+Training losses (``ground_grasp`` given; :92-184, :233-309) are plain torch elementwise code
+outside this round's forward hot path and raise NotImplementedError.
+"""
+import math
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import region_ops
+from .pointnet2 import PointNet2Refine, PointNet2TwoStage
+
+
+def _pool_rows(all_feature, rows):
+    """max over the G gathered rows: all_feature (B,N,F), rows (R,G) global row ids -> (R,F,1)."""
+    F = all_feature.shape[2]
+    flat = all_feature.contiguous().view(-1, F)
+    if flat.is_cuda and not torch.is_grad_enabled():
+        return region_ops.gather_max(flat, rows).unsqueeze(-1)
+    # autograd path: the reference's materialised gather followed by a max over the group axis
+    return flat[rows.reshape(-1)].view(rows.shape[0], rows.shape[1], F).max(dim=1)[0].unsqueeze(-1)
+
+
+class GripperRegionNetwork(nn.Module):
+    def __init__(self, training, group_num, gripper_num, grasp_score_threshold, radius, reg_channel):
+        super().__init__()
+        self.group_number = group_num
+        self.templates = _enumerate_templates()
+        self.anchor_number = self.templates.shape[1] * self.templates.shape[2]
+        self.gripper_number = gripper_num
+        self.grasp_score_thre = grasp_score_threshold
+        self.is_training_refine = training
+        self.radius = radius
+        self.reg_channel = reg_channel
+
+        self.extrat_feature_region = PointNet2TwoStage(num_points=group_num, input_chann=6,
+                                                       k_cls=self.anchor_number,
+                                                       k_reg=self.reg_channel * self.anchor_number,
+                                                       k_reg_theta=self.anchor_number)
+        self.extrat_feature_refine = PointNet2Refine(num_points=gripper_num, input_chann=6, k_cls=2,
+                                                     k_reg=self.reg_channel)
+        self.criterion_cos = nn.CosineEmbeddingLoss(reduction="mean")
+        self.criterion_cls = nn.CrossEntropyLoss(reduction="mean")
+        self.smooth_l1_loss = nn.SmoothL1Loss(reduction="mean")
+
+    def _enumerate_anchors(self, centers):
+        """centers (n,3) -> anchors (n, A, 7) = [centre xyz | template r (3) | template theta]
+        (gripper_region_network.py:30-44)."""
+        self.templates = self.templates.to(centers.device)
+        n = centers.shape[0]
+        tmpl = self.templates.float().view(1, self.anchor_number, 4).expand(n, -1, -1)
+        return torch.cat([centers.view(n, 1, 3).expand(-1, self.anchor_number, -1), tmpl], dim=-1)
+
+    def compute_loss(self, first_grasp, anchors, first_cls, ground):
+        """Decode the regression of the arg-max anchor of every centre into a grasp
+        (gripper_region_network.py:69-90):  centre = delta*radius + anchor, orientation
+        re-normalised, theta = pi*(delta + anchor), remaining channels passed through."""
+        if ground is not None:
+            raise NotImplementedError("stage-2 training loss is outside the forward hot path")
+        n = first_grasp.shape[0]
+        gmask = torch.arange(0, n, device=first_grasp.device)
+        pick = torch.max(first_cls, dim=1)[1]
+        sel = pick.view(n, 1, 1)
+        grasp = torch.gather(first_grasp, 1, sel.expand(n, 1, first_grasp.shape[2])).squeeze(1)
+        anchor = torch.gather(anchors.detach(), 1, sel.expand(n, 1, 7)).squeeze(1)
+        axis = grasp[:, 3:6] + anchor[:, 3:6]
+        norm = torch.sqrt(torch.sum(torch.mul(axis, axis), dim=1).add_(1e-12)).view(-1, 1)
+        next_grasp = torch.cat((grasp[:, :3] * self.radius + anchor[:, :3],
+                                torch.div(axis, norm),
+                                np.pi * (grasp[:, 6:7] + anchor[:, 6:7]),
+                                grasp[:, 7:]), dim=-1)
+        return next_grasp, (None, None), (None, None, None, None), None, None, gmask
+
+    def compute_loss_refine(self, next_grasp, next_x_cls, next_x_reg, next_gt):
+        """Apply the refine deltas and select class-1 grasps (gripper_region_network.py:201-215)."""
+        if next_gt is not None:
+            raise NotImplementedError("refine training loss is outside the forward hot path")
+        final_grasp = next_grasp.clone()
+        final_grasp[:, :3] = final_grasp[:, :3] + next_x_reg[:, :3] * self.radius
+        final_grasp[:, 3:] = final_grasp[:, 3:] + next_x_reg[:, 3:]
+        predicted = torch.max(next_x_cls, dim=-1)[1]
+        class_select = torch.nonzero(predicted == 1).view(-1)
+        score_select = torch.nonzero((predicted == 1) & (final_grasp[:, 7] > self.grasp_score_thre)).view(-1)
+        return (final_grasp[class_select].data, final_grasp[score_select].data, next_grasp[class_select].data,
+                class_select, score_select, (None, None), (None, None, None, None))
+
+    def refine_forward(self, pc_group_more_xyz, pc_group_more_index, true_mask, all_feature, group_feature_mp,
+                       next_grasp, gripper_params, next_gt=None):
+        """Crop the gripper closing box out of the large groups, pool the ScoreNet features of
+        the cropped points and refine the grasps (gripper_region_network.py:311-359)."""
+        B, N = all_feature.shape[0], all_feature.shape[1]
+        N_C, N_G_M = pc_group_more_index.shape[1], pc_group_more_index.shape[2]
+        _, _, index_inall, gripper_mask = get_gripper_region_transform(
+            pc_group_more_xyz[true_mask], pc_group_more_index.view(-1, N_G_M)[true_mask], next_grasp,
+            self.gripper_number, gripper_params)
+        out = [None, None, None, None, None, (None, None), (None, None), next_gt]
+        if len(gripper_mask) >= 2:
+            scene = torch.arange(B, device=true_mask.device).view(-1, 1).repeat(1, N_C).view(-1)[true_mask]
+            rows = (index_inall.long() + scene.view(-1, 1) * N)[gripper_mask]
+            gripper_feature = _pool_rows(all_feature, rows)                       # (m, F, 1)
+            region_feature = group_feature_mp.view(-1, 128)[gripper_mask].contiguous()  # the 128-wide re-view quirk
+            next_x_cls, next_x_reg = self.extrat_feature_refine(gripper_feature, region_feature, pooled=True)
+            if next_gt is not None:
+                next_gt = next_gt[gripper_mask]
+            (out[0], out[1], out[2], class_select, score_select, out[5], out[6]) = self.compute_loss_refine(
+                next_grasp[gripper_mask], next_x_cls, next_x_reg, next_gt)
+            if next_gt is not None:
+                next_gt = next_gt[class_select]
+            kept = true_mask.clone()[gripper_mask]
+            out[3], out[4], out[7] = kept[class_select], kept[score_select], next_gt
+        return tuple(out)
+
+    def forward(self, pc_group, pc_group_more, pc_group_index, pc_group_more_index, center_pc, center_pc_index, pc,
+                all_feature, gripper_params, ground_grasp=None, data_path=None):
+        """Shapes as the reference (gripper_region_network.py:361-375); returns its 16-tuple."""
+        B, N_C, N_G, _ = pc_group.shape
+        N = all_feature.shape[1]
+        anchors = self._enumerate_anchors(center_pc[:, :, :3].reshape(-1, 3).float())
+        pc_group_more_xyz = pc_group_more[:, :, :, :6].reshape(B * N_C, -1, 6)
+
+        scene = torch.arange(B, device=pc_group_index.device).view(B, 1)
+        rows = (pc_group_index.long().view(B, N_C * N_G) + scene * N).view(B * N_C, N_G)
+        pooled = _pool_rows(all_feature, rows)                                    # (B*N_C, F, 1)
+        x_cls, x_reg, mp_center_feature = self.extrat_feature_region(pooled, None, pooled=True)
+
+        next_grasp, loss_tuple, correct_tuple, next_gt, _, true_mask = self.compute_loss(x_reg, anchors, x_cls,
+                                                                                        ground_grasp)
+        keep2 = [torch.sum((true_mask < (i + 1) * N_C) & (true_mask >= i * N_C)) for i in range(B)]
+
+        res = (None,) * 5 + (None, None, None)
+        keep3 = keep3_score = None
+        if self.is_training_refine:
+            res = self.refine_forward(pc_group_more_xyz, pc_group_more_index, true_mask, all_feature,
+                                      mp_center_feature, next_grasp.detach(), gripper_params, next_gt)
+            final_mask, final_mask_sthre = res[3], res[4]
+            if final_mask is not None:
+                keep3 = [torch.sum((final_mask < (i + 1) * N_C) & (final_mask >= i * N_C)) for i in range(B)]
+                keep3_score = [torch.sum((final_mask_sthre < (i + 1) * N_C) & (final_mask_sthre >= i * N_C))
+                               for i in range(B)]
+            else:
+                keep3, keep3_score = [0] * B, [0] * B
+        (select_class, select_score, select_class_stage2, final_mask, final_mask_sthre, loss_refine_tuple,
+         correct_refine_tuple, gt) = res
+        return (next_grasp.detach(), keep2, true_mask, loss_tuple, correct_tuple, next_gt, select_class,
+                select_score, select_class_stage2, keep3, keep3_score, final_mask, final_mask_sthre,
+                loss_refine_tuple, correct_refine_tuple, gt)
+
+
+def _unit(v, fallback, eps):
+    """v / (|v| + eps) with the reference's zero-norm fallback rows."""
+    norm = torch.norm(v, dim=1)
+    if eps:
+        norm = norm + eps
+    out = torch.div(v, norm.view(-1, 1))
+    fb = torch.tensor(fallback, dtype=torch.float32, device=v.device)
+    return torch.where(torch.eq(norm, 0).view(-1, 1), fb.view(1, 3).expand_as(out), out)
+
+
+def gripper_frame(grasp):
+    """grasp (n,>=7) = [centre | axis_y | theta | ...] -> centre (n,3), rotation (n,3,3) whose rows
+    are [approach; axis_y; minor_normal] (gripper_region_network.py:447-506)."""
+    n = grasp.shape[0]
+    center = grasp[:, 0:3].float()
+    angle = grasp[:, 6].float()
+    cos_t, sin_t = torch.cos(angle).view(n, 1), torch.sin(angle).view(n, 1)
+    one, zero = torch.ones_like(cos_t), torch.zeros_like(cos_t)
+    R1 = torch.cat((cos_t, zero, -sin_t, zero, one, zero, sin_t, zero, cos_t), dim=1).view(n, 3, 3)
+    axis_y = _unit(grasp[:, 3:6].float(), [0.0, 1.0, 0.0], 1e-12)
+    axis_x = _unit(torch.cat((axis_y[:, 1:2], -axis_y[:, 0:1], zero), 1), [1.0, 0.0, 0.0], 1e-12)
+    axis_z = _unit(torch.cross(axis_x, axis_y, dim=1), [0.0, 0.0, 1.0], 0.0)
+    matrix = torch.bmm(torch.stack((axis_x, axis_y, axis_z), dim=2), R1)
+    approach = _unit(matrix[:, :, 0], [1.0, 0.0, 0.0], 1e-12)
+    minor_normal = torch.cross(approach, axis_y, dim=1)
+    return center, torch.stack((approach, axis_y, minor_normal), dim=1)
+
+
+def _half_extent(value, n, device):
+    """Scalar or per-grasp tensor limit -> (n,) float32 of value/2 (:512-516)."""
+    if isinstance(value, torch.Tensor):
+        return (value.float().view(-1) / 2).to(device).expand(n).contiguous()
+    return torch.full((n,), value / 2, dtype=torch.float32, device=device)
+
+
+def get_gripper_region_transform(group_points, group_index, grasp, region_num, gripper_params):
+    """Points of every group that fall inside the predicted gripper's closing box, resampled to
+    ``region_num`` per grasp (gripper_region_network.py:436-550).
+
+    group_points (n,G,C), group_index (n,G), grasp (n,>=7) ->
+    gripper_pc (n,region_num,C) int64 (the reference's truncating ``torch.full(..., -1)`` quirk),
+    gripper_pc_index (n,region_num), gripper_pc_index_inall (n,region_num), valid grasp ids.
+    A grasp is valid when more than 5 points are in the box; sampling is without replacement
+    when more than ``region_num`` candidates exist, else with replacement."""
+    widths, height, depths = gripper_params
+    n, G, C = group_points.shape
+    dev = group_points.device
+    center, rot = gripper_frame(grasp.to(dev))
+    xlim, ylim = _half_extent(depths, n, dev), _half_extent(widths, n, dev)
+    cand, count = region_ops.box_candidates(group_points, center, rot, xlim, ylim, height / 2)
+
+    counts = count.cpu().numpy()
+    pos = np.zeros((n, region_num), dtype=np.int64)
+    valid = np.zeros((n,), dtype=bool)
+    for i in range(n):
+        k = int(counts[i])
+        if k > region_num:
+            pos[i] = np.random.choice(k, region_num, replace=False)
+        elif k > 5:
+            pos[i] = np.random.choice(k, region_num, replace=True)
+        valid[i] = k > 5
+    pos_t = torch.from_numpy(pos).to(dev)
+    valid_t = torch.from_numpy(valid).to(dev)
+
+    index = torch.gather(cand, 1, pos_t).long()                      # positions inside the group
+    index_inall = torch.gather(group_index.long(), 1, index)
+    picked = torch.gather(group_points, 1, index.unsqueeze(-1).expand(n, region_num, C))
+    local = torch.bmm(rot, (picked[:, :, :3].float() - center.view(n, 1, 3)).permute(0, 2, 1)).permute(0, 2, 1)
+    gripper_pc = torch.cat((local, picked[:, :, 3:]), -1).to(torch.int64)
+
+    minus1 = torch.full((1,), -1, dtype=torch.int64, device=dev)
+    gripper_pc = torch.where(valid_t.view(n, 1, 1), gripper_pc, minus1.view(1, 1, 1))
+    index = torch.where(valid_t.view(n, 1), index, minus1.view(1, 1))
+    index_inall = torch.where(valid_t.view(n, 1), index_inall, minus1.view(1, 1))
+    return gripper_pc, index, index_inall, torch.nonzero(valid_t).view(-1)
+
+
+def _enumerate_templates():
+    """(1,4,1,4) fp16 anchor templates: four (+-1/sqrt3) orientations, theta 0
+    (gripper_region_network.py:552-587).  The fp16 rounding (0.5771484375) is part of the model."""
+    s = math.sqrt(3) / 3
+    t_r = torch.tensor([[s, s, s], [s, s, -s], [s, -s, -s], [s, -s, s]], dtype=torch.float32).view(1, 4, 1, 3)
+    t_theta = torch.zeros(1, 4, 1, 1, dtype=torch.float32)
+    return torch.cat([t_r, t_theta], dim=3).half()
+
+
+def compute_cos_sim(a, b):
+    """1 - cos(a, b) per row, (N,3) x (N,3) -> (N,1) (gripper_region_network.py:589-610)."""
+    eps = 1e-12
+    dot = torch.sum(a * b, dim=1)
+    na = torch.sum(a * a, dim=1) + eps
+    nb = torch.sum(b * b, dim=1) + eps
+    return (1 - dot / torch.sqrt(na * nb)).view(-1, 1)

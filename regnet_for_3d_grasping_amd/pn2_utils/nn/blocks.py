@@ -1,0 +1,119 @@
+"""Conv/FC + BatchNorm + ReLU blocks and the (Shared)MLP stacks built from them.
+
+Mirror of pn2_utils/nn/modules/{conv.py:6-76, linear.py:6-40, mlp.py:8-114}: same class
+names, constructor arguments and sub-module attribute names (``conv``/``fc``, ``bn``, ``relu``),
+hence identical ``state_dict`` keys (``mlp.<i>.conv.weight``, ``mlp.<i>.bn.running_mean`` ...).
+The affine layer is bias-free whenever BN follows (conv.py:24,64); BN uses eps 1e-5 and the
+given momentum; conv weights keep torch's default init unless ``init_weights(fn)`` is called.
+"""
+import torch.nn.functional as F
+from torch import nn
+
+from .init import init_bn
+
+
+class _AffineBNReLU(nn.Module):
+    """``x -> relu(bn(affine(x)))`` with optional bn / relu; ``_affine_name`` is 'conv' or 'fc'."""
+
+    _affine_name = "conv"
+
+    def _assemble(self, affine, bn, relu):
+        setattr(self, self._affine_name, affine)
+        self.bn = bn
+        self.relu = nn.ReLU(inplace=True) if relu else None
+
+    def forward(self, x):
+        x = getattr(self, self._affine_name)(x)
+        if self.bn is not None:
+            x = self.bn(x)
+        if self.relu is not None:
+            x = self.relu(x)
+        return x
+
+    def init_weights(self, init_fn=None):
+        if init_fn is not None:
+            init_fn(getattr(self, self._affine_name))
+        if self.bn is not None:
+            init_bn(self.bn)
+
+
+class Conv1d(_AffineBNReLU):
+    def __init__(self, in_channels, out_channels, kernel_size, relu=True, bn=True, bn_momentum=0.1, **kwargs):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self._assemble(nn.Conv1d(in_channels, out_channels, kernel_size, bias=(not bn), **kwargs),
+                       nn.BatchNorm1d(out_channels, momentum=bn_momentum) if bn else None, relu)
+        self.init_weights()
+
+
+class Conv2d(_AffineBNReLU):
+    def __init__(self, in_channels, out_channels, kernel_size, relu=True, bn=True, bn_momentum=0.1, **kwargs):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self._assemble(nn.Conv2d(in_channels, out_channels, kernel_size, bias=(not bn), **kwargs),
+                       nn.BatchNorm2d(out_channels, momentum=bn_momentum) if bn else None, relu)
+        self.init_weights()
+
+
+class FC(_AffineBNReLU):
+    _affine_name = "fc"
+
+    def __init__(self, in_channels, out_channels, relu=True, bn=True, bn_momentum=0.1):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self._assemble(nn.Linear(in_channels, out_channels, bias=(not bn)),
+                       nn.BatchNorm1d(out_channels, momentum=bn_momentum) if bn else None, relu)
+        # note: the reference FC does not call init_weights() in its constructor (linear.py:18-28)
+
+
+class _Stack(nn.ModuleList):
+    """A ModuleList of blocks applied in order, with functional dropout after every block in
+    training mode only (mlp.py:41-47, :95-107)."""
+
+    def _dropout(self, x):
+        return F.dropout(x, p=self.dropout_prob, training=True)
+
+    def forward(self, x):
+        for block in self:
+            x = block(x)
+            if self.training and self.dropout_prob > 0.0:
+                x = self._dropout(x)
+        return x
+
+    def init_weights(self, init_fn=None):
+        for block in self:
+            block.init_weights(init_fn)
+
+    def extra_repr(self):
+        return "dropout_prob={}".format(self.dropout_prob) if self.dropout_prob > 0.0 else ""
+
+
+class MLP(_Stack):
+    def __init__(self, in_channels, mlp_channels, dropout_prob=0.0, bn=True, bn_momentum=0.1):
+        super().__init__()
+        assert dropout_prob >= 0.0
+        self.in_channels, self.out_channels, self.dropout_prob = in_channels, mlp_channels[-1], dropout_prob
+        for width in mlp_channels:
+            self.append(FC(in_channels, width, relu=True, bn=bn, bn_momentum=bn_momentum))
+            in_channels = width
+
+
+class SharedMLP(_Stack):
+    """1x1-conv MLP shared over one (``ndim=1``: (B,C,N)) or two (``ndim=2``: (B,C,N,K)) point axes."""
+
+    def __init__(self, in_channels, mlp_channels, ndim=1, dropout_prob=0.0, bn=True, bn_momentum=0.1):
+        super().__init__()
+        if ndim not in (1, 2):
+            raise ValueError("SharedMLP only supports ndim=(1, 2).")
+        assert dropout_prob >= 0.0
+        self.in_channels, self.out_channels = in_channels, mlp_channels[-1]
+        self.ndim, self.dropout_prob = ndim, dropout_prob
+        block = Conv1d if ndim == 1 else Conv2d
+        for width in mlp_channels:
+            self.append(block(in_channels, width, 1, relu=True, bn=bn, bn_momentum=bn_momentum))
+            in_channels = width
+
+    def _dropout(self, x):
+        if self.ndim == 1:
+            return F.dropout(x, p=self.dropout_prob, training=True)
+        return F.dropout2d(x, p=self.dropout_prob, training=True)

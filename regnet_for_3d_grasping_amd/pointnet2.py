@@ -1,0 +1,163 @@
+"""Network definitions (mirror of multi_model/utils/pointnet2.py:12-255).
+
+``PointNet2Seg`` = the ScoreNet backbone (3 SA + 3 FP + shared-MLP head),
+``PointNet2TwoStage`` = grasp-region head, ``PointNet2Refine`` = refine head.  Attribute names
+match the reference so the 127 / 86 ``state_dict`` keys are identical.
+"""
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .pn2_utils.modules import PointNetSAModule, PointnetFPModule
+from .pn2_utils.nn import SharedMLP
+
+# hyper-parameters hard-coded by the reference (pointnet2.py:40-46)
+_SA_CENTROIDS = (5120, 1024, 256)
+_SA_RADIUS = (0.02, 0.08, 0.32)
+_SA_NEIGHBOURS = (64, 64, 64)
+_SA_CHANNELS = ((128, 128, 256), (256, 256, 512), (512, 512, 1024))
+_FP_CHANNELS = ((1024, 1024), (512, 512), (256, 256, 256))
+_FP_NEIGHBOURS = (3, 3, 3)
+_SEG_CHANNELS = (512, 256, 256, 128)
+
+
+class PointNet2Seg(nn.Module):
+    """points (B,6,N) -> (fp3 feature (B,256,N), score (B,N)).
+
+    Note the first return value is the LAST FP output (256 ch), not the 128-ch head
+    activation (pointnet2.py:121)."""
+
+    _SA_MODULE = PointNetSAModule
+    _FP_MODULE = PointnetFPModule
+
+    def __init__(self, input_chann=3, k_score=1, k_obj=2, add_channel_flag=False, dropout_prob=0.5):
+        super().__init__()
+        self.k_score = k_score
+        width = input_chann - 3
+        skip = [width]
+        self.sa_modules = nn.ModuleList()
+        for m, r, k, channels in zip(_SA_CENTROIDS, _SA_RADIUS, _SA_NEIGHBOURS, _SA_CHANNELS):
+            self.sa_modules.append(self._SA_MODULE(in_channels=width, mlp_channels=channels, num_centroids=m,
+                                                   radius=r, num_neighbours=k, use_xyz=True))
+            width = channels[-1]
+            skip.append(width)
+        self.fp_modules = nn.ModuleList()
+        for level, (channels, k) in enumerate(zip(_FP_CHANNELS, _FP_NEIGHBOURS)):
+            self.fp_modules.append(self._FP_MODULE(in_channels=width + skip[-2 - level], mlp_channels=channels,
+                                                   num_neighbors=k))
+            width = channels[-1]
+        self.mlp = SharedMLP(width * 3 if add_channel_flag else width, _SEG_CHANNELS, ndim=1,
+                             dropout_prob=dropout_prob)
+        self.conv_score = nn.Conv1d(_SEG_CHANNELS[-1], self.k_score, 1)
+        self.bn_score = nn.BatchNorm1d(self.k_score)
+        self.sigmoid = nn.Sigmoid()
+
+    def forward(self, points, add_channel1=None, add_channel2=None):
+        B, _, N = points.size()
+        xyz_stack, feat_stack = [points[:, :3, :]], [points[:, 3:6, :]]
+        for sa in self.sa_modules:
+            xyz, feat = sa(xyz_stack[-1], feat_stack[-1])
+            xyz_stack.append(xyz)
+            feat_stack.append(feat)
+
+        sparse_xyz, sparse_feature = xyz_stack[-1], feat_stack[-1]
+        for level, fp in enumerate(self.fp_modules):
+            dense_xyz = xyz_stack[-2 - level]
+            sparse_feature = fp(dense_xyz, sparse_xyz, feat_stack[-2 - level], sparse_feature)
+            sparse_xyz = dense_xyz
+
+        if add_channel1 is not None and add_channel2 is not None:
+            extra = [c.view(B, 1, N).repeat(1, sparse_feature.shape[1], 1).float() for c in (add_channel1, add_channel2)]
+            sparse_feature = torch.cat([sparse_feature] + extra, dim=1)
+
+        from . import fused
+        if fused.usable(self, sparse_feature):
+            return sparse_feature, fused.head_forward(self, sparse_feature)
+        x = self.bn_score(self.conv_score(self.mlp(sparse_feature)))
+        score = self.sigmoid(x.transpose(2, 1).contiguous()).view(B, N)
+        return sparse_feature, score
+
+
+class PointNet2TwoStage(nn.Module):
+    """Grasp-region head (pointnet2.py:123-197): max-pool the grouped ScoreNet features of each
+    centre, then a class branch (k_cls anchors) and a regression branch (k_reg values)."""
+
+    def __init__(self, num_points, input_chann, k_cls, k_reg, k_reg_theta, add_channel_flag=False):
+        super().__init__()
+        self.num_points, self.k_reg, self.k_cls = num_points, k_reg, k_cls
+        self.k_reg_no_anchor = self.k_reg // self.k_cls
+        self.k_reg_theta = k_reg_theta
+
+        self.conv = nn.Conv1d(256 * 3 if add_channel_flag else 256, 1024, 1)
+        self.bn = nn.BatchNorm1d(1024)
+        # registration order below fixes the state_dict key order (pointnet2.py:139-156)
+        self.conv_cls2 = nn.Conv1d(1024, 256, 1)
+        self.conv_cls3 = nn.Conv1d(256, 128, 1)
+        self.linear_cls = nn.Linear(128, self.k_cls)  # never used in forward (reference quirk)
+        self.conv_cls4 = nn.Conv1d(128, self.k_cls, 1)
+        self.bn_cls2 = nn.BatchNorm1d(256)
+        self.bn_cls3 = nn.BatchNorm1d(128)
+        self.bn_cls4 = nn.BatchNorm1d(self.k_cls)
+        self.conv_reg2 = nn.Conv1d(1024, 256, 1)
+        self.conv_reg3 = nn.Conv1d(256, 128, 1)
+        self.conv_reg4 = nn.Conv1d(128, self.k_reg, 1)
+        self.bn_reg2 = nn.BatchNorm1d(256)
+        self.bn_reg3 = nn.BatchNorm1d(128)
+        self.bn_reg4 = nn.BatchNorm1d(self.k_reg)
+
+        self.mp1 = nn.MaxPool1d(num_points)
+        self.ap = nn.AdaptiveAvgPool1d(1)
+        self.sigmod = nn.Sigmoid()
+
+    def _branch(self, x, tag):
+        for i in (2, 3):
+            x = F.relu(getattr(self, "bn_%s%d" % (tag, i))(getattr(self, "conv_%s%d" % (tag, i))(x)))
+        return getattr(self, "bn_%s4" % tag)(getattr(self, "conv_%s4" % tag)(x))
+
+    def forward(self, xyz, feature, pooled=False):
+        """xyz: grouped features (n, 256, num_points) -- or, with ``pooled=True``, the already
+        max-pooled (n, 256, 1) tensor produced by the fused gather+max kernel."""
+        mp_x = xyz if pooled else self.mp1(xyz)
+        if feature is not None:
+            mp_x = torch.cat((mp_x, feature.view(feature.shape[0], feature.shape[1], 1)), dim=1)
+        x = F.relu(self.bn(self.conv(mp_x)))
+        x_cls = self._branch(x, "cls")
+        n, c, _ = x_cls.size()
+        x_cls = x_cls.view(n, c)
+        x_reg = self._branch(x, "reg").view(n, -1, self.k_reg_no_anchor)
+        x_reg[:, :, 7:] = self.sigmod(x_reg[:, :, 7:])
+        return x_cls, x_reg, mp_x
+
+
+class PointNet2Refine(nn.Module):
+    """Refine head (pointnet2.py:199-255): pooled gripper-box feature (+ region feature) ->
+    2-way class and k_reg deltas."""
+
+    def __init__(self, num_points=2500, input_chann=3, k_cls=2, k_reg=8):
+        super().__init__()
+        self.num_points, self.k_reg, self.k_cls = num_points, k_reg, k_cls
+        self.conv_formal = nn.Conv1d(384, 1024, 1)
+        self.bn_formal = nn.BatchNorm1d(1024)
+        self.conv_formal_cls2 = nn.Conv1d(1024, 128, 1)
+        self.conv_formal_cls3 = nn.Conv1d(128, self.k_cls, 1)
+        self.bn_formal_cls2 = nn.BatchNorm1d(128)
+        self.bn_formal_cls3 = nn.BatchNorm1d(self.k_cls)
+        self.conv_formal_reg2 = nn.Conv1d(1024, 128, 1)
+        self.conv_formal_reg3 = nn.Conv1d(128, self.k_reg, 1)
+        self.bn_formal_reg2 = nn.BatchNorm1d(128)
+        self.bn_formal_reg3 = nn.BatchNorm1d(self.k_reg)
+        self.mp1 = nn.MaxPool1d(num_points)
+        self.ap = nn.AdaptiveAvgPool1d(1)
+        self.sigmoid = nn.Sigmoid()
+
+    def _branch(self, x, tag):
+        x = F.relu(getattr(self, "bn_formal_%s2" % tag)(getattr(self, "conv_formal_%s2" % tag)(x)))
+        x = getattr(self, "bn_formal_%s3" % tag)(getattr(self, "conv_formal_%s3" % tag)(x))
+        return x.view(x.shape[0], x.shape[1])
+
+    def forward(self, gripper_feature, group_feature, pooled=False):
+        x = gripper_feature if pooled else self.mp1(gripper_feature)
+        if group_feature is not None:
+            x = torch.cat((x, group_feature.view(group_feature.shape[0], group_feature.shape[1], 1)), dim=1)
+        x = F.relu(self.bn_formal(self.conv_formal(x)))
+        return self._branch(x, "cls"), self._branch(x, "reg")

@@ -1,0 +1,78 @@
+"""Python binding of the region-grouping kernels (csrc/region.hip): radius candidates, gripper
+closing-box candidates and the fused feature gather + max-pool.  GPU tensors only."""
+import numpy as np
+import torch
+
+from . import _lib
+from .pn2_ext import _need_f32, _need_i64, _stream
+
+_check = _lib.check
+_L = _lib.lib
+
+
+def sqrt_le_threshold(radius):
+    """Largest float32 ``T`` such that ``float32(sqrt(T)) <= float32(radius)``.
+
+    The reference tests ``torch.sqrt(d2) <= R`` (get_regiondataset.py:293-294).  Correctly
+    rounded sqrt is monotonic, so that set equals ``{d2 <= T}``; comparing squared distances with
+    ``T`` gives the same members without depending on the device's sqrt rounding."""
+    r = np.float32(radius)
+    if not r >= 0:
+        return float("-inf")
+    t = np.float32(np.float64(r) * np.float64(r))
+    inf = np.float32(np.inf)
+    while np.sqrt(t) > r:
+        t = np.nextafter(t, -inf, dtype=np.float32)
+    while np.sqrt(np.nextafter(t, inf, dtype=np.float32)) <= r:
+        t = np.nextafter(t, inf, dtype=np.float32)
+    return float(t)
+
+
+def radius_candidates(pc, centres, radius):
+    """pc (B,N,C>=3), centres (B,Nc,C'>=3), radius (float, already float32-rounded) ->
+    cand (B,Nc,N) int32 ascending member indices (first ``count`` entries valid), count (B,Nc) int32."""
+    _need_f32(pc, "pc")
+    _need_f32(centres, "centres")
+    if pc.stride(2) != 1 or centres.stride(2) != 1:
+        pc, centres = pc.contiguous(), centres.contiguous()
+    B, N, _ = pc.shape
+    Nc = centres.shape[1]
+    with torch.cuda.device(pc.device):
+        cand = torch.empty((B, Nc, max(N, 1)), dtype=torch.int32, device=pc.device)
+        count = torch.empty((B, Nc), dtype=torch.int32, device=pc.device)
+        _check(_L.regnet_radius_group_f32(pc.data_ptr(), pc.stride(0), pc.stride(1), centres.data_ptr(),
+                                          centres.stride(0), centres.stride(1), B, N, Nc,
+                                          sqrt_le_threshold(radius), cand.size(2), cand.data_ptr(), count.data_ptr(),
+                                          _stream(pc)), "radius_group")
+    return cand, count
+
+
+def box_candidates(group_points, centre, rot, xlim, ylim, zlim):
+    """group_points (n,G,C>=3), centre (n,3), rot (n,3,3), xlim/ylim (n) float32, zlim float ->
+    cand (n,G) int32 ascending in-box positions, count (n) int32."""
+    _need_f32(group_points, "group_points")
+    n, G, _ = group_points.shape
+    gp = group_points if group_points.stride(2) == 1 else group_points.contiguous()
+    centre, rot = centre.contiguous().float(), rot.contiguous().float()
+    xlim, ylim = xlim.contiguous().float(), ylim.contiguous().float()
+    with torch.cuda.device(gp.device):
+        cand = torch.empty((n, max(G, 1)), dtype=torch.int32, device=gp.device)
+        count = torch.empty((n,), dtype=torch.int32, device=gp.device)
+        _check(_L.regnet_box_crop_f32(gp.data_ptr(), gp.stride(0), gp.stride(1), centre.data_ptr(), rot.data_ptr(),
+                                      xlim.data_ptr(), ylim.data_ptr(), float(zlim), n, G, cand.data_ptr(),
+                                      count.data_ptr(), _stream(gp)), "box_crop")
+    return cand, count
+
+
+def gather_max(feature_rows, rows):
+    """feature_rows (R_all,F) contiguous, rows (R,G) int64 global row ids -> (R,F) max over G."""
+    _need_f32(feature_rows, "feature_rows")
+    _need_i64(rows, "rows")
+    feature_rows, rows = feature_rows.contiguous(), rows.contiguous()
+    R, G = rows.shape
+    F = feature_rows.shape[1]
+    with torch.cuda.device(feature_rows.device):
+        out = torch.empty((R, F), dtype=torch.float32, device=feature_rows.device)
+        _check(_L.regnet_gather_max_f32(feature_rows.data_ptr(), feature_rows.shape[0], F, rows.data_ptr(), R, G,
+                                        out.data_ptr(), _stream(feature_rows)), "gather_max")
+    return out
