@@ -1,0 +1,257 @@
+#!/usr/bin/env python
+"""bench.py -- REGNet forward hot path on MI355X.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the forward hot path (ScoreNet -> region grouping -> grasp-region +
+refine network, eval mode) over one batch of synthetic 25 600-point scenes that is already
+resident in HBM.  Workload = BASELINE.json configs[2] (batch 8 per GPU).  Scenes are independent,
+so ranks shard them with no data-path collective ("scaling": "weak"); value = scenes processed
+by all ranks / max-over-ranks wall time.
+
+Rank 0 prints ONE JSON line with the metric plus
+  "roofline":     the dominant kernel of this run, timed with HIP events inside the timed region;
+  "cpu_baseline": the same forward on the host CPU through the C oracle (oracle/, kind "port"),
+                  on a bounded sample (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32-input MFMA peak (same as the fp32 vector peak)
+SCORENET_GFLOP_PER_SCENE = {25600: 148.27, 51200: 180.20}  # SURVEY.md §8(d), 2*MAC of every 1x1 conv
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=8, help="scenes per GPU per step (configs[2]: 8)")
+    ap.add_argument("--points", type=int, default=25600)
+    ap.add_argument("--cpu-scenes", type=int, default=2, help="scenes timed for cpu_baseline (0 = skip)")
+    ap.add_argument("--score-only", action="store_true", help="configs[1]: ScoreNet forward only")
+    return ap.parse_args()
+
+
+class OpTimer:
+    """Brackets every native-op call of the product package with HIP events on the stream the
+    kernel is launched on (torch's current stream), without synchronising."""
+
+    def __init__(self):
+        self.records = []  # (name, meta, start_event, end_event)
+        self.enabled = False
+
+    def wrap(self, module, name, meta_fn):
+        orig = getattr(module, name)
+
+        def timed(*a, **k):
+            if not self.enabled:
+                return orig(*a, **k)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            out = orig(*a, **k)
+            e.record()
+            self.records.append((name, meta_fn(*a, **k), s, e))
+            return out
+        setattr(module, name, timed)
+
+    def summary(self):
+        agg = {}
+        for name, meta, s, e in self.records:
+            key = (name, meta)
+            ms = s.elapsed_time(e)
+            tot, cnt = agg.get(key, (0.0, 0))
+            agg[key] = (tot + ms, cnt + 1)
+        return agg
+
+
+def install_timers(timer):
+    import regnet_for_3d_grasping_amd.pn2_utils.function as fn
+    from regnet_for_3d_grasping_amd import region_ops
+    import regnet_for_3d_grasping_amd.get_regiondataset as grd
+    import regnet_for_3d_grasping_amd.gripper_region_network as grn
+    ext = fn.pn2_ext
+    timer.wrap(ext, "farthest_point_sample", lambda p, m: ("B%d N%d M%d" % (p.size(0), p.size(2), m)))
+    timer.wrap(ext, "ball_query", lambda p, c, r, k: ("B%d N%d M%d K%d" % (p.size(0), p.size(2), c.size(2), k)))
+    timer.wrap(ext, "point_search", lambda q, k, n: ("B%d Q%d K%d" % (q.size(0), q.size(2), k.size(2))))
+    timer.wrap(ext, "group_points_forward", lambda x, i: ("B%d C%d M%d K%d" % (x.size(0), x.size(1), i.size(1), i.size(2))))
+    timer.wrap(ext, "interpolate_forward", lambda x, i, w: ("B%d C%d M%d N%d" % (x.size(0), x.size(1), x.size(2), i.size(1))))
+    timer.wrap(region_ops, "radius_candidates", lambda pc, c, r: ("B%d N%d C%d" % (pc.size(0), pc.size(1), c.size(1))))
+    timer.wrap(region_ops, "box_candidates", lambda g, *a: ("n%d G%d" % (g.size(0), g.size(1))))
+    timer.wrap(region_ops, "gather_max", lambda f, r: ("R%d G%d F%d" % (r.size(0), r.size(1), f.size(1))))
+    from regnet_for_3d_grasping_amd import fused
+    for name, meta in getattr(fused, "TIMED_OPS", {}).items():
+        timer.wrap(fused, name, meta)
+    assert grd.region_ops is region_ops and grn.region_ops is region_ops
+
+
+def algorithmic_work(name, meta):
+    """(bound, units) of one launch: HBM bytes for the scan/gather kernels (SURVEY.md §8d, int64
+    indices, op-API granularity), flops for the shared-MLP contraction."""
+    d = {}
+    for tok in meta.split():
+        i = 0
+        while i < len(tok) and not tok[i].isdigit():
+            i += 1
+        d[tok[:i]] = int(tok[i:])
+    if name == "farthest_point_sample":
+        return "hbm", d["B"] * (12 * d["N"] + 8 * d["M"])
+    if name == "ball_query":
+        return "hbm", d["B"] * (12 * d["N"] + 12 * d["M"] + 8 * d["M"] * d["K"] + 8 * d["M"])
+    if name == "point_search":
+        return "hbm", d["B"] * (12 * d["Q"] + 12 * d["K"] + 36 * d["Q"])
+    if name == "group_points_forward":
+        return "hbm", d["B"] * (8 * d["M"] * d["K"] + 8 * d["C"] * d["M"] * d["K"])
+    if name == "interpolate_forward":
+        return "hbm", d["B"] * (4 * d["C"] * d["M"] + 36 * d["N"] + 4 * d["C"] * d["N"])
+    if name == "radius_candidates":
+        return "hbm", d["B"] * (24 * d["N"] + 4 * d["C"] * d["N"])
+    if name == "gather_max":
+        return "hbm", d["R"] * d["G"] * d["F"] * 4 + d["R"] * d["F"] * 4
+    if name == "box_candidates":
+        return "hbm", d["n"] * d["G"] * 28
+    if "flop" in d:
+        return "mfma", d["flop"]
+    return "hbm", 0
+
+
+def cpu_baseline(args, n_scenes):
+    """The same forward on the host CPU: the host-side mirror driven by the C oracle (OpenMP) and
+    torch-CPU 1x1 convs.  Bounded sample: ``n_scenes`` scenes of the bench workload, batch 1."""
+    from oracle.install import oracle_backend
+    from regnet_for_3d_grasping_amd import pipeline, synthetic
+    threads = torch.get_num_threads()
+    score_net, region_net = pipeline.build_models("cpu")
+    pc0 = synthetic.make_batch(1000, 1, args.points)
+    with oracle_backend():
+        synthetic.calibrate_score_head(score_net, pc0)
+        np.random.seed(0)
+        t0 = time.perf_counter()
+        for i in range(n_scenes):
+            pc = pc0 if i == 0 else synthetic.make_batch(1000 + i, 1, args.points)
+            t1 = time.perf_counter()
+            pipeline.forward_scenes(score_net, region_net, pc, with_region=not args.score_only)
+            if i == 0:
+                first = time.perf_counter() - t1
+        dt = time.perf_counter() - t0
+    return {"value": n_scenes / dt, "unit": "scenes/s", "cores": threads, "kind": "port",
+            "sample": "%d scene(s) x %d pts, batch 1, eval forward (%s), oracle C kernels (OpenMP) + torch-CPU convs, "
+                      "%.1f s total; host %s" % (n_scenes, args.points,
+                                                 "ScoreNet" if args.score_only else "ScoreNet+grouping+GRN+refine", dt,
+                                                 _cpu_model())}
+
+
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return "%s x%d" % (line.split(":", 1)[1].strip(), os.cpu_count())
+    except OSError:
+        pass
+    return "unknown x%d" % (os.cpu_count() or 0)
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    from regnet_for_3d_grasping_amd import pipeline, synthetic
+    timer = OpTimer()
+    install_timers(timer)
+
+    score_net, region_net = pipeline.build_models(dev)
+    # each rank owns its shard of independent scenes: rank r holds scenes r*B .. r*B+B-1
+    pc = synthetic.make_batch(1000 + rank * args.batch, args.batch, args.points, device=dev)
+    synthetic.calibrate_score_head(score_net, pc)
+    np.random.seed(1234 + rank)
+
+    def step():
+        return pipeline.forward_scenes(score_net, region_net, pc, with_region=not args.score_only)
+
+    def fence():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    timer.enabled = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    fence()
+    dt = time.perf_counter() - t0
+    timer.enabled = False
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        total_scenes = args.batch * args.steps * world
+        agg = timer.summary()
+        by_time = sorted(agg.items(), key=lambda kv: -kv[1][0])
+        kernels = [{"op": k[0], "shape": k[1], "calls": c, "avg_ms": round(tot / c, 4), "total_ms": round(tot, 3)}
+                   for k, (tot, c) in by_time]
+        roofline = None
+        if by_time:
+            (name, meta), (tot, cnt) = by_time[0]
+            bound, units = algorithmic_work(name, meta)
+            avg_s = tot / cnt / 1e3
+            if bound == "hbm":
+                achieved, peak, unit = units / avg_s / 1e9, HBM_PEAK_GBS, "GB/s"
+            else:
+                achieved, peak, unit = units / avg_s / 1e12, MFMA_F32_PEAK_TFLOPS, "TFLOP/s"
+            roofline = {"bound": bound, "achieved": round(achieved, 4), "peak": peak, "unit": unit,
+                        "frac": round(achieved / peak, 6), "traffic": None, "kernel": name, "shape": meta,
+                        "avg_launch_ms": round(tot / cnt, 4), "launches": cnt,
+                        "algorithmic_units_per_launch": units}
+        res = {
+            "metric": "scenes/sec (25 600-pt ScoreNet+GRN fwd)", "value": round(total_scenes / dt, 3),
+            "unit": "scenes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": ("configs[1]: ScoreNet forward" if args.score_only else
+                                    "configs[2]: ScoreNet+GraspRegionNet+RefineNet forward") +
+                                   ", %d-pt synthetic scenes, batch=%d per GPU, eval" % (args.points, args.batch),
+                       "points": args.points, "batch_per_gpu": args.batch, "global_batch": args.batch * world,
+                       "parallelism": "scene-sharded x%d (no data-path collective)" % world,
+                       "scorenet_gflop_per_scene": SCORENET_GFLOP_PER_SCENE.get(args.points)},
+            "roofline": roofline,
+            "mlp_tflops": round(SCORENET_GFLOP_PER_SCENE.get(args.points, 0.0) * total_scenes / world / dt / 1e3, 3),
+            "kernels": kernels[:12],
+            "grasps_last_step": int(out["next_grasp"].shape[0]) if "next_grasp" in out else None,
+        }
+        if world == 1 and args.cpu_scenes > 0:
+            res["cpu_baseline"] = cpu_baseline(args, args.cpu_scenes)
+            res["speedup_vs_cpu_baseline"] = round(res["value"] / res["cpu_baseline"]["value"], 1)
+        print(json.dumps(res))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

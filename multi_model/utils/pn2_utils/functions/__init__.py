@@ -1,0 +1,1 @@
+"""Import-path alias: the reference's module path, served by regnet_for_3d_grasping_amd."""

@@ -77,3 +77,29 @@ def seeded_state_dict(module, seed):
             val = rng.normal(0.0, 0.05, shape)
         out[key] = torch.from_numpy(np.asarray(val)).to(ref.dtype)
     return out
+
+
+def calibrate_score_head(score_net, pc):
+    """Set ``bn_score``'s running statistics to those of ``conv_score``'s output on ``pc`` (and its
+    affine to 2/0) so that eval-mode scores straddle the 0.5 centre-selection threshold instead of
+    collapsing on one side.  Returns (mean, var)."""
+    seg = score_net.extrat_featurePN2
+    grabbed = {}
+    hook = seg.conv_score.register_forward_hook(lambda m, i, o: grabbed.__setitem__("x", o.detach()))
+    from . import fused
+    was = fused.ENABLED
+    fused.ENABLED = False  # the hook needs the module-granular head
+    try:
+        with torch.no_grad():
+            score_net(pc)
+    finally:
+        fused.ENABLED = was
+        hook.remove()
+    x = grabbed["x"]
+    mean, var = float(x.mean()), float(x.var(unbiased=False))
+    with torch.no_grad():
+        seg.bn_score.running_mean.fill_(mean)
+        seg.bn_score.running_var.fill_(var)
+        seg.bn_score.weight.fill_(2.0)
+        seg.bn_score.bias.fill_(0.0)
+    return mean, var

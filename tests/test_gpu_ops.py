@@ -1,0 +1,269 @@
+"""GPU parity tests proper: every op of the HIP path, called through the C ABI (via the
+``pn2_ext`` binding), against the CPU oracle on the same seeded inputs.
+
+Bar: bit-exact for every index / count tensor; floats within the tolerance written in each test.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ext():
+    from regnet_for_3d_grasping_amd import pn2_ext
+    return pn2_ext
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import pn2_ext_oracle
+    return pn2_ext_oracle
+
+
+def cloud(seed, B, N, dup=0.0, grid=None):
+    """(B,3,N) float32.  dup: fraction of points that are exact duplicates of earlier ones;
+    grid: snap coordinates to a lattice so equal distances (ties) are frequent."""
+    rng = np.random.default_rng(seed)
+    p = rng.uniform(-0.4, 0.4, (B, N, 3)).astype(np.float32)
+    if grid:
+        p = (np.round(p / grid) * grid).astype(np.float32)
+    if dup > 0:
+        for b in range(B):
+            k = int(N * dup)
+            if k and N > 1:
+                dst = rng.choice(N, k, replace=False)
+                src = rng.integers(0, N, k)
+                p[b, dst] = p[b, src]
+    return torch.from_numpy(p).transpose(1, 2)  # (B,3,N) view of an AoS buffer (stride 3)
+
+
+def layouts(x):
+    """The same (B,3,N) values as: AoS view (as built), SoA contiguous, and the stride-6 view
+    ScoreNet passes (pc[:, :, :6].permute(0, 2, 1)[:, :3, :])."""
+    B, _, N = x.shape
+    six = torch.zeros(B, N, 6)
+    six[:, :, :3] = x.transpose(1, 2)
+    return [x, x.contiguous(), six.permute(0, 2, 1)[:, :3, :]]
+
+
+FPS_CASES = [  # (B, N, M, dup, grid)
+    (2, 1024, 256, 0, None), (2, 5120, 1024, 0, None), (1, 6144, 5120, 0, None), (2, 1, 1, 0, None),
+    (3, 20, 7, 0, None), (1, 64, 64, 0, None), (2, 300, 300, 0.3, None), (2, 2048, 512, 0.5, None),
+    (2, 4096, 1024, 0, 0.05), (1, 700, 200, 0, 0.1), (1, 17, 17, 0.5, 0.2), (1, 9000, 700, 0.2, 0.02),
+    (1, 13000, 300, 0, None), (1, 20000, 300, 0.1, None),
+]
+
+
+@pytest.mark.parametrize("B,N,M,dup,grid", FPS_CASES)
+def test_fps_bit_exact(ext, orc, B, N, M, dup, grid):
+    x = cloud(100 + N + M, B, N, dup, grid)
+    want = orc.farthest_point_sample(x, M)
+    for v in layouts(x):
+        got = ext.farthest_point_sample(v.to(DEV), M)
+        assert got.dtype == torch.int64 and tuple(got.shape) == (B, M)
+        assert torch.equal(got.cpu(), want), "FPS mismatch (N=%d M=%d)" % (N, M)
+
+
+def test_fps_all_identical_points(ext, orc):
+    x = torch.ones(2, 3, 130) * 0.25
+    assert torch.equal(ext.farthest_point_sample(x.to(DEV), 40).cpu(), orc.farthest_point_sample(x, 40))
+
+
+def test_fps_full_size_25600(ext, orc):
+    from regnet_for_3d_grasping_amd import synthetic
+    pc = synthetic.make_batch(1000, 2, 25600)
+    x = pc.permute(0, 2, 1)[:, :3, :]
+    got = ext.farthest_point_sample(x.to(DEV), 5120).cpu()
+    assert torch.equal(got, orc.farthest_point_sample(x, 5120))
+    for b in range(2):  # property: FPS of distinct points never repeats an index
+        assert len(set(got[b].tolist())) == 5120
+
+
+def test_fps_streaming_path_above_resident_limit(ext, orc):
+    x = cloud(7, 1, 30000)
+    assert torch.equal(ext.farthest_point_sample(x.to(DEV), 200).cpu(), orc.farthest_point_sample(x, 200))
+
+
+BQ_CASES = [  # (B, N1, N2, radius, K)
+    (2, 6144, 1024, 0.05, 64), (2, 1024, 256, 0.32, 64), (1, 50, 10, 0.2, 5), (2, 300, 70, 0.15, 3),
+    (1, 1000, 33, 0.9, 128), (1, 64, 64, 0.1, 1), (2, 2500, 500, 0.001, 16), (1, 10, 3, 10.0, 20),
+]
+
+
+@pytest.mark.parametrize("B,N1,N2,radius,K", BQ_CASES)
+def test_ball_query_bit_exact(ext, orc, B, N1, N2, radius, K):
+    x = cloud(N1 + N2, B, N1, dup=0.1)
+    rng = np.random.default_rng(K)
+    # half of the centroids are points of the cloud (as in SA), half are arbitrary (may be empty balls)
+    c = x[:, :, torch.from_numpy(rng.integers(0, N1, N2))].clone()
+    c[:, :, N2 // 2:] += 0.013
+    wi, wc = orc.ball_query(x, c, radius, K)
+    for v in layouts(x):
+        gi, gc = ext.ball_query(v.to(DEV), c.to(DEV), radius, K)
+        assert gi.dtype == torch.int64 and gc.dtype == torch.int64
+        assert torch.equal(gc.cpu(), wc)
+        assert torch.equal(gi.cpu(), wi)
+
+
+def test_ball_query_radius_boundary_is_strict(ext, orc):
+    # points exactly at distance r: d2 == r*r must be excluded (strict <, ball_query_kernel.cu:61)
+    x = torch.tensor([[[0.0, 0.5, 0.25, 0.5000001]], [[0.0] * 4], [[0.0] * 4]]).view(1, 3, 4)
+    c = torch.zeros(1, 3, 1)
+    gi, gc = ext.ball_query(x.to(DEV), c.to(DEV), 0.5, 4)
+    wi, wc = orc.ball_query(x, c, 0.5, 4)
+    assert torch.equal(gi.cpu(), wi) and torch.equal(gc.cpu(), wc)
+    assert wc.item() == 2 and wi.view(-1).tolist() == [0, 2, 0, 0]
+
+
+def test_ball_query_full_size_level1(ext, orc):
+    from regnet_for_3d_grasping_amd import synthetic
+    pc = synthetic.make_batch(1003, 1, 25600)
+    x = pc.permute(0, 2, 1)[:, :3, :]
+    idx = orc.farthest_point_sample(x, 5120)
+    c = torch.gather(x, 2, idx[:, None, :].expand(1, 3, 5120))
+    gi, gc = ext.ball_query(x.to(DEV), c.to(DEV), 0.02, 64)
+    wi, wc = orc.ball_query(x, c, 0.02, 64)
+    assert torch.equal(gi.cpu(), wi) and torch.equal(gc.cpu(), wc)
+    # properties: members are within the radius, the first `count` slots ascend, the rest repeat slot 0
+    g = torch.gather(x.contiguous(), 2, gi.cpu().view(1, 1, -1).expand(1, 3, -1)).view(1, 3, 5120, 64)
+    d2 = ((g - c.unsqueeze(-1)) ** 2).sum(1)
+    assert bool((d2 < 0.02 * 0.02 + 1e-9).all())
+    assert int(gc.min()) >= 1  # every centroid is a point of the cloud
+
+
+NN_CASES = [(2, 1024, 256), (2, 5120, 1024), (1, 6144, 5120), (1, 10, 3), (2, 77, 5), (1, 300, 2100)]
+
+
+@pytest.mark.parametrize("B,N1,N2", NN_CASES)
+def test_three_nn_bit_exact(ext, orc, B, N1, N2):
+    q = cloud(N1, B, N1)
+    k = cloud(N2 + 1, B, N2, dup=0.3, grid=0.05)  # duplicates + lattice => exact distance ties
+    wi, wd = orc.point_search(q, k, 3)
+    for v in layouts(q):
+        gi, gd = ext.point_search(v.to(DEV), k.to(DEV), 3)
+        assert torch.equal(gi.cpu(), wi)
+        assert torch.equal(gd.cpu(), wd)  # same fp32 op order => identical bits
+
+
+def test_three_nn_query_equals_key(ext, orc):
+    k = cloud(5, 1, 200)
+    gi, gd = ext.point_search(k.to(DEV), k.to(DEV), 3)
+    assert torch.equal(gi[0, :, 0].cpu(), torch.arange(200)) and float(gd[0, :, 0].abs().max()) == 0.0
+
+
+def test_group_points_forward_backward(ext, orc):
+    rng = np.random.default_rng(0)
+    B, C, N1, N2, K = 2, 37, 500, 60, 16
+    x = torch.from_numpy(rng.normal(size=(B, N1, C)).astype(np.float32)).transpose(1, 2)  # non-contiguous (B,C,N1)
+    idx = torch.from_numpy(rng.integers(0, N1, (B, N2, K)))
+    got = ext.group_points_forward(x.to(DEV), idx.to(DEV)).cpu()
+    assert torch.equal(got, orc.group_points_forward(x, idx))  # pure gather: exact
+    g = torch.from_numpy(rng.normal(size=(B, C, N2, K)).astype(np.float32))
+    gb = ext.group_points_backward(g.to(DEV), idx.to(DEV), N1).cpu()
+    # atomics: summation order differs from the oracle's; tolerance 1e-5 on O(K) sums of unit normals
+    torch.testing.assert_close(gb, orc.group_points_backward(g, idx, N1), rtol=0, atol=1e-5)
+
+
+def test_group_points_autograd_matches_torch_gather(ext):
+    from regnet_for_3d_grasping_amd.pn2_utils import function as F_
+    torch.manual_seed(1)
+    B, C, N, K = 2, 4, 5, 3  # the reference's own self-check sizes (functions/gather_knn.py:26-55)
+    feat = torch.rand(B, C, N, device=DEV)
+    idx = torch.randint(0, N, (B, N, K), device=DEV)
+    a = feat.clone().requires_grad_(True)
+    b = feat.clone().requires_grad_(True)
+    ya = torch.gather(a.unsqueeze(2).expand(B, C, N, N), 3, idx.unsqueeze(1).expand(B, C, N, K))
+    yb = F_.group_points(b, idx)
+    assert torch.allclose(ya, yb)
+    ya.backward(torch.ones_like(ya))
+    yb.backward(torch.ones_like(yb))
+    assert torch.allclose(a.grad, b.grad)
+
+
+def test_gather_knn_reference_selfcheck(ext):
+    from regnet_for_3d_grasping_amd.pn2_utils.functions.gather_knn import gather_knn
+    torch.manual_seed(1)
+    B, C, N, K = 2, 4, 5, 3
+    feat = torch.rand(B, C, N, device=DEV)
+    idx = torch.randint(0, N, (B, N, K), device=DEV)
+    a = feat.clone().requires_grad_(True)
+    b = feat.clone().requires_grad_(True)
+    ya = torch.gather(a.unsqueeze(2).expand(B, C, N, N), 3, idx.unsqueeze(1).expand(B, C, N, K))
+    yb = gather_knn(b, idx)
+    assert ya.allclose(yb)
+    ya.backward(torch.ones_like(ya))
+    yb.backward(torch.ones_like(yb))
+    assert a.grad.allclose(b.grad)
+
+
+def test_interpolate_forward_backward(ext, orc):
+    rng = np.random.default_rng(3)
+    B, C, M, N = 2, 70, 128, 900
+    x = torch.from_numpy(rng.normal(size=(B, M, C)).astype(np.float32)).transpose(1, 2)
+    idx = torch.from_numpy(rng.integers(0, M, (B, N, 3)))
+    w = torch.from_numpy(rng.dirichlet(np.ones(3), (B, N)).astype(np.float32))
+    got = ext.interpolate_forward(x.to(DEV), idx.to(DEV), w.to(DEV)).cpu()
+    # the kernel may contract mul+add into fma; 3-term sums of O(1) values: 1e-6
+    torch.testing.assert_close(got, orc.interpolate_forward(x, idx, w), rtol=0, atol=1e-6)
+    g = torch.from_numpy(rng.normal(size=(B, C, N)).astype(np.float32))
+    gb = ext.interpolate_backward(g.to(DEV), idx.to(DEV), w.to(DEV), M).cpu()
+    torch.testing.assert_close(gb, orc.interpolate_backward(g, idx, w, M), rtol=0, atol=2e-5)
+
+
+def test_empty_and_error_cases(ext):
+    x = torch.zeros(2, 3, 10, device=DEV)
+    with pytest.raises(RuntimeError):
+        ext.farthest_point_sample(x, 0)          # CHECK_GT(num_centroids, 0)
+    with pytest.raises(RuntimeError):
+        ext.farthest_point_sample(x, 11)         # CHECK_GE(num_points, num_centroids)
+    with pytest.raises(RuntimeError):
+        ext.farthest_point_sample(torch.zeros(2, 4, 10, device=DEV), 2)   # CHECK_EQ(size(1), 3)
+    with pytest.raises(RuntimeError):
+        ext.point_search(x, torch.zeros(2, 3, 2, device=DEV), 3)          # CHECK_GE(num_key, 3)
+    with pytest.raises(RuntimeError):
+        ext.point_search(x, x, 4)                # only 3-NN
+    with pytest.raises(RuntimeError):
+        ext.ball_query(x.cpu(), x, 0.1, 4)       # CHECK_CUDA
+    idx, cnt = ext.ball_query(x, torch.zeros(2, 3, 0, device=DEV), 0.1, 4)  # no centroids
+    assert tuple(idx.shape) == (2, 0, 4) and tuple(cnt.shape) == (2, 0)
+    e = ext.farthest_point_sample(torch.zeros(0, 3, 10, device=DEV), 2)      # empty batch
+    assert tuple(e.shape) == (0, 2)
+
+
+def test_region_ops_match_oracle():
+    from oracle import region_oracle
+    from regnet_for_3d_grasping_amd import region_ops, synthetic
+    from regnet_for_3d_grasping_amd.get_regiondataset import group_radius
+    pc = synthetic.make_batch(1001, 2, 6144)
+    rng = np.random.default_rng(5)
+    centres = torch.gather(pc, 1, torch.from_numpy(rng.integers(0, 6144, (2, 64, 1))).expand(2, 64, 6))
+    for r_time in (0.1, 0.8):
+        R = group_radius(0.08, 0.01, 0.06, r_time)
+        wc, wn = region_oracle.radius_candidates(pc, centres, R)
+        gc, gn = region_ops.radius_candidates(pc.to(DEV), centres.to(DEV), R)
+        assert torch.equal(gn.cpu(), wn)
+        for b in range(2):
+            for c in range(64):
+                n = int(wn[b, c])
+                assert torch.equal(gc[b, c, :n].cpu(), wc[b, c, :n])
+    # box crop
+    n, G = 40, 1024
+    pts = torch.from_numpy(rng.uniform(-0.07, 0.07, (n, G, 6)).astype(np.float32))
+    q, _ = np.linalg.qr(rng.normal(size=(n, 3, 3)))
+    rot = torch.from_numpy(q.astype(np.float32))
+    centre = torch.from_numpy(rng.uniform(-0.01, 0.01, (n, 3)).astype(np.float32))
+    xl = torch.full((n,), 0.03)
+    yl = torch.from_numpy(rng.uniform(0.02, 0.04, n).astype(np.float32))
+    wc, wn = region_oracle.box_candidates(pts, centre, rot, xl, yl, 0.005)
+    gc, gn = region_ops.box_candidates(pts.to(DEV), centre.to(DEV), rot.to(DEV), xl.to(DEV), yl.to(DEV), 0.005)
+    assert torch.equal(gn.cpu(), wn) and int(wn.max()) > 0
+    for i in range(n):
+        assert torch.equal(gc[i, :int(wn[i])].cpu(), wc[i, :int(wn[i])])
+    # gather + max
+    feat = torch.from_numpy(rng.normal(size=(2 * 6144, 256)).astype(np.float32))
+    rows = torch.from_numpy(rng.integers(0, 2 * 6144, (128, 256)))
+    assert torch.equal(region_ops.gather_max(feat.to(DEV), rows.to(DEV)).cpu(), region_oracle.gather_max(feat, rows))
