@@ -172,10 +172,16 @@ extern "C" int regnet_fps_f32(const float* xyz, int64_t sb, int64_t sc, int64_t 
   if (!xyz || !index) return REGNET_ERR_NULL;
   hipStream_t st = as_stream(stream);
   const int rbl = ref_block_log2(N);
-  if (N <= 256) FPS_CASE(64, 4);
-  else if (N <= 1024) FPS_CASE(256, 4);
+  // The in-thread scan keeps the first strict maximum in slot order; that equals the reference's
+  // order only if all points of a thread share one reference lane (j mod RB), i.e. T % RB == 0 or
+  // one point per thread.  Hence T = RB (PPT 1) up to 512 points and T in {512, 1024} above.
+  if (N <= 64) FPS_CASE(64, 1);
+  else if (N <= 128) FPS_CASE(128, 1);
+  else if (N <= 256) FPS_CASE(256, 1);
+  else if (N <= 512) FPS_CASE(512, 1);
+  else if (N <= 1024) FPS_CASE(512, 2);
   else if (N <= 2048) FPS_CASE(512, 4);
-  else if (N <= 4096) FPS_CASE(1024, 4);
+  else if (N <= 4096) FPS_CASE(512, 8);
   else if (N <= 6144) FPS_CASE(1024, 6);
   else if (N <= 8192) FPS_CASE(1024, 8);
   else if (N <= 12288) FPS_CASE(1024, 12);

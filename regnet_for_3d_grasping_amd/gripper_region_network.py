@@ -224,7 +224,8 @@ def get_gripper_region_transform(group_points, group_index, grasp, region_num, g
     pos_t = torch.from_numpy(pos).to(dev)
     valid_t = torch.from_numpy(valid).to(dev)
 
-    index = torch.gather(cand, 1, pos_t).long()                      # positions inside the group
+    # positions inside the group; rows without a valid crop hold unwritten candidate slots -> 0
+    index = torch.where(valid_t.view(n, 1), torch.gather(cand, 1, pos_t).long(), torch.zeros_like(pos_t))
     index_inall = torch.gather(group_index.long(), 1, index)
     picked = torch.gather(group_points, 1, index.unsqueeze(-1).expand(n, region_num, C))
     local = torch.bmm(rot, (picked[:, :, :3].float() - center.view(n, 1, 3)).permute(0, 2, 1)).permute(0, 2, 1)
