@@ -12,10 +12,10 @@ def main(path, top=45):
     rows = list(cur.execute("select name, total_calls, total_duration, average, percentage from top_kernels"))
     total = sum(float(r[2]) for r in rows)
     print("# rocprofv3 --kernel-trace --stats summary of %s" % path)
-    print("# total kernel time %.3f ms over %d distinct kernels; durations in microseconds" % (total / 1e6, len(rows)))
+    print("# total kernel time %.3f ms over %d distinct kernels; durations in microseconds" % (total / 1e3, len(rows)))
     print("%-100s %8s %14s %12s %7s" % ("kernel", "calls", "total_us", "avg_us", "pct"))
     for name, calls, tot, avg, pct in rows[:top]:
-        print("%-100s %8d %14.1f %12.2f %7.2f" % (str(name)[:100], int(calls), float(tot) / 1e3, float(avg) / 1e3,
+        print("%-100s %8d %14.1f %12.2f %7.2f" % (str(name)[:100], int(calls), float(tot), float(avg),
                                                   float(pct)))
 
 
