@@ -120,6 +120,45 @@ int regnet_box_crop_f32(const float* group_points, int64_t gb, int64_t gn, const
 int regnet_gather_max_f32(const float* feat, int64_t num_rows, int64_t F, const int64_t* rows,
                           int64_t R, int64_t G, float* out, void* stream);
 
+/* ---- per-point shared-MLP contraction on fp32 MFMA (channels-last activations) ---------------
+ * Replaces the cuDNN/cuBLAS 1x1-conv + BatchNorm + ReLU chains the reference runs for
+ * SharedMLP (pn2_utils/nn/modules/mlp.py:55-114, conv.py:6-76) inside PointNetSAModule.forward
+ * (pn2_utils/modules.py:210-246), PointnetFPModule.forward (:500-509) and the head
+ * (utils/pointnet2.py:116-119).  W is packed [Npad][Kpad] (Npad multiple of 128, Kpad multiple of
+ * 32, zero padded); scale/shift are the eval-mode BatchNorm folded to a per-channel affine.
+ *
+ * regnet_mlp_layer_f32: C[P,N] = act(scale * (A[P,Ka] . W^T) + shift); pool_group == 64 additionally
+ * takes the max over every 64 consecutive rows (torch.max(x, 3), modules.py:245) -> C[P/64, N].  */
+int regnet_mlp_layer_f32(const float* A, int64_t lda, int64_t Ka, const float* W, int64_t Kpad,
+                         const float* scale, const float* shift, float* C, int64_t ldc, int64_t P,
+                         int64_t N, int relu, int pool_group, void* stream);
+
+/* regnet_sa_layer1_f32: first SharedMLP layer of a set-abstraction block with the grouping fused
+ * into the operand load (no (B,C,M,K) tensor is materialised; reference: QueryGrouper.forward,
+ * modules.py:39-56).  Row p = (b, m, k): A[p] = [feat[b, nbr[p], 0:Cf] | xyz[b,:,nbr[p]] -
+ * xyz[b,:,ctr[b*M+m]]]; W columns must be packed in that order (features first).  feat element
+ * (b,n,c) at feat[b*fb + n*fn + c*fc]; xyz (B,3,N) with strides (xb,xc,xn); nbr (B,M,group) int64,
+ * ctr (B,M) int64.  -> C[B*M*group, N].                                                          */
+int regnet_sa_layer1_f32(const float* feat, int64_t fb, int64_t fn, int64_t fc, int64_t Cf,
+                         const float* xyz, int64_t xb, int64_t xc, int64_t xn, const int64_t* nbr,
+                         const int64_t* ctr, int64_t B, int64_t M, int64_t group, const float* W,
+                         int64_t Kpad, const float* scale, const float* shift, float* C, int64_t ldc,
+                         int64_t N, int relu, void* stream);
+
+/* regnet_interp_concat_f32: FeatureInterpolator.forward (modules.py:104-131) channels-last:
+ * out[b*Nd+n] = [sum_k w_k * sparse[b, idx[b,n,k], 0:Cs] | dense[b,n,0:Cd] | 0...], w from squared
+ * distances (inv = 1/max(d2,eps), w = inv/sum).  sparse (b,n,:) at sparse[b*sb + n*sn + c];
+ * dense element (b,n,c) at dense[b*db + n*dn + c*dc]; out row stride ldo >= Cout >= Cs+Cd.        */
+int regnet_interp_concat_f32(const float* sparse, int64_t sb, int64_t sn, int64_t Cs,
+                             const int64_t* idx, const float* dist2, float eps, const float* dense,
+                             int64_t db, int64_t dn, int64_t dc, int64_t Cd, int64_t B, int64_t Nd,
+                             float* out, int64_t ldo, int64_t Cout, void* stream);
+
+/* regnet_score_head_f32: score = sigmoid(bn_score(conv_score(x))) (utils/pointnet2.py:117-119),
+ * x (P,C) channels-last, w (C), bn folded to (bn_scale, bn_shift).                                */
+int regnet_score_head_f32(const float* x, int64_t ldx, int64_t C, const float* w, float bias,
+                          float bn_scale, float bn_shift, float* score, int64_t P, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

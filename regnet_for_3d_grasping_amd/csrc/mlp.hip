@@ -1,0 +1,373 @@
+// mlp.hip -- the per-point shared-MLP contraction of the set-abstraction / feature-propagation
+// layers on gfx950 matrix cores (fp32-input MFMA, exact fp32 products, fp32 accumulate).
+//
+// Reference behaviour restated (paths relative to /root/reference/multi_model/utils):
+//   SharedMLP = [1x1 conv (bias-free) -> BatchNorm -> ReLU]*   pn2_utils/nn/modules/mlp.py:55-114, conv.py:6-76
+//   SA block: group -> (xyz - centre | feature) -> SharedMLP -> max over K   pn2_utils/modules.py:39-56,:210-246
+//   FP block: 3-NN weights -> interpolate -> cat(interp, skip) -> SharedMLP  pn2_utils/modules.py:104-131,:500-509
+//   score head: conv_score(+bias) -> bn_score -> sigmoid                    pointnet2.py:116-119
+//
+// Layout: activations are CHANNELS-LAST, X[point][channel]; a 1x1 conv over P points is the GEMM
+//   C[P x N] = X[P x K] * W[N x K]^T,  then  y = relu(scale[n] * c + shift[n])   (eval-mode BN folded
+// into a per-channel affine).  Both operands sit in LDS as [row][k] tiles, so the A fragment
+// (A[i][k], i = lane&31, k = lane>>5) and the B fragment (B[k][j] = W[j][k]) are read with the
+// same ds_read_b128 pattern: a lane fetches 4 consecutive k of its row and feeds 4 MFMAs; the
+// k order inside an 8-wide slab is therefore permuted identically for A and W (a sum is order
+// independent up to fp32 rounding).
+//
+// Tile: 128 points x 128 channels x 32 k per workgroup of 4 waves (2x2), each wave 64x64 =
+// 2x2 v_mfma_f32_32x32x2_f32 accumulators (64 VGPRs).  LDS rows are padded to 36 floats so the
+// 16-lane service groups of ds_read_b128 hit 64 distinct banks.  Global->LDS goes through
+// registers (the gather prologue needs per-row pointers), prefetching tile t+1 while tile t is
+// multiplied; two LDS buffers, one barrier per k-tile.
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define BM 128
+#define BN 128
+#define BK 32
+#define LDS_LD 36
+#define MLP_THREADS 256
+
+struct MlpArgs {
+  // ---- A operand, plain mode: rows of a channels-last activation buffer
+  const float* A;
+  long long lda;
+  int Ka;  // valid columns of A (multiple of 4); columns >= Ka read as zero
+  // ---- A operand, gather mode (first layer of a set-abstraction block):
+  //      row p = (scene b, centre m, neighbour k);  A[p] = [feat[b, nbr[p], 0:Cf] | xyz[nbr[p]] - xyz[ctr[p/group]] | 0]
+  const float* feat;  // (B*Nsrc, ldf) channels-last features of the source level (may be NULL if Cf == 0)
+  long long ldf;
+  long long fb, fn, fc;  // generic strides of feat: element (b, n, c) at feat[b*fb + n*fn + c*fc]
+  int Cf;
+  int feat_vec;  // 1: channel stride 1, Cf % 4 == 0 and 16-byte aligned rows -> float4 loads
+  const float* xyz;  // (B,3,Nsrc) strided
+  long long xb, xc, xn;
+  const long long* nbr;  // [P] neighbour ids (ball-query output, int64)
+  const long long* ctr;  // [P/group] centre ids (FPS output, int64)
+  int group;             // neighbours per centre (64)
+  long long rows_per_scene;
+  // ---- W operand: packed [Npad][Kpad] (zero padded), folded BN affine
+  const float* W;
+  int Kpad;
+  const float* scale;
+  const float* shift;
+  // ---- output
+  float* C;
+  long long ldc;
+  long long P;
+  int N;
+  int relu;
+};
+
+__device__ __forceinline__ void xcd_tile(int& tm, int& tn, int tiles_m, int tiles_n) {
+  // Blocks are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8, a speed-only
+  // observation).  Remap so that consecutive blocks ON ONE XCD walk the N-tiles of the same
+  // M-tile: the A tile is then fetched into one L2 instead of eight.
+  const long long total = (long long)tiles_m * tiles_n;
+  const long long L = blockIdx.x;
+  const long long q = total / 8, r = total % 8;
+  const long long xcd = L % 8, s = L / 8;
+  const long long t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + s;
+  tm = (int)(t / tiles_n);
+  tn = (int)(t % tiles_n);
+}
+
+template <bool GATHER, bool POOL>
+__global__ __launch_bounds__(MLP_THREADS, 2) void mlp_gemm_kernel(const MlpArgs p) {
+  __shared__ __attribute__((aligned(16))) float sA[2][BM][LDS_LD];
+  __shared__ __attribute__((aligned(16))) float sW[2][BN][LDS_LD];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int tiles_m = (int)((p.P + BM - 1) / BM);
+  int tm, tn;
+  xcd_tile(tm, tn, tiles_m, tiles_n);
+  const long long row0 = (long long)tm * BM;
+  const int col0 = tn * BN;
+
+  // staging map: thread -> (row r + 32*i, 4 columns starting at 4*c4)
+  const int sr = tid >> 3, c4 = tid & 7;
+
+  // per-row source pointers
+  const float* arow[4];
+  bool arow_ok[4];
+  float relx[4], rely[4], relz[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const long long row = row0 + sr + 32 * i;
+    arow_ok[i] = row < p.P;
+    const long long rs = arow_ok[i] ? row : 0;
+    if (GATHER) {
+      const long long b = rs / p.rows_per_scene;
+      const long long j = p.nbr[rs];
+      const long long cj = p.ctr[rs / p.group];
+      arow[i] = p.feat ? p.feat + b * p.fb + j * p.fn : nullptr;
+      const float* xb = p.xyz + b * p.xb;
+      relx[i] = xb[j * p.xn] - xb[cj * p.xn];
+      rely[i] = xb[p.xc + j * p.xn] - xb[p.xc + cj * p.xn];
+      relz[i] = xb[2 * p.xc + j * p.xn] - xb[2 * p.xc + cj * p.xn];
+    } else {
+      arow[i] = p.A + rs * p.lda;
+      relx[i] = rely[i] = relz[i] = 0.f;
+    }
+  }
+  const float* wrow[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) wrow[i] = p.W + (long long)(col0 + sr + 32 * i) * p.Kpad;
+
+  float4 ra[4], rw[4];
+  auto load_tile = [&](int k0) {
+    const int kc = k0 + 4 * c4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (arow_ok[i]) {
+        if (GATHER) {
+          if (p.feat_vec && kc + 4 <= p.Cf) {
+            v = *reinterpret_cast<const float4*>(arow[i] + kc);
+          } else {
+            float e[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              const int col = kc + t;
+              float x = 0.f;
+              if (col < p.Cf) x = arow[i][(long long)col * p.fc];
+              else if (col == p.Cf) x = relx[i];
+              else if (col == p.Cf + 1) x = rely[i];
+              else if (col == p.Cf + 2) x = relz[i];
+              e[t] = x;
+            }
+            v = make_float4(e[0], e[1], e[2], e[3]);
+          }
+        } else if (kc < p.Ka) {
+          v = *reinterpret_cast<const float4*>(arow[i] + kc);
+        }
+      }
+      ra[i] = v;
+      rw[i] = *reinterpret_cast<const float4*>(wrow[i] + kc);
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *reinterpret_cast<float4*>(&sA[buf][sr + 32 * i][4 * c4]) = ra[i];
+      *reinterpret_cast<float4*>(&sW[buf][sr + 32 * i][4 * c4]) = rw[i];
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  const int KT = p.Kpad / BK;
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  const int fr = lane & 31, fh = lane >> 5;
+  for (int kt = 0; kt < KT; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < KT) load_tile((kt + 1) * BK);
+#pragma unroll
+    for (int kk = 0; kk < BK / 8; ++kk) {
+      float4 a[2], b[2];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+        a[mi] = *reinterpret_cast<const float4*>(&sA[buf][wr * 64 + mi * 32 + fr][kk * 8 + 4 * fh]);
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+        b[ni] = *reinterpret_cast<const float4*>(&sW[buf][wc * 64 + ni * 32 + fr][kk * 8 + 4 * fh]);
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].x, b[ni].x, acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].y, b[ni].y, acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].z, b[ni].z, acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].w, b[ni].w, acc[mi][ni], 0, 0, 0);
+        }
+    }
+    if (kt + 1 < KT) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: folded BN affine + ReLU (+ max over the 64 rows of a group) -------------
+  // C/D layout of v_mfma_f32_32x32x2_f32: element r of lane l is row (r&3) + 8*(r>>2) + 4*(l>>5), col l&31.
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    const int col = col0 + wc * 64 + ni * 32 + fr;
+    const bool col_ok = col < p.N;
+    const float s = col_ok ? p.scale[col] : 0.f;
+    const float t = col_ok ? p.shift[col] : 0.f;
+    if (POOL) {
+      float m = -__builtin_inff();
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float y = acc[mi][ni][r] * s + t;
+          if (p.relu) y = fmaxf(y, 0.f);
+          m = fmaxf(m, y);
+        }
+      m = fmaxf(m, __shfl_xor(m, 32, 64));
+      const long long g = (row0 + wr * 64) / 64;  // a wave's 64 rows are exactly one group
+      if (col_ok && fh == 0 && row0 + wr * 64 < p.P) p.C[g * p.ldc + col] = m;
+    } else {
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const long long row = row0 + wr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+          float y = acc[mi][ni][r] * s + t;
+          if (p.relu) y = fmaxf(y, 0.f);
+          if (col_ok && row < p.P) p.C[row * p.ldc + col] = y;
+        }
+    }
+  }
+}
+
+static int launch_gemm(const MlpArgs& a, bool gather, bool pool, hipStream_t st) {
+  const long long tiles = ((a.P + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+  if (tiles <= 0) return REGNET_OK;
+  if (tiles >= (1ll << 31)) return REGNET_ERR_UNSUPPORTED;
+  dim3 grid((unsigned)tiles), block(MLP_THREADS);
+  if (gather && pool) hipLaunchKernelGGL((mlp_gemm_kernel<true, true>), grid, block, 0, st, a);
+  else if (gather) hipLaunchKernelGGL((mlp_gemm_kernel<true, false>), grid, block, 0, st, a);
+  else if (pool) hipLaunchKernelGGL((mlp_gemm_kernel<false, true>), grid, block, 0, st, a);
+  else hipLaunchKernelGGL((mlp_gemm_kernel<false, false>), grid, block, 0, st, a);
+  REGNET_LAUNCH_CHECK();
+  return REGNET_OK;
+}
+
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+extern "C" int regnet_mlp_layer_f32(const float* A, int64_t lda, int64_t Ka, const float* W, int64_t Kpad,
+                                    const float* scale, const float* shift, float* C, int64_t ldc, int64_t P,
+                                    int64_t N, int relu, int pool_group, void* stream) {
+  if (P < 0 || N <= 0 || Ka < 0 || Kpad <= 0 || Kpad % BK || Ka > Kpad || (Ka & 3) || (lda & 3)) return REGNET_ERR_SHAPE;
+  if (pool_group != 0 && (pool_group != 64 || P % 64)) return REGNET_ERR_UNSUPPORTED;
+  if (P == 0) return REGNET_OK;
+  if (!A || !W || !scale || !shift || !C) return REGNET_ERR_NULL;
+  if (!aligned16(A) || !aligned16(W)) return REGNET_ERR_SHAPE;
+  MlpArgs a = {};
+  a.A = A; a.lda = lda; a.Ka = (int)Ka;
+  a.W = W; a.Kpad = (int)Kpad; a.scale = scale; a.shift = shift;
+  a.C = C; a.ldc = ldc; a.P = P; a.N = (int)N; a.relu = relu; a.group = 64; a.rows_per_scene = 1;
+  return launch_gemm(a, false, pool_group != 0, as_stream(stream));
+}
+
+extern "C" int regnet_sa_layer1_f32(const float* feat, int64_t fb, int64_t fn, int64_t fc, int64_t Cf,
+                                    const float* xyz, int64_t xb, int64_t xc, int64_t xn, const int64_t* nbr,
+                                    const int64_t* ctr, int64_t B, int64_t M, int64_t group, const float* W,
+                                    int64_t Kpad, const float* scale, const float* shift, float* C, int64_t ldc,
+                                    int64_t N, int relu, void* stream) {
+  if (B < 0 || M < 0 || group <= 0 || N <= 0 || Cf < 0 || Kpad <= 0 || Kpad % BK || Cf + 3 > Kpad) return REGNET_ERR_SHAPE;
+  const long long P = B * M * group;
+  if (P == 0) return REGNET_OK;
+  if (!xyz || !nbr || !ctr || !W || !scale || !shift || !C || (Cf > 0 && !feat)) return REGNET_ERR_NULL;
+  if (!aligned16(W)) return REGNET_ERR_SHAPE;
+  MlpArgs a = {};
+  a.feat = Cf > 0 ? feat : nullptr; a.fb = fb; a.fn = fn; a.fc = fc; a.Cf = (int)Cf;
+  a.feat_vec = Cf > 0 && fc == 1 && (Cf & 3) == 0 && aligned16(feat) && !(fb & 3) && !(fn & 3);
+  a.xyz = xyz; a.xb = xb; a.xc = xc; a.xn = xn; a.nbr = (const long long*)nbr; a.ctr = (const long long*)ctr;
+  a.group = (int)group; a.rows_per_scene = M * group;
+  a.W = W; a.Kpad = (int)Kpad; a.scale = scale; a.shift = shift;
+  a.C = C; a.ldc = ldc; a.P = P; a.N = (int)N; a.relu = relu;
+  return launch_gemm(a, true, false, as_stream(stream));
+}
+
+// ---------------------------------------------------------------------------------------
+// 3-NN interpolation + skip concat, channels-last:  out[p] = [sum_k w_k * sparse[idx_k] | dense[p] | 0]
+// Weights from SQUARED distances: inv = 1/max(d2, eps), w = inv / sum(inv)  (modules.py:117-122).
+// One workgroup handles ROWS rows; a thread walks channels so every gathered row is read coalesced.
+#define IC_ROWS 4
+__global__ __launch_bounds__(256) void interp_concat_kernel(
+    const float* __restrict__ sparse, long long sb, long long sn, int Cs, const long long* __restrict__ idx,
+    const float* __restrict__ dist2, float eps, const float* __restrict__ dense, long long db, long long dn,
+    long long dc, int Cd, long long Nd, float* __restrict__ out, long long ldo, int Cout, long long P) {
+  const long long row_base = (long long)blockIdx.x * IC_ROWS;
+  for (int rr = 0; rr < IC_ROWS; ++rr) {
+    const long long p = row_base + rr;
+    if (p >= P) return;
+    const long long b = p / Nd, n = p - b * Nd;
+    const long long j0 = idx[p * 3], j1 = idx[p * 3 + 1], j2 = idx[p * 3 + 2];
+    const float i0 = 1.0f / fmaxf(dist2[p * 3], eps), i1 = 1.0f / fmaxf(dist2[p * 3 + 1], eps),
+                i2 = 1.0f / fmaxf(dist2[p * 3 + 2], eps);
+    const float norm = (i0 + i1) + i2;
+    const float w0 = i0 / norm, w1 = i1 / norm, w2 = i2 / norm;
+    const float* s0 = sparse + b * sb + j0 * sn;
+    const float* s1 = sparse + b * sb + j1 * sn;
+    const float* s2 = sparse + b * sb + j2 * sn;
+    float* o = out + p * ldo;
+    for (int c = threadIdx.x; c < Cout; c += 256) {
+      float v = 0.f;
+      if (c < Cs) {
+        float acc = 0.f;  // k order, as interpolate_kernel.cu:165-170
+        acc += s0[c] * w0;
+        acc += s1[c] * w1;
+        acc += s2[c] * w2;
+        v = acc;
+      } else if (c < Cs + Cd) {
+        v = dense[b * db + n * dn + (long long)(c - Cs) * dc];
+      }
+      o[c] = v;
+    }
+  }
+}
+
+extern "C" int regnet_interp_concat_f32(const float* sparse, int64_t sb, int64_t sn, int64_t Cs, const int64_t* idx,
+                                        const float* dist2, float eps, const float* dense, int64_t db, int64_t dn,
+                                        int64_t dc, int64_t Cd, int64_t B, int64_t Nd, float* out, int64_t ldo,
+                                        int64_t Cout, void* stream) {
+  if (B < 0 || Nd < 0 || Cs < 0 || Cd < 0 || Cout < Cs + Cd || ldo < Cout) return REGNET_ERR_SHAPE;
+  const long long P = B * Nd;
+  if (P == 0 || Cout == 0) return REGNET_OK;
+  if (!sparse || !idx || !dist2 || !out || (Cd > 0 && !dense)) return REGNET_ERR_NULL;
+  const long long blocks = (P + IC_ROWS - 1) / IC_ROWS;
+  if (blocks >= (1ll << 31)) return REGNET_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(interp_concat_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), sparse,
+                     (long long)sb, (long long)sn, (int)Cs, (const long long*)idx, dist2, eps, dense, (long long)db,
+                     (long long)dn, (long long)dc, (int)Cd, (long long)Nd, out, (long long)ldo, (int)Cout, P);
+  REGNET_LAUNCH_CHECK();
+  return REGNET_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// Score head: score[p] = sigmoid(bn(dot(x[p], w) + bias))  (pointnet2.py:116-119), x channels-last.
+// One wave per point: 64 lanes stride the channels, DPP-free shuffle reduction.
+__global__ __launch_bounds__(256) void score_head_kernel(const float* __restrict__ x, long long ldx, int C,
+                                                        const float* __restrict__ w, float bias, float bn_scale,
+                                                        float bn_shift, float* __restrict__ score, long long P) {
+  const long long p = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (p >= P) return;
+  const int lane = threadIdx.x & 63;
+  const float* row = x + p * ldx;
+  float acc = 0.f;
+  for (int c = lane; c < C; c += 64) acc += row[c] * w[c];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  if (lane == 0) {
+    const float v = (acc + bias) * bn_scale + bn_shift;
+    score[p] = 1.0f / (1.0f + expf(-v));
+  }
+}
+
+extern "C" int regnet_score_head_f32(const float* x, int64_t ldx, int64_t C, const float* w, float bias,
+                                     float bn_scale, float bn_shift, float* score, int64_t P, void* stream) {
+  if (P < 0 || C <= 0 || ldx < C) return REGNET_ERR_SHAPE;
+  if (P == 0) return REGNET_OK;
+  if (!x || !w || !score) return REGNET_ERR_NULL;
+  const long long blocks = (P + 3) / 4;
+  if (blocks >= (1ll << 31)) return REGNET_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(score_head_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), x, (long long)ldx,
+                     (int)C, w, bias, bn_scale, bn_shift, score, (long long)P);
+  REGNET_LAUNCH_CHECK();
+  return REGNET_OK;
+}

@@ -1,20 +1,252 @@
-"""Fused eval-mode forward for SA / FP modules on MI355X (placeholder until mlp.hip lands).
+"""Fused eval-mode forward of the set-abstraction / feature-propagation / head blocks on MI355X.
 
-``usable(module, xyz)`` is the single dispatch predicate used by ``pn2_utils.modules``: the
-fused path is taken only for inference (module in eval mode, autograd off) on GPU tensors.
+``pn2_utils.modules`` and ``pointnet2`` dispatch here when ``usable()`` holds (module in eval
+mode, autograd off, GPU tensors).  The module API is unchanged -- channel-first ``(B,C,N)``
+tensors in and out -- but internally activations are channels-last buffers driven through the
+fp32-MFMA shared-MLP kernels of csrc/mlp.hip, and the tensors handed back are transposed *views*
+of those buffers (so the next fused block reads them without a copy).
+
+Per block (reference pn2_utils/modules.py:210-246 and :500-509, pointnet2.py:116-119):
+  SA  : FPS -> ball query -> [gather(feat | xyz - centre) . W1] -> [. W2] -> [. W3 + max over K]
+  FP  : 3-NN -> interpolate+concat (channels-last) -> [. W1] -> [. W2] (-> [. W3])
+  head: [. W]*4 -> conv_score + bn_score + sigmoid
+Eval-mode BatchNorm is folded into a per-channel (scale, shift) applied in the GEMM epilogue.
 """
 import torch
 
-ENABLED = False
+from . import _lib, pn2_ext
+
+ENABLED = True
+
+_check = _lib.check
+_L = _lib.lib
 
 
 def usable(module, xyz):
     return ENABLED and xyz.is_cuda and not module.training and not torch.is_grad_enabled()
 
 
-def sa_forward(module, xyz, feature):
-    raise NotImplementedError
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
 
 
-def fp_forward(module, dense_xyz, sparse_xyz, dense_feature, sparse_feature):
-    raise NotImplementedError
+def _round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+class _Layer:
+    """One conv(1x1, bias-free or biased) + eval BatchNorm (+ReLU) packed for the GEMM kernel."""
+
+    __slots__ = ("W", "scale", "shift", "N", "K", "Kpad", "relu")
+
+
+def _pack(conv, bn, relu, col_order=None):
+    w = conv.weight.detach().reshape(conv.weight.shape[0], -1).float()  # (N, K)
+    N, K = w.shape
+    if col_order is not None:
+        w = w[:, col_order]
+        K = w.shape[1]
+    L = _Layer()
+    L.N, L.K, L.Kpad, L.relu = N, K, _round_up(max(K, 1), 32), 1 if relu else 0
+    Wp = torch.zeros((_round_up(N, 128), L.Kpad), dtype=torch.float32, device=w.device)
+    Wp[:N, :K] = w
+    if bn is not None:
+        scale = bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)
+        shift = bn.bias.detach().float() - bn.running_mean.detach().float() * scale
+    else:
+        scale = torch.ones(N, dtype=torch.float32, device=w.device)
+        shift = torch.zeros(N, dtype=torch.float32, device=w.device)
+    if conv.bias is not None:
+        shift = shift + conv.bias.detach().float() * scale
+    L.W, L.scale, L.shift = Wp.contiguous(), scale.contiguous(), shift.contiguous()
+    return L
+
+
+def _signature(module):
+    return tuple((t.data_ptr(), t._version) for t in list(module.parameters()) + list(module.buffers()))
+
+
+def _packed_stack(owner, stack, first_col_order=None):
+    """Packed layers of a SharedMLP (list of conv/bn/relu blocks), cached on ``owner`` and rebuilt
+    whenever a parameter or BN buffer is modified (in-place updates bump ``_version``)."""
+    sig = _signature(stack)
+    cache = getattr(owner, "_regnet_packed", None)
+    if cache is None or cache[0] != sig:
+        layers = []
+        for i, block in enumerate(stack):
+            layers.append(_pack(block.conv, block.bn, block.relu is not None, first_col_order if i == 0 else None))
+        cache = (sig, layers)
+        owner._regnet_packed = cache
+    return cache[1]
+
+
+# ---- thin kernel wrappers (module-level names so bench.py can bracket them with events) ------
+def mlp_layer(A, Ka, layer, P, pool_group=0):
+    """A: channels-last (P, lda) float32 buffer whose first Ka columns are valid."""
+    rows = P // pool_group if pool_group else P
+    out = torch.empty((rows, layer.N), dtype=torch.float32, device=A.device)
+    _check(_L.regnet_mlp_layer_f32(A.data_ptr(), A.stride(0), Ka, layer.W.data_ptr(), layer.Kpad,
+                                   layer.scale.data_ptr(), layer.shift.data_ptr(), out.data_ptr(), out.stride(0), P,
+                                   layer.N, layer.relu, pool_group, _stream(A)), "mlp_layer")
+    return out
+
+
+def sa_layer1(feature, xyz, nbr, ctr, layer, B, M, group):
+    """Gather-fused first SA layer.  feature (B,Cf,N) any strides or None; xyz (B,3,N) any strides."""
+    out = torch.empty((B * M * group, layer.N), dtype=torch.float32, device=xyz.device)
+    if feature is None:
+        fptr, fb, fn, fc, Cf = None, 0, 0, 0, 0
+    else:
+        fptr, (fb, fc, fn), Cf = feature.data_ptr(), feature.stride(), feature.size(1)
+    _check(_L.regnet_sa_layer1_f32(fptr, fb, fn, fc, Cf, xyz.data_ptr(), *xyz.stride(), nbr.data_ptr(), ctr.data_ptr(),
+                                   B, M, group, layer.W.data_ptr(), layer.Kpad, layer.scale.data_ptr(),
+                                   layer.shift.data_ptr(), out.data_ptr(), out.stride(0), layer.N, layer.relu,
+                                   _stream(xyz)), "sa_layer1")
+    return out
+
+
+def interp_concat(sparse_cl, idx, dist2, eps, dense_feature, B, Nd):
+    """sparse_cl: (B,Ns,Cs) channels-last contiguous; dense_feature (B,Cd,Nd) any strides or None.
+    Returns the (B*Nd, round_up(Cs+Cd,4)) channels-last operand of the first FP layer and its valid width."""
+    Cs = sparse_cl.size(2)
+    Cd = 0 if dense_feature is None else dense_feature.size(1)
+    width = _round_up(Cs + Cd, 4)
+    out = torch.empty((B * Nd, width), dtype=torch.float32, device=sparse_cl.device)
+    if dense_feature is None:
+        dptr, db, dn, dc = None, 0, 0, 0
+    else:
+        dptr, (db, dc, dn) = dense_feature.data_ptr(), dense_feature.stride()
+    _check(_L.regnet_interp_concat_f32(sparse_cl.data_ptr(), sparse_cl.stride(0), sparse_cl.stride(1), Cs,
+                                       idx.data_ptr(), dist2.data_ptr(), float(eps), dptr, db, dn, dc, Cd, B, Nd,
+                                       out.data_ptr(), out.stride(0), width, _stream(sparse_cl)), "interp_concat")
+    return out, width
+
+
+def _packed_head(seg):
+    """conv_score weight + folded bn_score scalars, cached like the layer stacks (reading the
+    scalars costs a device sync, so do it once per weight version, not per forward)."""
+    sig = _signature(seg.conv_score) + _signature(seg.bn_score)
+    cache = getattr(seg, "_regnet_head", None)
+    if cache is None or cache[0] != sig:
+        conv, bn = seg.conv_score, seg.bn_score
+        w = conv.weight.detach().reshape(-1).float().contiguous()
+        bn_scale = float(bn.weight.detach()[0] / torch.sqrt(bn.running_var.detach()[0] + bn.eps))
+        bn_shift = float(bn.bias.detach()[0] - bn.running_mean.detach()[0] * bn_scale)
+        bias = float(conv.bias.detach()[0]) if conv.bias is not None else 0.0
+        cache = (sig, (w, bias, bn_scale, bn_shift))
+        seg._regnet_head = cache
+    return cache[1]
+
+
+def score_head(x, seg, P):
+    w, bias, bn_scale, bn_shift = _packed_head(seg)
+    score = torch.empty((P,), dtype=torch.float32, device=x.device)
+    _check(_L.regnet_score_head_f32(x.data_ptr(), x.stride(0), w.numel(), w.data_ptr(), bias, bn_scale, bn_shift,
+                                    score.data_ptr(), P, _stream(x)), "score_head")
+    return score
+
+
+def _flop_meta(P, K, N):
+    return "P%d K%d N%d flop%d" % (P, K, N, 2 * P * K * N)
+
+
+# what bench.py brackets with HIP events: name -> meta(args) (algorithmic flops use the TRUE K)
+TIMED_OPS = {
+    "mlp_layer": lambda A, Ka, layer, P, pool_group=0: _flop_meta(P, layer.K, layer.N),
+    "sa_layer1": lambda feature, xyz, nbr, ctr, layer, B, M, group: _flop_meta(B * M * group, layer.K, layer.N),
+}
+
+
+def _as_channels_last(feature):
+    """(B,C,N) tensor -> (B,N,C) contiguous view/copy with channel stride 1."""
+    cl = feature.transpose(1, 2)
+    return cl if cl.is_contiguous() else cl.contiguous()
+
+
+# ---- block-level forwards ---------------------------------------------------------------------
+# Every block is split into its GEOMETRY part (indices; depends on xyz only) and its FEATURE part
+# (the MLP chain).  Called back to back they are the module forward; pipeline.ForwardPipeline runs
+# the geometry of batch i+1 on another stream while the features of batch i are on the matrix cores.
+def sa_geometry(module, xyz):
+    """FPS + centroid gather + ball query of a PointNetSAModule (modules.py:23-26, :41, :238-239)."""
+    B = xyz.shape[0]
+    M, K, radius = module.num_centroids, module.grouper.num_neighbours, module.grouper.radius
+    ctr = pn2_ext.farthest_point_sample(xyz, M)
+    new_xyz = torch.gather(xyz, 2, ctr[:, None, :].expand(B, 3, M))
+    nbr, _ = pn2_ext.ball_query(xyz, new_xyz, radius, K)
+    return {"ctr": ctr, "new_xyz": new_xyz, "nbr": nbr}
+
+
+def sa_features(module, xyz, feature, geo):
+    """Grouping + SharedMLP + max over K of a PointNetSAModule (modules.py:44-56, :244-245)."""
+    B = xyz.shape[0]
+    M, K = module.num_centroids, module.grouper.num_neighbours
+    Cf = 0 if feature is None else feature.size(1)
+    if K != 64 or len(module.mlp) < 2:
+        raise NotImplementedError("fused SA supports 64 neighbours and >= 2 MLP layers")
+    if feature is not None and not module.use_xyz:
+        raise NotImplementedError("fused SA without use_xyz")
+    # reference channel order is [xyz(3) | feature] (modules.py:52); the kernel gathers
+    # [feature | xyz], so permute the first layer's weight columns accordingly.
+    order = torch.cat([torch.arange(3, 3 + Cf), torch.arange(0, 3)])
+    layers = _packed_stack(module, module.mlp, order.to(xyz.device))
+    h = sa_layer1(feature, xyz, geo["nbr"], geo["ctr"], layers[0], B, M, K)
+    P = B * M * K
+    for layer in layers[1:-1]:
+        h = mlp_layer(h, layer.K, layer, P)
+    pooled = mlp_layer(h, layers[-1].K, layers[-1], P, pool_group=K)          # (B*M, C_out)
+    return geo["new_xyz"], pooled.view(B, M, -1).transpose(1, 2)
+
+
+def sa_forward(module, xyz, feature, geo=None):
+    """PointNetSAModule.forward (modules.py:210-246) for num_centroids > 0 with a ball grouper."""
+    return sa_features(module, xyz, feature, geo if geo is not None else sa_geometry(module, xyz))
+
+
+def fp_geometry(module, dense_xyz, sparse_xyz):
+    """3-NN search of a PointnetFPModule (modules.py:115-116)."""
+    idx, dist2 = pn2_ext.point_search(dense_xyz, sparse_xyz, module.interpolator.num_neighbors)
+    return {"idx": idx, "dist2": dist2}
+
+
+def fp_features(module, dense_xyz, dense_feature, sparse_feature, geo):
+    """Interpolate + concat + SharedMLP of a PointnetFPModule (modules.py:117-131, :507)."""
+    B, _, Nd = dense_xyz.shape
+    layers = _packed_stack(module, module.mlp)
+    A, width = interp_concat(_as_channels_last(sparse_feature), geo["idx"], geo["dist2"], module.interpolator._eps,
+                             dense_feature, B, Nd)
+    P = B * Nd
+    h, Ka = A, width
+    for layer in layers:
+        h = mlp_layer(h, Ka, layer, P)
+        Ka = layer.N
+    return h.view(B, Nd, -1).transpose(1, 2)
+
+
+def fp_forward(module, dense_xyz, sparse_xyz, dense_feature, sparse_feature, geo=None):
+    """PointnetFPModule.forward with a 3-NN interpolator (modules.py:104-131, :500-509)."""
+    if geo is None:
+        geo = fp_geometry(module, dense_xyz, sparse_xyz)
+    return fp_features(module, dense_xyz, dense_feature, sparse_feature, geo)
+
+
+def head_forward(seg, sparse_feature):
+    """PointNet2Seg head (pointnet2.py:116-119): SharedMLP -> conv_score -> bn_score -> sigmoid -> (B,N)."""
+    B, C, N = sparse_feature.shape
+    layers = _packed_stack(seg.mlp, seg.mlp)
+    h = _as_channels_last(sparse_feature).view(B * N, C)
+    Ka = C
+    if Ka % 4:
+        raise NotImplementedError("head input width must be a multiple of 4")
+    for layer in layers:
+        h = mlp_layer(h, Ka, layer, B * N)
+        Ka = layer.N
+    return score_head(h, seg, B * N).view(B, N)
+
+
+def plan_tensors(plan):
+    """All tensors of a geometry plan (for Tensor.record_stream when it crosses streams)."""
+    out = []
+    for level in plan["sa"] + plan["fp"]:
+        out.extend(v for v in level.values() if isinstance(v, torch.Tensor))
+    return out

@@ -183,10 +183,10 @@ class PointNetSAModule(_SetAbstraction):
         super().__init__()
         self._build(in_channels, mlp_channels, num_centroids, radius, num_neighbours, use_xyz, in_channels)
 
-    def forward(self, xyz, feature=None):
+    def forward(self, xyz, feature=None, geo=None):
         from .. import fused
         if fused.usable(self, xyz) and self.num_centroids > 0 and self.grouper is not None:
-            return fused.sa_forward(self, xyz, feature)
+            return fused.sa_forward(self, xyz, feature, geo)
         return super().forward(xyz, feature)
 
 
@@ -291,12 +291,12 @@ class PointnetFPModule(nn.Module):
         self.mlp = SharedMLP(in_channels, mlp_channels, ndim=1, bn=True)
         self.interpolator = _make_interpolator(num_neighbors, FeatureInterpolator)
 
-    def forward(self, dense_xyz, sparse_xyz, dense_feature, sparse_feature):
+    def forward(self, dense_xyz, sparse_xyz, dense_feature, sparse_feature, geo=None):
         if self.interpolator is None:
             return self.mlp(_broadcast_global(dense_xyz, sparse_xyz, dense_feature, sparse_feature))
         from .. import fused
         if fused.usable(self, dense_xyz):
-            return fused.fp_forward(self, dense_xyz, sparse_xyz, dense_feature, sparse_feature)
+            return fused.fp_forward(self, dense_xyz, sparse_xyz, dense_feature, sparse_feature, geo)
         return self.mlp(self.interpolator(dense_xyz, sparse_xyz, dense_feature, sparse_feature))
 
     def init_weights(self, init_fn=None):

@@ -52,18 +52,45 @@ class PointNet2Seg(nn.Module):
         self.bn_score = nn.BatchNorm1d(self.k_score)
         self.sigmoid = nn.Sigmoid()
 
-    def forward(self, points, add_channel1=None, add_channel2=None):
+    def plan(self, points):
+        """Geometry of a forward pass -- FPS / ball-query / 3-NN indices of every level.  Depends on
+        xyz only, so it can be computed ahead of (and concurrently with) the feature pass; hand the
+        result to ``forward(points, plan=...)``.  Fused MI355X path only."""
+        from . import fused
+        xyz = points[:, :3, :]
+        if not fused.usable(self, xyz):
+            raise RuntimeError("PointNet2Seg.plan needs eval mode, torch.no_grad() and GPU tensors")
+        levels, sa_geo = [xyz], []
+        for sa in self.sa_modules:
+            geo = fused.sa_geometry(sa, levels[-1])
+            sa_geo.append(geo)
+            levels.append(geo["new_xyz"])
+        fp_geo, sparse = [], levels[-1]
+        for level, fp in enumerate(self.fp_modules):
+            dense = levels[-2 - level]
+            fp_geo.append(fused.fp_geometry(fp, dense, sparse))
+            sparse = dense
+        return {"sa": sa_geo, "fp": fp_geo}
+
+    def forward(self, points, add_channel1=None, add_channel2=None, plan=None):
         B, _, N = points.size()
         xyz_stack, feat_stack = [points[:, :3, :]], [points[:, 3:6, :]]
-        for sa in self.sa_modules:
-            xyz, feat = sa(xyz_stack[-1], feat_stack[-1])
+        for level, sa in enumerate(self.sa_modules):
+            if plan is not None:
+                xyz, feat = sa(xyz_stack[-1], feat_stack[-1], geo=plan["sa"][level])
+            else:
+                xyz, feat = sa(xyz_stack[-1], feat_stack[-1])
             xyz_stack.append(xyz)
             feat_stack.append(feat)
 
         sparse_xyz, sparse_feature = xyz_stack[-1], feat_stack[-1]
         for level, fp in enumerate(self.fp_modules):
             dense_xyz = xyz_stack[-2 - level]
-            sparse_feature = fp(dense_xyz, sparse_xyz, feat_stack[-2 - level], sparse_feature)
+            if plan is not None:
+                sparse_feature = fp(dense_xyz, sparse_xyz, feat_stack[-2 - level], sparse_feature,
+                                    geo=plan["fp"][level])
+            else:
+                sparse_feature = fp(dense_xyz, sparse_xyz, feat_stack[-2 - level], sparse_feature)
             sparse_xyz = dense_xyz
 
         if add_channel1 is not None and add_channel2 is not None:

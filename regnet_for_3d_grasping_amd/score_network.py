@@ -19,8 +19,16 @@ class ScoreNetwork(nn.Module):
         """MSE between predicted and target per-point score (score_network.py:18-29)."""
         return self.criterion_reg(pscore, tscore.float())
 
-    def forward(self, pc, pc_score=None, pc_label=None):
-        feature, output_score = self.extrat_featurePN2(pc[:, :, :6].permute(0, 2, 1))
+    def plan(self, pc):
+        """Geometry plan (sampling / grouping / 3-NN indices) for ``pc``; see PointNet2Seg.plan."""
+        return self.extrat_featurePN2.plan(pc[:, :, :6].permute(0, 2, 1))
+
+    def forward(self, pc, pc_score=None, pc_label=None, plan=None):
+        points = pc[:, :, :6].permute(0, 2, 1)
+        if plan is not None:
+            feature, output_score = self.extrat_featurePN2(points, plan=plan)
+        else:
+            feature, output_score = self.extrat_featurePN2(points)
         all_feature = feature.transpose(2, 1)
         loss = None
         if self.is_training and pc_score is not None:
