@@ -166,16 +166,14 @@ def _cpu_model():
 
 def main():
     args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    from regnet_for_3d_grasping_amd import sharding
+    rank, local_rank, world = sharding.env_world()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        sharding.init("nccl", dev)   # RCCL; used only for the barrier + max-over-ranks of the contract
 
     from regnet_for_3d_grasping_amd import pipeline, synthetic
     timer = OpTimer()
@@ -183,7 +181,8 @@ def main():
 
     score_net, region_net = pipeline.build_models(dev)
     # each rank owns its shard of independent scenes: rank r holds scenes r*B .. r*B+B-1
-    pc = synthetic.make_batch(1000 + rank * args.batch, args.batch, args.points, device=dev)
+    seeds = sharding.scene_seeds(rank, world, args.batch)
+    pc = torch.from_numpy(np.stack([synthetic.make_scene(s_, args.points) for s_ in seeds], 0)).to(dev)
     synthetic.calibrate_score_head(score_net, pc)
     np.random.seed(1234 + rank)
 
@@ -213,10 +212,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     timer.enabled = False
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = sharding.max_over_ranks(dt, dev)
 
     if rank == 0:
         total_scenes = args.batch * args.steps * world
