@@ -159,6 +159,17 @@ int regnet_interp_concat_f32(const float* sparse, int64_t sb, int64_t sn, int64_
 int regnet_score_head_f32(const float* x, int64_t ldx, int64_t C, const float* w, float bias,
                           float bn_scale, float bn_shift, float* score, int64_t P, void* stream);
 
+/* ---- host-side numpy-compatible random draws of the region stage (no GPU involved) ------------
+ * Replaces the per-centre / per-grasp np.random.choice calls of the reference's Python loops
+ * (dataset_utils/get_regiondataset.py:331-337, multi_model/gripper_region_network.py:532-544) while
+ * consuming numpy's MT19937 stream identically.  mt_key[624] / mt_pos are np.random.get_state()[1:3]
+ * (updated in place; the caller hands them back with np.random.set_state).  counts (rows) int32;
+ * out (rows,size) int64 positions; valid (rows) u8 or NULL.  mode 0 = radius groups (n>=size: no
+ * replacement, 0<n<size: replacement, n==0: -1), mode 1 = gripper crops (n>size / 5<n<=size / else
+ * invalid).                                                                                       */
+int regnet_np_choice_rows(uint32_t* mt_key, int32_t* mt_pos, const int32_t* counts, int64_t rows,
+                          int64_t size, int mode, int64_t* out, uint8_t* valid);
+
 #ifdef __cplusplus
 }
 #endif

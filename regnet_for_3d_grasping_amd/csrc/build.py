@@ -20,6 +20,7 @@ SOURCES = [
     ("gather.hip", []),
     ("region.hip", ["-ffp-contract=off"]),
     ("mlp.hip", []),
+    ("np_random.hip", []),
 ]
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
           "-fno-gpu-rdc"]

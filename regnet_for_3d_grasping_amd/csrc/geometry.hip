@@ -9,6 +9,10 @@
 //   3-NN       csrc/interpolate_kernel.cu:28-77
 #include "common.h"
 
+#ifndef FPS_ABLATE
+#define FPS_ABLATE 0  // 0 = product; >0 = timing experiments of scripts/ablate (results are wrong)
+#endif
+
 // =====================================================================================
 // Furthest point sampling
 // =====================================================================================
@@ -44,12 +48,47 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
   return v;
 }
 
+// Wave-wide float max without LDS traffic: four DPP steps leave every lane of a 16-lane row with
+// the row maximum, the four row results are read back as scalars.
+#define DPP_MAX_STEP(v, CTRL)                                                                          \
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v),      \
+                                                                     __builtin_bit_cast(int, v), CTRL, \
+                                                                     0xf, 0xf, false)))
+__device__ __forceinline__ float wave_max_f32(float v) {
+  DPP_MAX_STEP(v, 0xB1);   // quad_perm [1,0,3,2]
+  DPP_MAX_STEP(v, 0x4E);   // quad_perm [2,3,0,1]
+  DPP_MAX_STEP(v, 0x141);  // row_half_mirror
+  DPP_MAX_STEP(v, 0x140);  // row_mirror
+  const int b = __builtin_bit_cast(int, v);
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0));
+  const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32));
+  const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+  return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+}
+
+// min(a, b) for non-NaN operands as ONE v_min_f32 (fminf() inserts a canonicalising v_max first).
+__device__ __forceinline__ float vmin_f32(float a, float b) {
+  float r;
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
+// Round structure (2 barriers):
+//   scan     every lane: d -> dist = min(dist, d), running thread maximum (VALUE ONLY: 1 v_max/point)
+//   stage 1  wave max (DPP) -> LDS -> barrier -> block maximum Mx (wave-uniform)
+//   stage 2  only lanes whose maximum equals Mx look up WHICH slot it was and publish the tie-break
+//            key with an LDS atomic min -> barrier -> every lane decodes the winner.
+// Searching the slot after the fact costs 2 instructions per point in (typically) one wave instead
+// of 2 per point in all sixteen.
 template <int T, int PPT>
 __global__ __launch_bounds__(T) void fps_resident_kernel(const float* __restrict__ xyz, int64_t sb, int64_t sc,
                                                          int64_t sn, int N, int M, int rb_log2,
                                                          int64_t* __restrict__ index) {
   constexpr int W = T / 64;
-  __shared__ unsigned long long part[2][W];
+  constexpr int WP = (W + 3) / 4 * 4;
+  __shared__ __attribute__((aligned(16))) float part[2][WP];
+  __shared__ unsigned win_key[2];
   const int tid = threadIdx.x;
   const float* base = xyz + (int64_t)blockIdx.x * sb;
   int64_t* out = index + (int64_t)blockIdx.x * M;
@@ -68,34 +107,246 @@ __global__ __launch_bounds__(T) void fps_resident_kernel(const float* __restrict
       dist[s] = -1.f;  // padding: min(-1, d) stays -1 and never beats the 0-initialised maximum
     }
   }
+  if (tid < 2 * WP) (&part[0][0])[tid] = 0.f;
+  if (tid < 2) win_key[tid] = 0xffffffffu;
   if (tid == 0) out[0] = 0;
+  __syncthreads();
   int cur = 0;
   for (int i = 1; i < M; ++i) {
+    const int buf = i & 1;
     const float cx = base[(int64_t)cur * sn];
     const float cy = base[sc + (int64_t)cur * sn];
     const float cz = base[2 * sc + (int64_t)cur * sn];
-    float best = 0.f;
-    int best_s = -1;
+    float tmax = 0.f;  // the reference's max_dist = 0 with strict >: only positive distances compete
 #pragma unroll
     for (int s = 0; s < PPT; ++s) {
-      float d = sqdist3(px[s], py[s], pz[s], cx, cy, cz);
-      float nd = fminf(dist[s], d);
+      const float nd = vmin_f32(dist[s], sqdist3(px[s], py[s], pz[s], cx, cy, cz));
       dist[s] = nd;
-      if (nd > best) { best = nd; best_s = s; }
+      tmax = fmaxf(tmax, nd);
     }
-    int best_j = best_s < 0 ? cur : best_s * T + tid;
-    unsigned long long packed =
-        ((unsigned long long)__float_as_uint(best) << 32) | (unsigned long long)(~fps_key(best_j, rb_log2));
-    packed = wave_max_u64(packed);
-    if ((tid & 63) == 0) part[i & 1][tid >> 6] = packed;
+    const float wmax = wave_max_f32(tmax);
+    if ((tid & 63) == 0) part[buf][tid >> 6] = wmax;
+    if (tid == 0) win_key[buf ^ 1] = 0xffffffffu;  // re-arm the slot the NEXT round will use
     __syncthreads();
-    unsigned long long m = part[i & 1][0];
+    float mx = 0.f;
 #pragma unroll
-    for (int w = 1; w < W; ++w) {
-      unsigned long long o = part[i & 1][w];
-      m = o > m ? o : m;
+    for (int w4 = 0; w4 < WP / 4; ++w4) {
+      const float4 q = *reinterpret_cast<const float4*>(&part[buf][w4 * 4]);
+      mx = fmaxf(fmaxf(mx, fmaxf(q.x, q.y)), fmaxf(q.z, q.w));
     }
-    cur = fps_unkey(~(unsigned)(m & 0xffffffffull), rb_log2);
+    if (mx > 0.f && tmax == mx) {
+      int best_s = 0;
+#pragma unroll
+      for (int s = PPT - 1; s >= 0; --s)
+        if (dist[s] == mx) best_s = s;  // first matching slot = smallest j of this reference lane
+      atomicMin(&win_key[buf], fps_key(best_s * T + tid, rb_log2));
+    }
+    __syncthreads();
+    const unsigned key = win_key[buf];
+    if (key != 0xffffffffu) cur = fps_unkey(key, rb_log2);  // else: every distance is 0 -> repeat cur
+    cur = __builtin_amdgcn_readfirstlane(cur);
+    if (tid == 0) out[i] = cur;
+  }
+}
+
+// -------------------------------------------------------------------------------------------
+// Large scenes: spatially sorted residency + wave-level skipping.
+//
+// A new centroid c can lower dist[p] only if |p - c|^2 < dist[p] <= (current maximum of p's
+// thread).  If the points a thread holds are spatially compact (bounding sphere (q, R)) the whole
+// thread is untouched whenever |q - c| >= R + sqrt(tmax_thread); if that holds for all 64 lanes the
+// wave skips the 25-point scan altogether.  Late in the sampling the active radius is a few cm, so
+// typically 1-3 of the 16 waves do the scan.  Results are IDENTICAL to the plain kernel: skipped
+// updates are provably no-ops (the test is conservative, inflated against fp32 rounding), and the
+// arg-max tie-break uses the ORIGINAL point index kept in LDS.
+//
+// Prologue (once per scene, inside the kernel, no workspace): counting sort of the points by the
+// Morton code of a 16x16x16 grid over the scene's bounding box (LDS histogram + scan + scatter of
+// the original indices), then thread t loads sorted positions [t*PPT, (t+1)*PPT).
+__device__ __forceinline__ unsigned spread4(unsigned v) {  // 4 bits -> every third bit
+  return (v & 1u) | ((v & 2u) << 2) | ((v & 4u) << 4) | ((v & 8u) << 6);
+}
+
+template <int PPT>
+__global__ __launch_bounds__(1024) void fps_sorted_kernel(const float* __restrict__ xyz, int64_t sb, int64_t sc,
+                                                          int64_t sn, int N, int M, int rb_log2,
+                                                          int64_t* __restrict__ index) {
+  constexpr int T = 1024, W = 16, CELLS = 4096;
+  __shared__ unsigned perm[T * PPT];   // sorted position -> original index (also the tie-break lookup)
+  __shared__ unsigned hist[CELLS];     // histogram, then exclusive offsets
+  __shared__ __attribute__((aligned(16))) float part[2][W];
+  __shared__ float red[6][W];
+  __shared__ unsigned wsum[W];
+  __shared__ unsigned win_key[2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* base = xyz + (int64_t)blockIdx.x * sb;
+  int64_t* out = index + (int64_t)blockIdx.x * M;
+
+  float px[PPT], py[PPT], pz[PPT], dist[PPT];
+  // ---- 1. bounding box of the scene --------------------------------------------------------
+  float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
+  float hi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+#pragma unroll
+  for (int s = 0; s < PPT; ++s) {
+    const int j = s * T + tid;
+    if (j < N) {
+      px[s] = base[(int64_t)j * sn];
+      py[s] = base[sc + (int64_t)j * sn];
+      pz[s] = base[2 * sc + (int64_t)j * sn];
+      lo[0] = fminf(lo[0], px[s]); hi[0] = fmaxf(hi[0], px[s]);
+      lo[1] = fminf(lo[1], py[s]); hi[1] = fmaxf(hi[1], py[s]);
+      lo[2] = fminf(lo[2], pz[s]); hi[2] = fmaxf(hi[2], pz[s]);
+    } else {
+      px[s] = py[s] = pz[s] = 0.f;
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      lo[a] = fminf(lo[a], __shfl_xor(lo[a], off, 64));
+      hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], off, 64));
+    }
+    if (lane == 0) { red[a][wave] = lo[a]; red[3 + a][wave] = hi[a]; }
+  }
+  for (int c = tid; c < CELLS; c += T) hist[c] = 0;
+  if (tid < 2 * W) (&part[0][0])[tid] = 0.f;
+  if (tid < 2) win_key[tid] = 0xffffffffu;
+  if (tid == 0) out[0] = 0;
+  __syncthreads();
+  float scale[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    float l = red[a][0], h = red[3 + a][0];
+#pragma unroll
+    for (int w = 1; w < W; ++w) { l = fminf(l, red[a][w]); h = fmaxf(h, red[3 + a][w]); }
+    lo[a] = l;
+    const float ext = h - l;
+    scale[a] = ext > 0.f ? 16.0f / ext : 0.f;
+  }
+  // ---- 2. counting sort by Morton cell ------------------------------------------------------
+  unsigned short cell[PPT], rank[PPT];
+#pragma unroll
+  for (int s = 0; s < PPT; ++s) {
+    const int j = s * T + tid;
+    cell[s] = 0; rank[s] = 0;
+    if (j < N) {
+      const unsigned qx = min(15u, (unsigned)((px[s] - lo[0]) * scale[0]));
+      const unsigned qy = min(15u, (unsigned)((py[s] - lo[1]) * scale[1]));
+      const unsigned qz = min(15u, (unsigned)((pz[s] - lo[2]) * scale[2]));
+      const unsigned c = spread4(qx) | (spread4(qy) << 1) | (spread4(qz) << 2);
+      cell[s] = (unsigned short)c;
+      rank[s] = (unsigned short)atomicAdd(&hist[c], 1u);
+    }
+  }
+  __syncthreads();
+  {  // exclusive scan of hist[4096]: 4 bins per thread, wave scan, scan of the 16 wave sums
+    unsigned h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
+    const unsigned local = h0 + h1 + h2 + h3;
+    unsigned incl = local;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const unsigned o = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += o;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    unsigned wbase = 0;
+#pragma unroll
+    for (int w = 0; w < W; ++w) wbase += (w < wave) ? wsum[w] : 0u;
+    unsigned o = wbase + incl - local;
+    hist[4 * tid] = o; o += h0;
+    hist[4 * tid + 1] = o; o += h1;
+    hist[4 * tid + 2] = o; o += h2;
+    hist[4 * tid + 3] = o;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < PPT; ++s) {
+    const int j = s * T + tid;
+    if (j < N) perm[hist[cell[s]] + rank[s]] = (unsigned)j;
+  }
+  __syncthreads();
+  // ---- 3. load this thread's spatially consecutive points + bounding sphere -------------------
+  float blo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
+  float bhi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+#pragma unroll
+  for (int s = 0; s < PPT; ++s) {
+    const int q = tid * PPT + s;
+    if (q < N) {
+      const int64_t j = perm[q];
+      px[s] = base[j * sn];
+      py[s] = base[sc + j * sn];
+      pz[s] = base[2 * sc + j * sn];
+      dist[s] = __builtin_inff();
+      blo[0] = fminf(blo[0], px[s]); bhi[0] = fmaxf(bhi[0], px[s]);
+      blo[1] = fminf(blo[1], py[s]); bhi[1] = fmaxf(bhi[1], py[s]);
+      blo[2] = fminf(blo[2], pz[s]); bhi[2] = fmaxf(bhi[2], pz[s]);
+    } else {
+      px[s] = py[s] = pz[s] = 0.f;
+      dist[s] = -1.f;
+    }
+  }
+  const bool has_points = tid * PPT < N;
+  const float qx = has_points ? 0.5f * (blo[0] + bhi[0]) : 0.f;
+  const float qy = has_points ? 0.5f * (blo[1] + bhi[1]) : 0.f;
+  const float qz = has_points ? 0.5f * (blo[2] + bhi[2]) : 0.f;
+  float r2 = 0.f;
+#pragma unroll
+  for (int s = 0; s < PPT; ++s)
+    if (tid * PPT + s < N) r2 = fmaxf(r2, sqdist3(px[s], py[s], pz[s], qx, qy, qz));
+  const float R = sqrtf(r2) * 1.0001f + 1e-12f;         // conservative cluster radius
+  float tmax = 0.f;
+  float thr = has_points ? __builtin_inff() : -1.f;      // update needed while |q - c|^2 < thr
+
+  int cur = 0;
+  for (int i = 1; i < M; ++i) {
+    const int buf = i & 1;
+#if FPS_ABLATE == 3
+    const float cx = 0.001f * cur, cy = 0.002f * cur, cz = 0.75f;  // no centroid load
+#else
+    const float cx = base[(int64_t)cur * sn];
+    const float cy = base[sc + (int64_t)cur * sn];
+    const float cz = base[2 * sc + (int64_t)cur * sn];
+#endif
+    const bool need = sqdist3(qx, qy, qz, cx, cy, cz) < thr;
+    if (FPS_ABLATE != 1 && (FPS_ABLATE == 4 || __ballot(need) != 0ull)) {  // wave-uniform: scan all 64 lanes' points (extra updates are no-ops)
+      float m = 0.f;
+#pragma unroll
+      for (int s = 0; s < PPT; ++s) {
+        const float nd = vmin_f32(dist[s], sqdist3(px[s], py[s], pz[s], cx, cy, cz));
+        dist[s] = nd;
+        m = fmaxf(m, nd);
+      }
+      tmax = m;
+      const float reach = R + sqrtf(m) * 1.0001f;
+      thr = has_points ? reach * reach * 1.0001f + 1e-30f : -1.f;
+    }
+    const float wmax = wave_max_f32(tmax);
+    if (lane == 0) part[buf][wave] = wmax;
+    if (tid == 0) win_key[buf ^ 1] = 0xffffffffu;
+    __syncthreads();
+    float mx = 0.f;
+#pragma unroll
+    for (int w4 = 0; w4 < W / 4; ++w4) {
+      const float4 v = *reinterpret_cast<const float4*>(&part[buf][w4 * 4]);
+      mx = fmaxf(fmaxf(mx, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+    }
+#if FPS_ABLATE == 2
+    cur = (i * 37) % N;  // no stage 2
+    if (mx < 0.f) cur = 0;
+#else
+    if (mx > 0.f && tmax == mx) {
+      unsigned kmin = 0xffffffffu;
+#pragma unroll
+      for (int s = 0; s < PPT; ++s)
+        if (dist[s] == mx) kmin = min(kmin, fps_key((int)perm[tid * PPT + s], rb_log2));
+      atomicMin(&win_key[buf], kmin);
+    }
+    __syncthreads();
+    const unsigned key = win_key[buf];
+    if (key != 0xffffffffu) cur = fps_unkey(key, rb_log2);
+#endif
     cur = __builtin_amdgcn_readfirstlane(cur);
     if (tid == 0) out[i] = cur;
   }
@@ -164,6 +415,10 @@ extern "C" int64_t regnet_fps_workspace_bytes(int64_t B, int64_t N, int64_t M) {
   hipLaunchKernelGGL((fps_resident_kernel<T, PPT>), dim3((unsigned)B), dim3(T), 0, st, xyz, sb, sc, sn, \
                      (int)N, (int)M, rbl, index)
 
+#define FPS_SORTED_CASE(PPT)                                                                          \
+  hipLaunchKernelGGL((fps_sorted_kernel<PPT>), dim3((unsigned)B), dim3(1024), 0, st, xyz, sb, sc, sn, \
+                     (int)N, (int)M, rbl, index)
+
 extern "C" int regnet_fps_f32(const float* xyz, int64_t sb, int64_t sc, int64_t sn, int64_t B, int64_t N, int64_t M,
                               int64_t* index, float* workspace, void* stream) {
   if (M <= 0 || N < M || B < 0) return REGNET_ERR_SHAPE;
@@ -184,10 +439,10 @@ extern "C" int regnet_fps_f32(const float* xyz, int64_t sb, int64_t sc, int64_t 
   else if (N <= 4096) FPS_CASE(512, 8);
   else if (N <= 6144) FPS_CASE(1024, 6);
   else if (N <= 8192) FPS_CASE(1024, 8);
-  else if (N <= 12288) FPS_CASE(1024, 12);
-  else if (N <= 16384) FPS_CASE(1024, 16);
-  else if (N <= 20480) FPS_CASE(1024, 20);
-  else if (N <= FPS_RESIDENT_MAX) FPS_CASE(1024, 25);
+  else if (N <= 12288) FPS_SORTED_CASE(12);
+  else if (N <= 16384) FPS_SORTED_CASE(16);
+  else if (N <= 20480) FPS_SORTED_CASE(20);
+  else if (N <= FPS_RESIDENT_MAX) FPS_SORTED_CASE(25);
   else {
     if (!workspace) return REGNET_ERR_NULL;
     hipLaunchKernelGGL((fps_streaming_kernel<1024>), dim3((unsigned)B), dim3(1024), 0, st, xyz, sb, sc, sn, (int)N,

@@ -68,13 +68,16 @@ def _signature(module):
 
 def _packed_stack(owner, stack, first_col_order=None):
     """Packed layers of a SharedMLP (list of conv/bn/relu blocks), cached on ``owner`` and rebuilt
-    whenever a parameter or BN buffer is modified (in-place updates bump ``_version``)."""
+    whenever a parameter or BN buffer is modified (in-place updates bump ``_version``).
+    ``first_col_order``: optional callable returning the column permutation of the first layer (only
+    evaluated on a cache miss -- it involves a host->device copy, which would stall the stream)."""
     sig = _signature(stack)
     cache = getattr(owner, "_regnet_packed", None)
     if cache is None or cache[0] != sig:
         layers = []
+        order = first_col_order() if first_col_order is not None else None
         for i, block in enumerate(stack):
-            layers.append(_pack(block.conv, block.bn, block.relu is not None, first_col_order if i == 0 else None))
+            layers.append(_pack(block.conv, block.bn, block.relu is not None, order if i == 0 else None))
         cache = (sig, layers)
         owner._regnet_packed = cache
     return cache[1]
@@ -188,8 +191,8 @@ def sa_features(module, xyz, feature, geo):
         raise NotImplementedError("fused SA without use_xyz")
     # reference channel order is [xyz(3) | feature] (modules.py:52); the kernel gathers
     # [feature | xyz], so permute the first layer's weight columns accordingly.
-    order = torch.cat([torch.arange(3, 3 + Cf), torch.arange(0, 3)])
-    layers = _packed_stack(module, module.mlp, order.to(xyz.device))
+    layers = _packed_stack(module, module.mlp,
+                           lambda: torch.cat([torch.arange(3, 3 + Cf), torch.arange(0, 3)]).to(xyz.device))
     h = sa_layer1(feature, xyz, geo["nbr"], geo["ctr"], layers[0], B, M, K)
     P = B * M * K
     for layer in layers[1:-1]:

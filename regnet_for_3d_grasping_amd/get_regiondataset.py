@@ -15,7 +15,7 @@ pickles and are outside this round's scope: ``data_paths`` must be empty.
 import numpy as np
 import torch
 
-from . import region_ops
+from . import np_random, region_ops
 from .pn2_utils import function as _F
 
 
@@ -41,13 +41,18 @@ def _select_score_center(pc, pre_score, center_num, score_thre):
     (get_regiondataset.py:354-434): FPS over the positive subset when there are more than
     ``center_num`` positives (its first positive point is always centre 0); all positives padded
     with random repeats when 0 < P <= center_num; random points when P == 0.  The B == 1 and
-    B > 1 branches of the reference implement the same rule and draw the same numpy variates."""
+    B > 1 branches of the reference implement the same rule and draw the same numpy variates.
+
+    One host sync for the whole batch (the positive counts); the ascending positive indices of
+    every scene come from one stable argsort instead of a ``torch.nonzero`` per scene."""
     B, N, C = pc.shape
     positive = pre_score.to(pc.device) > score_thre
+    order = torch.argsort((~positive).to(torch.uint8), dim=1, stable=True)   # positives first, ascending
+    counts = positive.sum(1).cpu().tolist()
     index = torch.empty((B, center_num), dtype=torch.int64, device=pc.device)
     for b in range(B):
-        map_index = torch.nonzero(positive[b]).view(-1)
-        P = int(map_index.numel())
+        P = int(counts[b])
+        map_index = order[b, :P]
         if P > center_num:
             sub_xyz = pc[b, map_index, :3].view(1, P, 3).transpose(2, 1)
             index[b] = map_index[_F.farthest_point_sample(sub_xyz, center_num).view(-1)]
@@ -70,19 +75,12 @@ def group_radius(width, height, depth, r_time):
 
 def _draw_positions(counts, group_num):
     """Host-side resampling of every (scene, centre) candidate list to exactly ``group_num``
-    entries, consuming numpy's global RNG in the reference's order (get_regiondataset.py:331-337).
+    entries, consuming numpy's global RNG in the reference's order (get_regiondataset.py:331-337:
+    scene-major, then centre; without replacement when ``n >= group_num`` else with).
     counts: (B,Nc) int array.  Returns positions (B,Nc,group_num) int64 into the ascending
-    candidate lists; rows with no candidate are -1."""
-    B, Nc = counts.shape
-    pos = np.full((B, Nc, group_num), -1, dtype=np.int64)
-    for b in range(B):
-        for c in range(Nc):
-            n = int(counts[b, c])
-            if n >= group_num:
-                pos[b, c] = np.random.choice(n, group_num, replace=False)
-            elif n > 0:
-                pos[b, c] = np.random.choice(n, group_num, replace=True)
-    return pos
+    candidate lists; rows with no candidate are -1.  The draws run in native host code that is
+    stream-compatible with numpy's legacy generator (np_random.choice_rows)."""
+    return np_random.choice_rows(counts, group_num, 0)[0]
 
 
 def _get_group_pc(pc, center_pc, center_pc_index, group_num, width, height, depth, r_time):

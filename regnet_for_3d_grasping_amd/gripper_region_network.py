@@ -21,7 +21,7 @@ import numpy as np
 import torch
 from torch import nn
 
-from . import region_ops
+from . import np_random, region_ops
 from .pointnet2 import PointNet2Refine, PointNet2TwoStage
 
 
@@ -139,7 +139,7 @@ class GripperRegionNetwork(nn.Module):
 
         next_grasp, loss_tuple, correct_tuple, next_gt, _, true_mask = self.compute_loss(x_reg, anchors, x_cls,
                                                                                         ground_grasp)
-        keep2 = [torch.sum((true_mask < (i + 1) * N_C) & (true_mask >= i * N_C)) for i in range(B)]
+        keep2 = _per_scene_counts(true_mask, N_C, B)
 
         res = (None,) * 5 + (None, None, None)
         keep3 = keep3_score = None
@@ -148,9 +148,8 @@ class GripperRegionNetwork(nn.Module):
                                       mp_center_feature, next_grasp.detach(), gripper_params, next_gt)
             final_mask, final_mask_sthre = res[3], res[4]
             if final_mask is not None:
-                keep3 = [torch.sum((final_mask < (i + 1) * N_C) & (final_mask >= i * N_C)) for i in range(B)]
-                keep3_score = [torch.sum((final_mask_sthre < (i + 1) * N_C) & (final_mask_sthre >= i * N_C))
-                               for i in range(B)]
+                keep3 = _per_scene_counts(final_mask, N_C, B)
+                keep3_score = _per_scene_counts(final_mask_sthre, N_C, B)
             else:
                 keep3, keep3_score = [0] * B, [0] * B
         (select_class, select_score, select_class_stage2, final_mask, final_mask_sthre, loss_refine_tuple,
@@ -158,6 +157,13 @@ class GripperRegionNetwork(nn.Module):
         return (next_grasp.detach(), keep2, true_mask, loss_tuple, correct_tuple, next_gt, select_class,
                 select_score, select_class_stage2, keep3, keep3_score, final_mask, final_mask_sthre,
                 loss_refine_tuple, correct_refine_tuple, gt)
+
+
+def _per_scene_counts(ids, per_scene, B):
+    """[#ids falling into scene i's range [i*per_scene, (i+1)*per_scene) for i in range(B)] as 0-dim
+    tensors (the reference builds the same list with B masked sums, :411, :424-425)."""
+    scene = torch.div(ids, per_scene, rounding_mode="floor").view(-1, 1)
+    return list((scene == torch.arange(B, device=ids.device).view(1, B)).sum(0).unbind(0))   # no host sync
 
 
 def _unit(v, fallback, eps):
@@ -211,18 +217,12 @@ def get_gripper_region_transform(group_points, group_index, grasp, region_num, g
     xlim, ylim = _half_extent(depths, n, dev), _half_extent(widths, n, dev)
     cand, count = region_ops.box_candidates(group_points, center, rot, xlim, ylim, height / 2)
 
-    counts = count.cpu().numpy()
-    pos = np.zeros((n, region_num), dtype=np.int64)
-    valid = np.zeros((n,), dtype=bool)
-    for i in range(n):
-        k = int(counts[i])
-        if k > region_num:
-            pos[i] = np.random.choice(k, region_num, replace=False)
-        elif k > 5:
-            pos[i] = np.random.choice(k, region_num, replace=True)
-        valid[i] = k > 5
+    # one sync for all grasps, then numpy-stream-compatible native draws in grasp order:
+    # > region_num candidates: without replacement; 6..region_num: with replacement; <= 5: invalid
+    pos, valid = np_random.choice_rows(count.cpu().numpy(), region_num, 1)
     pos_t = torch.from_numpy(pos).to(dev)
     valid_t = torch.from_numpy(valid).to(dev)
+    valid_ids = torch.from_numpy(np.nonzero(valid)[0]).to(dev)
 
     # positions inside the group; rows without a valid crop hold unwritten candidate slots -> 0
     index = torch.where(valid_t.view(n, 1), torch.gather(cand, 1, pos_t).long(), torch.zeros_like(pos_t))
@@ -235,7 +235,7 @@ def get_gripper_region_transform(group_points, group_index, grasp, region_num, g
     gripper_pc = torch.where(valid_t.view(n, 1, 1), gripper_pc, minus1.view(1, 1, 1))
     index = torch.where(valid_t.view(n, 1), index, minus1.view(1, 1))
     index_inall = torch.where(valid_t.view(n, 1), index_inall, minus1.view(1, 1))
-    return gripper_pc, index, index_inall, torch.nonzero(valid_t).view(-1)
+    return gripper_pc, index, index_inall, valid_ids
 
 
 def _enumerate_templates():

@@ -69,9 +69,12 @@ class ForwardPipeline:
         self.score_net, self.region_net, self.with_region = score_net, region_net, with_region
         dev = next(score_net.parameters()).device
         self.device = dev
-        self.s_geo = torch.cuda.Stream(dev)
-        self.s_mlp = torch.cuda.Stream(dev)
-        self.s_reg = torch.cuda.Stream(dev)
+        # Priorities: the region stage is a chain of small kernels separated by host syncs (numpy
+        # RNG draws) and FPS is a single-CU latency chain -- neither may queue behind the big MLP
+        # launches, so both get high-priority HW queues and the MFMA stream the default one.
+        self.s_geo = torch.cuda.Stream(dev, priority=-1)
+        self.s_mlp = torch.cuda.Stream(dev, priority=0)
+        self.s_reg = torch.cuda.Stream(dev, priority=-1)
 
     # -- stages -------------------------------------------------------------------------------
     def _geometry(self, pc):

@@ -1,0 +1,33 @@
+// Ablation harness for the FPS kernels: hipcc -DFPS_ABLATE=n ... ; times B scenes of N points.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "../../regnet_for_3d_grasping_amd/csrc/geometry.hip"
+
+int main(int argc, char** argv) {
+  int B = 8, N = argc > 1 ? atoi(argv[1]) : 25600, M = argc > 2 ? atoi(argv[2]) : 5120;
+  std::vector<float> h((size_t)B * N * 3);
+  srand(1);
+  for (int b = 0; b < B; ++b)
+    for (int j = 0; j < N; ++j) {
+      h[((size_t)b * N + j) * 3 + 0] = -0.4f + 0.8f * rand() / RAND_MAX;
+      h[((size_t)b * N + j) * 3 + 1] = -0.35f + 0.7f * rand() / RAND_MAX;
+      h[((size_t)b * N + j) * 3 + 2] = 0.75f + ((rand() % 10) < 6 ? 0.001f * rand() / RAND_MAX : 0.1f * rand() / RAND_MAX);
+    }
+  float* d; int64_t* idx;
+  hipMalloc(&d, h.size() * 4); hipMalloc(&idx, (size_t)B * M * 8);
+  hipMemcpy(d, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+  hipEvent_t s, e; hipEventCreate(&s); hipEventCreate(&e);
+  regnet_fps_f32(d, (int64_t)N * 3, 1, 3, B, N, M, idx, nullptr, nullptr);
+  hipDeviceSynchronize();
+  hipEventRecord(s);
+  for (int r = 0; r < 3; ++r) regnet_fps_f32(d, (int64_t)N * 3, 1, 3, B, N, M, idx, nullptr, nullptr);
+  hipEventRecord(e); hipEventSynchronize(e);
+  float ms; hipEventElapsedTime(&ms, s, e);
+  std::vector<int64_t> out((size_t)B * M);
+  hipMemcpy(out.data(), idx, out.size() * 8, hipMemcpyDeviceToHost);
+  long long cs = 0; for (auto v : out) cs += v;
+  printf("ABLATE=%d N=%d M=%d: %.3f ms  %.3f us/round  checksum %lld\n", FPS_ABLATE, N, M, ms / 3, ms / 3 * 1e3 / (M - 1), cs);
+  return 0;
+}

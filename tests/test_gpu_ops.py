@@ -55,6 +55,8 @@ FPS_CASES = [  # (B, N, M, dup, grid)
     (3, 20, 7, 0, None), (1, 64, 64, 0, None), (2, 300, 300, 0.3, None), (2, 2048, 512, 0.5, None),
     (2, 4096, 1024, 0, 0.05), (1, 700, 200, 0, 0.1), (1, 17, 17, 0.5, 0.2), (1, 9000, 700, 0.2, 0.02),
     (1, 13000, 300, 0, None), (1, 20000, 300, 0.1, None),
+    # spatially sorted kernel (N > 8192): heavy ties / duplicates / degenerate extents
+    (1, 12000, 2000, 0.3, 0.05), (2, 25600, 1000, 0.5, 0.01), (1, 9000, 9000, 0.1, None), (1, 16000, 500, 0.9, 0.1),
 ]
 
 
@@ -71,6 +73,19 @@ def test_fps_bit_exact(ext, orc, B, N, M, dup, grid):
 def test_fps_all_identical_points(ext, orc):
     x = torch.ones(2, 3, 130) * 0.25
     assert torch.equal(ext.farthest_point_sample(x.to(DEV), 40).cpu(), orc.farthest_point_sample(x, 40))
+    x = torch.ones(1, 3, 10000) * 0.25   # sorted kernel, zero-extent bounding box
+    assert torch.equal(ext.farthest_point_sample(x.to(DEV), 50).cpu(), orc.farthest_point_sample(x, 50))
+
+
+def test_fps_sorted_kernel_planar_and_collinear(ext, orc):
+    rng = np.random.default_rng(9)
+    p = rng.uniform(-1, 1, (1, 11000, 3)).astype(np.float32)
+    p[:, :, 2] = 0.75                      # all points in one z plane (flat table)
+    x = torch.from_numpy(p).transpose(1, 2)
+    assert torch.equal(ext.farthest_point_sample(x.to(DEV), 800).cpu(), orc.farthest_point_sample(x, 800))
+    p[:, :, 1] = -0.2                      # ... and on one line
+    x = torch.from_numpy(p).transpose(1, 2)
+    assert torch.equal(ext.farthest_point_sample(x.to(DEV), 800).cpu(), orc.farthest_point_sample(x, 800))
 
 
 def test_fps_full_size_25600(ext, orc):
