@@ -125,7 +125,7 @@ int regnet_gather_max_f32(const float* feat, int64_t num_rows, int64_t F, const 
  * SharedMLP (pn2_utils/nn/modules/mlp.py:55-114, conv.py:6-76) inside PointNetSAModule.forward
  * (pn2_utils/modules.py:210-246), PointnetFPModule.forward (:500-509) and the head
  * (utils/pointnet2.py:116-119).  W is packed [Npad][Kpad] (Npad multiple of 128, Kpad multiple of
- * 32, zero padded); scale/shift are the eval-mode BatchNorm folded to a per-channel affine.
+ * 16, zero padded); scale/shift are the eval-mode BatchNorm folded to a per-channel affine.
  *
  * regnet_mlp_layer_f32: C[P,N] = act(scale * (A[P,Ka] . W^T) + shift); pool_group == 64 additionally
  * takes the max over every 64 consecutive rows (torch.max(x, 3), modules.py:245) -> C[P/64, N].  */

@@ -439,6 +439,11 @@ extern "C" int regnet_fps_f32(const float* xyz, int64_t sb, int64_t sc, int64_t 
   else if (N <= 4096) FPS_CASE(512, 8);
   else if (N <= 6144) FPS_CASE(1024, 6);
   else if (N <= 8192) FPS_CASE(1024, 8);
+  // the counting-sort prologue of the sorted kernel costs ~0.7 ms: only worth it for long runs
+  else if (M < 1024 && N <= 12288) FPS_CASE(1024, 12);
+  else if (M < 1024 && N <= 16384) FPS_CASE(1024, 16);
+  else if (M < 1024 && N <= 20480) FPS_CASE(1024, 20);
+  else if (M < 1024 && N <= FPS_RESIDENT_MAX) FPS_CASE(1024, 25);
   else if (N <= 12288) FPS_SORTED_CASE(12);
   else if (N <= 16384) FPS_SORTED_CASE(16);
   else if (N <= 20480) FPS_SORTED_CASE(20);

@@ -15,9 +15,9 @@
 // k order inside an 8-wide slab is therefore permuted identically for A and W (a sum is order
 // independent up to fp32 rounding).
 //
-// Tile: 128 points x 128 channels x 32 k per workgroup of 4 waves (2x2), each wave 64x64 =
-// 2x2 v_mfma_f32_32x32x2_f32 accumulators (64 VGPRs).  LDS rows are padded to 36 floats so the
-// 16-lane service groups of ds_read_b128 hit 64 distinct banks.  Global->LDS goes through
+// Tile: 128 points x 128 channels x BK k per workgroup of 4 waves (2x2), each wave 64x64 =
+// 2x2 v_mfma_f32_32x32x2_f32 accumulators (64 VGPRs).  LDS rows are padded by 4 floats so the
+// 16-lane service groups of ds_read_b128 hit 64 distinct banks (SQ_LDS_BANK_CONFLICT = 0).  Global->LDS goes through
 // registers (the gather prologue needs per-row pointers), prefetching tile t+1 while tile t is
 // multiplied; two LDS buffers, one barrier per k-tile.
 #include "common.h"
@@ -26,9 +26,19 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define BM 128
 #define BN 128
-#define BK 32
-#define LDS_LD 36
 #define MLP_THREADS 256
+#ifndef MLP_BK
+#define MLP_BK 16  // k-depth of one LDS tile: 16 -> 41 KB LDS and <=128 VGPRs = 4 workgroups/CU (measured
+                   // 91 vs 77 TFLOP/s over the ScoreNet shapes against 32 -> 74 KB, 2 workgroups/CU: the
+                   // extra resident waves cover the global-load latency of the short-K layers)
+#endif
+#define BK MLP_BK
+#define LDS_LD (BK + 4)  // +4 floats: the 16-lane service groups of ds_read_b128 then hit 64 distinct banks
+#define ROWS_PER_PASS (MLP_THREADS / (BK / 4))  // rows one staging pass of the 256 threads covers
+#define STAGE_PASSES (BM / ROWS_PER_PASS)
+#ifndef MLP_MIN_WAVES
+#define MLP_MIN_WAVES (BK == 32 ? 2 : 4)
+#endif
 
 struct MlpArgs {
   // ---- A operand, plain mode: rows of a channels-last activation buffer
@@ -75,7 +85,7 @@ __device__ __forceinline__ void xcd_tile(int& tm, int& tn, int tiles_m, int tile
 }
 
 template <bool GATHER, bool POOL>
-__global__ __launch_bounds__(MLP_THREADS, 2) void mlp_gemm_kernel(const MlpArgs p) {
+__global__ __launch_bounds__(MLP_THREADS, MLP_MIN_WAVES) void mlp_gemm_kernel(const MlpArgs p) {
   __shared__ __attribute__((aligned(16))) float sA[2][BM][LDS_LD];
   __shared__ __attribute__((aligned(16))) float sW[2][BN][LDS_LD];
 
@@ -89,16 +99,16 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void mlp_gemm_kernel(const MlpArgs 
   const long long row0 = (long long)tm * BM;
   const int col0 = tn * BN;
 
-  // staging map: thread -> (row r + 32*i, 4 columns starting at 4*c4)
-  const int sr = tid >> 3, c4 = tid & 7;
+  // staging map: thread -> (row sr + ROWS_PER_PASS*i, 4 columns starting at 4*c4)
+  const int sr = tid / (BK / 4), c4 = tid % (BK / 4);
 
   // per-row source pointers
-  const float* arow[4];
-  bool arow_ok[4];
-  float relx[4], rely[4], relz[4];
+  const float* arow[STAGE_PASSES];
+  bool arow_ok[STAGE_PASSES];
+  float relx[STAGE_PASSES], rely[STAGE_PASSES], relz[STAGE_PASSES];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const long long row = row0 + sr + 32 * i;
+  for (int i = 0; i < STAGE_PASSES; ++i) {
+    const long long row = row0 + sr + ROWS_PER_PASS * i;
     arow_ok[i] = row < p.P;
     const long long rs = arow_ok[i] ? row : 0;
     if (GATHER) {
@@ -115,15 +125,15 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void mlp_gemm_kernel(const MlpArgs 
       relx[i] = rely[i] = relz[i] = 0.f;
     }
   }
-  const float* wrow[4];
+  const float* wrow[STAGE_PASSES];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) wrow[i] = p.W + (long long)(col0 + sr + 32 * i) * p.Kpad;
+  for (int i = 0; i < STAGE_PASSES; ++i) wrow[i] = p.W + (long long)(col0 + sr + ROWS_PER_PASS * i) * p.Kpad;
 
-  float4 ra[4], rw[4];
+  float4 ra[STAGE_PASSES], rw[STAGE_PASSES];
   auto load_tile = [&](int k0) {
     const int kc = k0 + 4 * c4;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < STAGE_PASSES; ++i) {
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (arow_ok[i]) {
         if (GATHER) {
@@ -153,9 +163,9 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void mlp_gemm_kernel(const MlpArgs 
   };
   auto store_tile = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      *reinterpret_cast<float4*>(&sA[buf][sr + 32 * i][4 * c4]) = ra[i];
-      *reinterpret_cast<float4*>(&sW[buf][sr + 32 * i][4 * c4]) = rw[i];
+    for (int i = 0; i < STAGE_PASSES; ++i) {
+      *reinterpret_cast<float4*>(&sA[buf][sr + ROWS_PER_PASS * i][4 * c4]) = ra[i];
+      *reinterpret_cast<float4*>(&sW[buf][sr + ROWS_PER_PASS * i][4 * c4]) = rw[i];
     }
   };
 

@@ -47,7 +47,7 @@ def _pack(conv, bn, relu, col_order=None):
         w = w[:, col_order]
         K = w.shape[1]
     L = _Layer()
-    L.N, L.K, L.Kpad, L.relu = N, K, _round_up(max(K, 1), 32), 1 if relu else 0
+    L.N, L.K, L.Kpad, L.relu = N, K, _round_up(max(K, 1), 16), 1 if relu else 0
     Wp = torch.zeros((_round_up(N, 128), L.Kpad), dtype=torch.float32, device=w.device)
     Wp[:N, :K] = w
     if bn is not None:
