@@ -127,6 +127,25 @@ def algorithmic_work(name, meta):
     return "hbm", 0
 
 
+# host wrapper -> device kernel it launches (for grouping launches into kernel families)
+KERNEL_OF = {"mlp_layer": "mlp_gemm_kernel", "sa_layer1": "mlp_gemm_kernel", "sa_layer12": "mlp_gemm_kernel",
+             "farthest_point_sample": "fps_kernel", "ball_query": "ball_query_kernel",
+             "point_search": "three_nn_kernel", "radius_candidates": "radius_group_kernel",
+             "box_candidates": "box_crop_kernel", "gather_max": "gather_max_kernel"}
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of ``kernel`` from the rocprofv3 PMC passes of this same command
+    (FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 corrections applied; produced by
+    scripts/collect_pmc.py and committed under profiles/).  None when no such file exists."""
+    path = os.path.join(REPO, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get(kernel, {}).get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_baseline(args, n_scenes):
     """The same forward on the host CPU: the host-side mirror driven by the C oracle (OpenMP) and
     torch-CPU 1x1 convs.  Bounded sample: ``n_scenes`` scenes of the bench workload, batch 1."""
@@ -220,19 +239,31 @@ def main():
         by_time = sorted(agg.items(), key=lambda kv: -kv[1][0])
         kernels = [{"op": k[0], "shape": k[1], "calls": c, "avg_ms": round(tot / c, 4), "total_ms": round(tot, 3)}
                    for k, (tot, c) in by_time]
-        roofline = None
-        if by_time:
-            (name, meta), (tot, cnt) = by_time[0]
+        # kernel families: every mlp_layer / sa_layer1 launch is the same device kernel (mlp_gemm_kernel)
+        fam = {}
+        for (name, meta), (tot, cnt) in agg.items():
             bound, units = algorithmic_work(name, meta)
-            avg_s = tot / cnt / 1e3
-            if bound == "hbm":
-                achieved, peak, unit = units / avg_s / 1e9, HBM_PEAK_GBS, "GB/s"
+            key = KERNEL_OF.get(name, name)
+            f = fam.setdefault(key, {"ms": 0.0, "launches": 0, "units": 0, "bound": bound})
+            f["ms"] += tot
+            f["launches"] += cnt
+            f["units"] += units * cnt
+        roofline = None
+        if fam:
+            dom = max(fam, key=lambda k: fam[k]["ms"])
+            f = fam[dom]
+            avg_s = f["ms"] / f["launches"] / 1e3
+            per_launch = f["units"] / f["launches"]
+            if f["bound"] == "hbm":
+                achieved, peak, unit = per_launch / avg_s / 1e9, HBM_PEAK_GBS, "GB/s"
             else:
-                achieved, peak, unit = units / avg_s / 1e12, MFMA_F32_PEAK_TFLOPS, "TFLOP/s"
-            roofline = {"bound": bound, "achieved": round(achieved, 4), "peak": peak, "unit": unit,
-                        "frac": round(achieved / peak, 6), "traffic": None, "kernel": name, "shape": meta,
-                        "avg_launch_ms": round(tot / cnt, 4), "launches": cnt,
-                        "algorithmic_units_per_launch": units}
+                achieved, peak, unit = per_launch / avg_s / 1e12, MFMA_F32_PEAK_TFLOPS, "TFLOP/s"
+            roofline = {"bound": f["bound"], "achieved": round(achieved, 4), "peak": peak, "unit": unit,
+                        "frac": round(achieved / peak, 6), "traffic": pmc_traffic(dom), "kernel": dom,
+                        "avg_launch_ms": round(f["ms"] / f["launches"], 4), "launches": f["launches"],
+                        "algorithmic_units_per_launch": round(per_launch),
+                        "families_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in
+                                                 sorted(fam.items(), key=lambda kv: -kv[1]["ms"])[:6]}}
         res = {
             "metric": "scenes/sec (25 600-pt ScoreNet+GRN fwd)", "value": round(total_scenes / dt, 3),
             "unit": "scenes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -145,6 +145,18 @@ int regnet_sa_layer1_f32(const float* feat, int64_t fb, int64_t fn, int64_t fc, 
                          int64_t Kpad, const float* scale, const float* shift, float* C, int64_t ldc,
                          int64_t N, int relu, void* stream);
 
+/* regnet_sa_layer12_f32: like regnet_sa_layer1_f32 but with the FIRST TWO SharedMLP layers of the block in
+ * one kernel, for blocks whose gathered input is narrow (Cf + 3 <= 8, i.e. the level-1 SA of ScoreNet:
+ * 3 rgb + 3 xyz).  Layer 1 (W1 packed [C1][8] with columns [feat | xyz | 0], folded BN scale1/shift1,
+ * ReLU) runs on the VALU inside the operand load of layer 2 (W packed [Npad][Kpad = C1]); the (P x C1)
+ * layer-1 activation never reaches HBM.  pool_group as in regnet_mlp_layer_f32.                      */
+int regnet_sa_layer12_f32(const float* feat, int64_t fb, int64_t fn, int64_t fc, int64_t Cf,
+                          const float* xyz, int64_t xb, int64_t xc, int64_t xn, const int64_t* nbr,
+                          const int64_t* ctr, int64_t B, int64_t M, int64_t group, const float* W1,
+                          const float* scale1, const float* shift1, int64_t C1, const float* W,
+                          int64_t Kpad, const float* scale, const float* shift, float* C, int64_t ldc,
+                          int64_t N, int relu, int pool_group, void* stream);
+
 /* regnet_interp_concat_f32: FeatureInterpolator.forward (modules.py:104-131) channels-last:
  * out[b*Nd+n] = [sum_k w_k * sparse[b, idx[b,n,k], 0:Cs] | dense[b,n,0:Cd] | 0...], w from squared
  * distances (inv = 1/max(d2,eps), w = inv/sum).  sparse (b,n,:) at sparse[b*sb + n*sn + c];

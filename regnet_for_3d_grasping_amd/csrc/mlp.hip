@@ -63,6 +63,13 @@ struct MlpArgs {
   int Kpad;
   const float* scale;
   const float* shift;
+  // ---- gather mode with the FIRST MLP layer fused into the operand load (AMODE 2): the gathered
+  //      row x = [feat | rel xyz] (Cf + 3 <= 8 inputs) is pushed through layer 1 on the VALU while
+  //      it is staged,  A[p][k] = relu(scale1[k] * dot(W1[k][0:8], x) + shift1[k]),  so the
+  //      (P x C1) activation of layer 1 never goes to HBM.  W1 is packed [C1][8] (zero padded).
+  const float* W1;
+  const float* scale1;
+  const float* shift1;
   // ---- output
   float* C;
   long long ldc;
@@ -84,12 +91,24 @@ __device__ __forceinline__ void xcd_tile(int& tm, int& tn, int tiles_m, int tile
   tn = (int)(t % tiles_n);
 }
 
-template <bool GATHER, bool POOL>
-__global__ __launch_bounds__(MLP_THREADS, MLP_MIN_WAVES) void mlp_gemm_kernel(const MlpArgs p) {
+template <int AMODE, bool POOL>
+__global__ __launch_bounds__(MLP_THREADS, AMODE == 2 ? 3 : MLP_MIN_WAVES) void mlp_gemm_kernel(const MlpArgs p) {
   __shared__ __attribute__((aligned(16))) float sA[2][BM][LDS_LD];
   __shared__ __attribute__((aligned(16))) float sW[2][BN][LDS_LD];
+  __shared__ __attribute__((aligned(16))) float sW1[AMODE == 2 ? 256 * 10 : 4];  // [C1 <= 256][8 weights | scale | shift]
 
+  constexpr bool GATHER = AMODE != 0;
+  constexpr bool FUSE1 = AMODE == 2;
   const int tid = threadIdx.x;
+  if (FUSE1) {
+    for (int k = tid; k < p.Kpad; k += MLP_THREADS) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) sW1[k * 10 + c] = p.W1[(long long)k * 8 + c];
+      sW1[k * 10 + 8] = p.scale1[k];
+      sW1[k * 10 + 9] = p.shift1[k];
+    }
+    __syncthreads();
+  }
   const int lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const int tiles_n = (p.N + BN - 1) / BN;
@@ -106,6 +125,7 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_MIN_WAVES) void mlp_gemm_kernel(co
   const float* arow[STAGE_PASSES];
   bool arow_ok[STAGE_PASSES];
   float relx[STAGE_PASSES], rely[STAGE_PASSES], relz[STAGE_PASSES];
+  float xin[STAGE_PASSES][8];  // FUSE1: the gathered layer-1 input row [feat | rel xyz | 0]
 #pragma unroll
   for (int i = 0; i < STAGE_PASSES; ++i) {
     const long long row = row0 + sr + ROWS_PER_PASS * i;
@@ -120,6 +140,17 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_MIN_WAVES) void mlp_gemm_kernel(co
       relx[i] = xb[j * p.xn] - xb[cj * p.xn];
       rely[i] = xb[p.xc + j * p.xn] - xb[p.xc + cj * p.xn];
       relz[i] = xb[2 * p.xc + j * p.xn] - xb[2 * p.xc + cj * p.xn];
+      if (FUSE1) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          float x = 0.f;
+          if (c < p.Cf) x = arow[i][(long long)c * p.fc];
+          else if (c == p.Cf) x = relx[i];
+          else if (c == p.Cf + 1) x = rely[i];
+          else if (c == p.Cf + 2) x = relz[i];
+          xin[i][c] = arow_ok[i] ? x : 0.f;
+        }
+      }
     } else {
       arow[i] = p.A + rs * p.lda;
       relx[i] = rely[i] = relz[i] = 0.f;
@@ -136,7 +167,18 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_MIN_WAVES) void mlp_gemm_kernel(co
     for (int i = 0; i < STAGE_PASSES; ++i) {
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (arow_ok[i]) {
-        if (GATHER) {
+        if (FUSE1) {
+          float e[4];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const float* w = &sW1[(kc + t) * 10];
+            float acc = w[0] * xin[i][0];
+#pragma unroll
+            for (int c = 1; c < 8; ++c) acc += w[c] * xin[i][c];
+            e[t] = fmaxf(acc * w[8] + w[9], 0.f);
+          }
+          v = make_float4(e[0], e[1], e[2], e[3]);
+        } else if (GATHER) {
           if (p.feat_vec && kc + 4 <= p.Cf) {
             v = *reinterpret_cast<const float4*>(arow[i] + kc);
           } else {
@@ -243,15 +285,17 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_MIN_WAVES) void mlp_gemm_kernel(co
   }
 }
 
-static int launch_gemm(const MlpArgs& a, bool gather, bool pool, hipStream_t st) {
+static int launch_gemm(const MlpArgs& a, int amode, bool pool, hipStream_t st) {
   const long long tiles = ((a.P + BM - 1) / BM) * ((a.N + BN - 1) / BN);
   if (tiles <= 0) return REGNET_OK;
   if (tiles >= (1ll << 31)) return REGNET_ERR_UNSUPPORTED;
   dim3 grid((unsigned)tiles), block(MLP_THREADS);
-  if (gather && pool) hipLaunchKernelGGL((mlp_gemm_kernel<true, true>), grid, block, 0, st, a);
-  else if (gather) hipLaunchKernelGGL((mlp_gemm_kernel<true, false>), grid, block, 0, st, a);
-  else if (pool) hipLaunchKernelGGL((mlp_gemm_kernel<false, true>), grid, block, 0, st, a);
-  else hipLaunchKernelGGL((mlp_gemm_kernel<false, false>), grid, block, 0, st, a);
+  if (amode == 2 && pool) hipLaunchKernelGGL((mlp_gemm_kernel<2, true>), grid, block, 0, st, a);
+  else if (amode == 2) hipLaunchKernelGGL((mlp_gemm_kernel<2, false>), grid, block, 0, st, a);
+  else if (amode == 1 && pool) hipLaunchKernelGGL((mlp_gemm_kernel<1, true>), grid, block, 0, st, a);
+  else if (amode == 1) hipLaunchKernelGGL((mlp_gemm_kernel<1, false>), grid, block, 0, st, a);
+  else if (pool) hipLaunchKernelGGL((mlp_gemm_kernel<0, true>), grid, block, 0, st, a);
+  else hipLaunchKernelGGL((mlp_gemm_kernel<0, false>), grid, block, 0, st, a);
   REGNET_LAUNCH_CHECK();
   return REGNET_OK;
 }
@@ -270,7 +314,7 @@ extern "C" int regnet_mlp_layer_f32(const float* A, int64_t lda, int64_t Ka, con
   a.A = A; a.lda = lda; a.Ka = (int)Ka;
   a.W = W; a.Kpad = (int)Kpad; a.scale = scale; a.shift = shift;
   a.C = C; a.ldc = ldc; a.P = P; a.N = (int)N; a.relu = relu; a.group = 64; a.rows_per_scene = 1;
-  return launch_gemm(a, false, pool_group != 0, as_stream(stream));
+  return launch_gemm(a, 0, pool_group != 0, as_stream(stream));
 }
 
 extern "C" int regnet_sa_layer1_f32(const float* feat, int64_t fb, int64_t fn, int64_t fc, int64_t Cf,
@@ -290,7 +334,31 @@ extern "C" int regnet_sa_layer1_f32(const float* feat, int64_t fb, int64_t fn, i
   a.group = (int)group; a.rows_per_scene = M * group;
   a.W = W; a.Kpad = (int)Kpad; a.scale = scale; a.shift = shift;
   a.C = C; a.ldc = ldc; a.P = P; a.N = (int)N; a.relu = relu;
-  return launch_gemm(a, true, false, as_stream(stream));
+  return launch_gemm(a, 1, false, as_stream(stream));
+}
+
+extern "C" int regnet_sa_layer12_f32(const float* feat, int64_t fb, int64_t fn, int64_t fc, int64_t Cf,
+                                     const float* xyz, int64_t xb, int64_t xc, int64_t xn, const int64_t* nbr,
+                                     const int64_t* ctr, int64_t B, int64_t M, int64_t group, const float* W1,
+                                     const float* scale1, const float* shift1, int64_t C1, const float* W,
+                                     int64_t Kpad, const float* scale, const float* shift, float* C, int64_t ldc,
+                                     int64_t N, int relu, int pool_group, void* stream) {
+  if (B < 0 || M < 0 || group <= 0 || N <= 0 || Cf < 0 || Cf + 3 > 8 || C1 <= 0 || C1 > 256 || Kpad != C1 || Kpad % BK)
+    return REGNET_ERR_SHAPE;
+  if (pool_group != 0 && (pool_group != 64 || group != 64)) return REGNET_ERR_UNSUPPORTED;
+  const long long P = B * M * group;
+  if (P == 0) return REGNET_OK;
+  if (!xyz || !nbr || !ctr || !W1 || !scale1 || !shift1 || !W || !scale || !shift || !C || (Cf > 0 && !feat))
+    return REGNET_ERR_NULL;
+  if (!aligned16(W) || !aligned16(W1)) return REGNET_ERR_SHAPE;
+  MlpArgs a = {};
+  a.feat = Cf > 0 ? feat : nullptr; a.fb = fb; a.fn = fn; a.fc = fc; a.Cf = (int)Cf;
+  a.xyz = xyz; a.xb = xb; a.xc = xc; a.xn = xn; a.nbr = (const long long*)nbr; a.ctr = (const long long*)ctr;
+  a.group = (int)group; a.rows_per_scene = M * group;
+  a.W1 = W1; a.scale1 = scale1; a.shift1 = shift1;
+  a.W = W; a.Kpad = (int)Kpad; a.scale = scale; a.shift = shift;
+  a.C = C; a.ldc = ldc; a.P = P; a.N = (int)N; a.relu = relu;
+  return launch_gemm(a, 2, pool_group != 0, as_stream(stream));
 }
 
 // ---------------------------------------------------------------------------------------

@@ -37,7 +37,7 @@ def _round_up(x, m):
 class _Layer:
     """One conv(1x1, bias-free or biased) + eval BatchNorm (+ReLU) packed for the GEMM kernel."""
 
-    __slots__ = ("W", "scale", "shift", "N", "K", "Kpad", "relu")
+    __slots__ = ("W", "W8", "scale", "shift", "N", "K", "Kpad", "relu")
 
 
 def _pack(conv, bn, relu, col_order=None):
@@ -59,6 +59,11 @@ def _pack(conv, bn, relu, col_order=None):
     if conv.bias is not None:
         shift = shift + conv.bias.detach().float() * scale
     L.W, L.scale, L.shift = Wp.contiguous(), scale.contiguous(), shift.contiguous()
+    L.W8 = None
+    if K <= 8:  # narrow first layer: also keep the [N][8] form consumed by the layer-1-fused gather kernel
+        W8 = torch.zeros((N, 8), dtype=torch.float32, device=w.device)
+        W8[:, :K] = w
+        L.W8 = W8.contiguous()
     return L
 
 
@@ -105,6 +110,23 @@ def sa_layer1(feature, xyz, nbr, ctr, layer, B, M, group):
                                    B, M, group, layer.W.data_ptr(), layer.Kpad, layer.scale.data_ptr(),
                                    layer.shift.data_ptr(), out.data_ptr(), out.stride(0), layer.N, layer.relu,
                                    _stream(xyz)), "sa_layer1")
+    return out
+
+
+def sa_layer12(feature, xyz, nbr, ctr, first, layer, B, M, group, pool_group=0):
+    """Gather + layer 1 (VALU, inside the operand load) + layer 2 (MFMA) of a narrow-input SA block."""
+    P = B * M * group
+    rows = P // pool_group if pool_group else P
+    out = torch.empty((rows, layer.N), dtype=torch.float32, device=xyz.device)
+    if feature is None:
+        fptr, fb, fn, fc, Cf = None, 0, 0, 0, 0
+    else:
+        fptr, (fb, fc, fn), Cf = feature.data_ptr(), feature.stride(), feature.size(1)
+    _check(_L.regnet_sa_layer12_f32(fptr, fb, fn, fc, Cf, xyz.data_ptr(), *xyz.stride(), nbr.data_ptr(),
+                                    ctr.data_ptr(), B, M, group, first.W8.data_ptr(), first.scale.data_ptr(),
+                                    first.shift.data_ptr(), first.N, layer.W.data_ptr(), layer.Kpad,
+                                    layer.scale.data_ptr(), layer.shift.data_ptr(), out.data_ptr(), out.stride(0),
+                                    layer.N, layer.relu, pool_group, _stream(xyz)), "sa_layer12")
     return out
 
 
@@ -157,6 +179,9 @@ def _flop_meta(P, K, N):
 TIMED_OPS = {
     "mlp_layer": lambda A, Ka, layer, P, pool_group=0: _flop_meta(P, layer.K, layer.N),
     "sa_layer1": lambda feature, xyz, nbr, ctr, layer, B, M, group: _flop_meta(B * M * group, layer.K, layer.N),
+    "sa_layer12": lambda feature, xyz, nbr, ctr, first, layer, B, M, group, pool_group=0:
+        "P%d K%d N%d flop%d" % (B * M * group, layer.K, layer.N,
+                                2 * B * M * group * (layer.K * layer.N + first.K * first.N)),
 }
 
 
@@ -193,11 +218,21 @@ def sa_features(module, xyz, feature, geo):
     # [feature | xyz], so permute the first layer's weight columns accordingly.
     layers = _packed_stack(module, module.mlp,
                            lambda: torch.cat([torch.arange(3, 3 + Cf), torch.arange(0, 3)]).to(xyz.device))
-    h = sa_layer1(feature, xyz, geo["nbr"], geo["ctr"], layers[0], B, M, K)
     P = B * M * K
-    for layer in layers[1:-1]:
+    if layers[0].W8 is not None and layers[0].N % 16 == 0 and layers[0].relu:
+        # narrow gathered input (level 1: rgb + xyz): layer 1 is recomputed on the VALU inside layer 2's
+        # operand load, its (P x C1) activation never exists in HBM
+        if len(layers) == 2:
+            pooled = sa_layer12(feature, xyz, geo["nbr"], geo["ctr"], layers[0], layers[1], B, M, K, pool_group=K)
+            return geo["new_xyz"], pooled.view(B, M, -1).transpose(1, 2)
+        h = sa_layer12(feature, xyz, geo["nbr"], geo["ctr"], layers[0], layers[1], B, M, K)
+        rest = layers[2:]
+    else:
+        h = sa_layer1(feature, xyz, geo["nbr"], geo["ctr"], layers[0], B, M, K)
+        rest = layers[1:]
+    for layer in rest[:-1]:
         h = mlp_layer(h, layer.K, layer, P)
-    pooled = mlp_layer(h, layers[-1].K, layers[-1], P, pool_group=K)          # (B*M, C_out)
+    pooled = mlp_layer(h, rest[-1].K, rest[-1], P, pool_group=K)              # (B*M, C_out)
     return geo["new_xyz"], pooled.view(B, M, -1).transpose(1, 2)
 
 

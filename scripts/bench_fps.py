@@ -18,3 +18,8 @@ for N, M in ((25600, 5120), (25600, 1280), (25600, 320), (16384, 4096), (8192, 2
     x = xyz[:, :, :N]
     ms, idx = timeit(x, M)
     print("N=%5d M=%4d: %.3f ms  %.3f us/round" % (N, M, ms, ms * 1e3 / (M - 1)))
+print("-- short runs (centre selection shapes), B=1, contiguous (P,3) rows")
+for N, M in ((16215, 64), (16215, 2), (9891, 64), (25600, 64), (4000, 64)):
+    x = pc[0, :N, :3].contiguous().view(1, N, 3).transpose(2, 1)
+    ms, idx = timeit(x, M, reps=20)
+    print("N=%5d M=%4d: %.3f ms" % (N, M, ms))

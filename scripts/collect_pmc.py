@@ -1,0 +1,66 @@
+#!/usr/bin/env python
+"""Post-processes rocprofv3 PMC passes of `python bench.py` into profiles/pmc_traffic.json.
+
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_fetch -o p -- python bench.py ...
+    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_write -o p -- python bench.py ...
+    python scripts/collect_pmc.py gpurun_out/pmc_fetch gpurun_out/pmc_write > profiles/pmc_traffic.json
+
+Units / corrections (MI355X_MICROARCH.md §HBM): FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE
+counts 64 B per 128-B request for wide (16 B/lane) coalesced streams, so it is DOUBLED for the kernels whose
+reads are such streams (the MLP GEMM: float4 operand loads).  WRITE_SIZE is uncalibrated in the guide; for the
+MLP GEMM's store pattern it was calibrated on a launch with a known byte count (scripts/ablate/mlp_ablate 0:
+P=2621440, K=N=128 writes exactly 1 310 720 KiB; rocprofv3 reported 2 140 420 KiB) -> factor 0.612.  Other
+kernels' WRITE_SIZE is used as reported.
+"""
+import collections
+import csv
+import glob
+import json
+import sys
+
+FAMILY = [("mlp_gemm_kernel", "mlp_gemm_kernel"), ("fps_", "fps_kernel"), ("ball_query_kernel", "ball_query_kernel"),
+          ("three_nn_kernel", "three_nn_kernel"), ("interp_concat_kernel", "interp_concat_kernel"),
+          ("gather_max_kernel", "gather_max_kernel"), ("radius_group_kernel", "radius_group_kernel")]
+WIDE_STREAM = {"mlp_gemm_kernel", "interp_concat_kernel"}
+WRITE_CAL = {"mlp_gemm_kernel": 1310720.0 / 2140420.25}
+
+
+def family(kernel_name):
+    for pat, fam in FAMILY:
+        if pat in kernel_name:
+            return fam
+    return None
+
+
+def collect(directory, counter):
+    tot, n = collections.Counter(), collections.Counter()
+    for f in glob.glob(directory + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            fam = family(r["Kernel_Name"])
+            if fam and r["Counter_Name"] == counter:
+                tot[fam] += float(r["Counter_Value"])
+                n[fam] += 1
+    return tot, n
+
+
+def main(fetch_dir, write_dir):
+    ft, fn = collect(fetch_dir, "FETCH_SIZE")
+    wt, wn = collect(write_dir, "WRITE_SIZE")
+    out = {}
+    for fam in sorted(set(ft) | set(wt)):
+        fetch_kib = ft[fam] / max(fn[fam], 1)
+        write_kib = wt[fam] / max(wn[fam], 1)
+        corr = 2.0 if fam in WIDE_STREAM else 1.0
+        wcal = WRITE_CAL.get(fam, 1.0)
+        out[fam] = {"launches_profiled": int(max(fn[fam], wn[fam])),
+                    "fetch_size_kib_per_launch_raw": round(fetch_kib, 1),
+                    "fetch_correction": corr,
+                    "write_size_kib_per_launch_raw": round(write_kib, 1),
+                    "write_calibration": round(wcal, 4),
+                    "hbm_bytes_per_launch": int((fetch_kib * corr + write_kib * wcal) * 1024)}
+    json.dump(out, sys.stdout, indent=1, sort_keys=True)
+    print()
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])
