@@ -167,6 +167,21 @@ __device__ __forceinline__ unsigned spread4(unsigned v) {  // 4 bits -> every th
   return (v & 1u) | ((v & 2u) << 2) | ((v & 4u) << 4) | ((v & 8u) << 6);
 }
 
+#if FPS_ABLATE == 9
+__device__ unsigned long long fps_dbg[8];
+#define FPS_T(k) do { if (blockIdx.x == 0) { unsigned long long t_ = __builtin_readcyclecounter(); if (tid == tstamp_tid) atomicAdd(&fps_dbg[k], t_ - tprev); tprev = t_; } } while (0)
+#else
+#define FPS_T(k) do {} while (0)
+#endif
+
+template <int PPT>
+__device__ __forceinline__ float dist_at(const float (&d)[PPT], int s) {  // register array, dynamic index
+  float v = d[0];
+#pragma unroll
+  for (int t = 1; t < PPT; ++t) v = (s == t) ? d[t] : v;
+  return v;
+}
+
 template <int PPT>
 __global__ __launch_bounds__(1024) void fps_sorted_kernel(const float* __restrict__ xyz, int64_t sb, int64_t sc,
                                                           int64_t sn, int N, int M, int rb_log2,
@@ -300,8 +315,13 @@ __global__ __launch_bounds__(1024) void fps_sorted_kernel(const float* __restric
   float thr = has_points ? __builtin_inff() : -1.f;      // update needed while |q - c|^2 < thr
 
   int cur = 0;
+#if FPS_ABLATE == 9
+  const int tstamp_tid = 0;
+  unsigned long long tprev = __builtin_readcyclecounter();
+#endif
   for (int i = 1; i < M; ++i) {
     const int buf = i & 1;
+    FPS_T(0);
 #if FPS_ABLATE == 3
     const float cx = 0.001f * cur, cy = 0.002f * cur, cz = 0.75f;  // no centroid load
 #else
@@ -310,6 +330,10 @@ __global__ __launch_bounds__(1024) void fps_sorted_kernel(const float* __restric
     const float cz = base[2 * sc + (int64_t)cur * sn];
 #endif
     const bool need = sqdist3(qx, qy, qz, cx, cy, cz) < thr;
+#if FPS_ABLATE == 9
+    asm volatile("" :: "v"(need ? 1 : 0));
+    FPS_T(1);
+#endif
     if (FPS_ABLATE != 1 && (FPS_ABLATE == 4 || __ballot(need) != 0ull)) {  // wave-uniform: scan all 64 lanes' points (extra updates are no-ops)
       float m = 0.f;
 #pragma unroll
@@ -322,10 +346,13 @@ __global__ __launch_bounds__(1024) void fps_sorted_kernel(const float* __restric
       const float reach = R + sqrtf(m) * 1.0001f;
       thr = has_points ? reach * reach * 1.0001f + 1e-30f : -1.f;
     }
+    FPS_T(2);
     const float wmax = wave_max_f32(tmax);
     if (lane == 0) part[buf][wave] = wmax;
     if (tid == 0) win_key[buf ^ 1] = 0xffffffffu;
+    FPS_T(3);
     __syncthreads();
+    FPS_T(4);
     float mx = 0.f;
 #pragma unroll
     for (int w4 = 0; w4 < W / 4; ++w4) {
@@ -337,13 +364,27 @@ __global__ __launch_bounds__(1024) void fps_sorted_kernel(const float* __restric
     if (mx < 0.f) cur = 0;
 #else
     if (mx > 0.f && tmax == mx) {
-      unsigned kmin = 0xffffffffu;
+      // which slot(s) hold the maximum?  Branch-free count + last match (pure VALU), ONE LDS read
+      // for the usual single match; several equal maxima in one thread (duplicated points) take
+      // the slow path that compares every matching slot's tie-break key.
+      int nmatch = 0, slot = 0;
 #pragma unroll
-      for (int s = 0; s < PPT; ++s)
-        if (dist[s] == mx) kmin = min(kmin, fps_key((int)perm[tid * PPT + s], rb_log2));
+      for (int s = 0; s < PPT; ++s) {
+        const bool hit = dist[s] == mx;
+        nmatch += hit ? 1 : 0;
+        slot = hit ? s : slot;
+      }
+      unsigned kmin = fps_key((int)perm[tid * PPT + slot], rb_log2);
+      if (nmatch > 1) {
+#pragma unroll 1
+        for (int s = 0; s < PPT; ++s)
+          if (dist_at(dist, s) == mx) kmin = min(kmin, fps_key((int)perm[tid * PPT + s], rb_log2));
+      }
       atomicMin(&win_key[buf], kmin);
     }
+    FPS_T(5);
     __syncthreads();
+    FPS_T(6);
     const unsigned key = win_key[buf];
     if (key != 0xffffffffu) cur = fps_unkey(key, rb_log2);
 #endif

@@ -160,56 +160,68 @@ __global__ __launch_bounds__(MLP_THREADS, AMODE == 2 ? 3 : MLP_MIN_WAVES) void m
 #pragma unroll
   for (int i = 0; i < STAGE_PASSES; ++i) wrow[i] = p.W + (long long)(col0 + sr + ROWS_PER_PASS * i) * p.Kpad;
 
-  float4 ra[STAGE_PASSES], rw[STAGE_PASSES];
-  auto load_tile = [&](int k0) {
-    const int kc = k0 + 4 * c4;
-#pragma unroll
-    for (int i = 0; i < STAGE_PASSES; ++i) {
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (arow_ok[i]) {
-        if (FUSE1) {
-          float e[4];
-#pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            const float* w = &sW1[(kc + t) * 10];
-            float acc = w[0] * xin[i][0];
-#pragma unroll
-            for (int c = 1; c < 8; ++c) acc += w[c] * xin[i][c];
-            e[t] = fmaxf(acc * w[8] + w[9], 0.f);
-          }
-          v = make_float4(e[0], e[1], e[2], e[3]);
-        } else if (GATHER) {
-          if (p.feat_vec && kc + 4 <= p.Cf) {
-            v = *reinterpret_cast<const float4*>(arow[i] + kc);
-          } else {
-            float e[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-              const int col = kc + t;
-              float x = 0.f;
-              if (col < p.Cf) x = arow[i][(long long)col * p.fc];
-              else if (col == p.Cf) x = relx[i];
-              else if (col == p.Cf + 1) x = rely[i];
-              else if (col == p.Cf + 2) x = relz[i];
-              e[t] = x;
-            }
-            v = make_float4(e[0], e[1], e[2], e[3]);
-          }
-        } else if (kc < p.Ka) {
-          v = *reinterpret_cast<const float4*>(arow[i] + kc);
-        }
-      }
-      ra[i] = v;
-      rw[i] = *reinterpret_cast<const float4*>(wrow[i] + kc);
-    }
-  };
-  auto store_tile = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < STAGE_PASSES; ++i) {
-      *reinterpret_cast<float4*>(&sA[buf][sr + ROWS_PER_PASS * i][4 * c4]) = ra[i];
-      *reinterpret_cast<float4*>(&sW[buf][sr + ROWS_PER_PASS * i][4 * c4]) = rw[i];
-    }
-  };
+  // Staging registers.  (Kept as plain locals + an inlined helper macro: a by-reference lambda
+  // made the compiler keep ra/rw in scratch and wait for every global load right after issuing it.)
+  float4 ra0, ra1, ra2, ra3, rw0, rw1, rw2, rw3;  // named scalars (arrays here ended up in scratch)
+  ra0 = ra1 = ra2 = ra3 = rw0 = rw1 = rw2 = rw3 = make_float4(0.f, 0.f, 0.f, 0.f);
+#define LOAD_PASS(I, RA, RW, KC)                                                                        \
+  if ((I) < STAGE_PASSES) {                                                                             \
+    constexpr int i = (I) < STAGE_PASSES ? (I) : 0;                                                     \
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);                                                         \
+    if (arow_ok[i]) {                                                                                   \
+      if (FUSE1) {                                                                                      \
+        float e[4];                                                                                     \
+        _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                 \
+          const float* w = &sW1[((KC) + t) * 10];                                                       \
+          float a1 = w[0] * xin[i][0];                                                                  \
+          _Pragma("unroll") for (int c = 1; c < 8; ++c) a1 += w[c] * xin[i][c];                         \
+          e[t] = fmaxf(a1 * w[8] + w[9], 0.f);                                                          \
+        }                                                                                               \
+        v = make_float4(e[0], e[1], e[2], e[3]);                                                        \
+      } else if (GATHER) {                                                                              \
+        if (p.feat_vec && (KC) + 4 <= p.Cf) {                                                           \
+          v = *reinterpret_cast<const float4*>(arow[i] + (KC));                                         \
+        } else {                                                                                        \
+          float e[4];                                                                                   \
+          _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                               \
+            const int col = (KC) + t;                                                                   \
+            float x = 0.f;                                                                              \
+            if (col < p.Cf) x = arow[i][(long long)col * p.fc];                                         \
+            else if (col == p.Cf) x = relx[i];                                                          \
+            else if (col == p.Cf + 1) x = rely[i];                                                      \
+            else if (col == p.Cf + 2) x = relz[i];                                                      \
+            e[t] = x;                                                                                   \
+          }                                                                                             \
+          v = make_float4(e[0], e[1], e[2], e[3]);                                                      \
+        }                                                                                               \
+      } else if ((KC) < p.Ka) {                                                                         \
+        v = *reinterpret_cast<const float4*>(arow[i] + (KC));                                           \
+      }                                                                                                 \
+    }                                                                                                   \
+    RA = v;                                                                                             \
+    RW = *reinterpret_cast<const float4*>(wrow[i] + (KC));                                              \
+  }
+#define LOAD_TILE(K0)                  \
+  do {                                 \
+    const int kc_ = (K0) + 4 * c4;     \
+    LOAD_PASS(0, ra0, rw0, kc_)        \
+    LOAD_PASS(1, ra1, rw1, kc_)        \
+    LOAD_PASS(2, ra2, rw2, kc_)        \
+    LOAD_PASS(3, ra3, rw3, kc_)        \
+  } while (0)
+#define STORE_PASS(I, RA, RW, BUF)                                                          \
+  if ((I) < STAGE_PASSES) {                                                                 \
+    *reinterpret_cast<float4*>(&sA[BUF][sr + ROWS_PER_PASS * (I)][4 * c4]) = RA;            \
+    *reinterpret_cast<float4*>(&sW[BUF][sr + ROWS_PER_PASS * (I)][4 * c4]) = RW;            \
+  }
+#define STORE_TILE(BUF)                \
+  do {                                 \
+    STORE_PASS(0, ra0, rw0, BUF)       \
+    STORE_PASS(1, ra1, rw1, BUF)       \
+    STORE_PASS(2, ra2, rw2, BUF)       \
+    STORE_PASS(3, ra3, rw3, BUF)       \
+  } while (0)
+  static_assert(STAGE_PASSES <= 4, "staging macros cover at most 4 passes");
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -220,13 +232,13 @@ __global__ __launch_bounds__(MLP_THREADS, AMODE == 2 ? 3 : MLP_MIN_WAVES) void m
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
   const int KT = p.Kpad / BK;
-  load_tile(0);
-  store_tile(0);
+  LOAD_TILE(0);
+  STORE_TILE(0);
   __syncthreads();
   const int fr = lane & 31, fh = lane >> 5;
   for (int kt = 0; kt < KT; ++kt) {
     const int buf = kt & 1;
-    if (kt + 1 < KT) load_tile((kt + 1) * BK);
+    if (kt + 1 < KT) LOAD_TILE((kt + 1) * BK);
 #pragma unroll
     for (int kk = 0; kk < BK / 8; ++kk) {
       float4 a[2], b[2];
@@ -246,7 +258,7 @@ __global__ __launch_bounds__(MLP_THREADS, AMODE == 2 ? 3 : MLP_MIN_WAVES) void m
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].w, b[ni].w, acc[mi][ni], 0, 0, 0);
         }
     }
-    if (kt + 1 < KT) store_tile(buf ^ 1);
+    if (kt + 1 < KT) STORE_TILE(buf ^ 1);
     __syncthreads();
   }
 
@@ -272,15 +284,37 @@ __global__ __launch_bounds__(MLP_THREADS, AMODE == 2 ? 3 : MLP_MIN_WAVES) void m
       const long long g = (row0 + wr * 64) / 64;  // a wave's 64 rows are exactly one group
       if (col_ok && fh == 0 && row0 + wr * 64 < p.P) p.C[g * p.ldc + col] = m;
     } else {
+      // Rows of one accumulator in register order: 0,1,2,3, 8,9,10,11, 16.., 24.. (+4 for the upper
+      // lane half).  Walk them with pointer increments (no 64-bit multiply per store); interior
+      // tiles take the unguarded path so the 32 stores of an accumulator issue back to back.
+      const long long first_row = row0 + wr * 64 + 4 * fh;
+      float* cp = p.C + first_row * p.ldc + col;
+      const long long ld = p.ldc;
+      const bool interior = (row0 + BM <= p.P) && (col0 + BN <= p.N);
+      if (interior) {
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
+        for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const long long row = row0 + wr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-          float y = acc[mi][ni][r] * s + t;
-          if (p.relu) y = fmaxf(y, 0.f);
-          if (col_ok && row < p.P) p.C[row * p.ldc + col] = y;
+          for (int r = 0; r < 16; ++r) {
+            float y = acc[mi][ni][r] * s + t;
+            if (p.relu) y = fmaxf(y, 0.f);
+            *cp = y;
+            cp += ((r & 3) == 3) ? 5 * ld : ld;   // after rows 3, 11, 19, 27 jump to the next block of four
+          }
         }
+      } else {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const long long row = first_row + mi * 32 + (r & 3) + 8 * (r >> 2);
+            float y = acc[mi][ni][r] * s + t;
+            if (p.relu) y = fmaxf(y, 0.f);
+            if (col_ok && row < p.P) *cp = y;
+            cp += ((r & 3) == 3) ? 5 * ld : ld;
+          }
+        }
+      }
     }
   }
 }

@@ -28,6 +28,13 @@ int main(int argc, char** argv) {
   std::vector<int64_t> out((size_t)B * M);
   hipMemcpy(out.data(), idx, out.size() * 8, hipMemcpyDeviceToHost);
   long long cs = 0; for (auto v : out) cs += v;
+#if FPS_ABLATE == 9
+  unsigned long long dbg[8];
+  hipMemcpyFromSymbol(dbg, HIP_SYMBOL(fps_dbg), sizeof(dbg));
+  const char* names[8] = {"loop-top(after unkey/store)", "centroid load+test", "scan", "wave reduce+lds write", "barrier1", "read partials+stage2", "barrier2", ""};
+  double rounds = 4.0 * (M - 1);
+  for (int k = 0; k < 7; ++k) printf("  phase %d %-28s %8.1f cycles/round (thread 0 of block 0)\n", k, names[k], dbg[k] / rounds);
+#endif
   printf("ABLATE=%d N=%d M=%d: %.3f ms  %.3f us/round  checksum %lld\n", FPS_ABLATE, N, M, ms / 3, ms / 3 * 1e3 / (M - 1), cs);
   return 0;
 }
