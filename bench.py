@@ -36,7 +36,7 @@ SCORENET_GFLOP_PER_SCENE = {25600: 148.27, 51200: 180.20}
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=8, help="scenes per GPU per step (configs[2]: 8)")
     ap.add_argument("--points", type=int, default=25600)

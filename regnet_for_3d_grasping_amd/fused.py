@@ -195,14 +195,22 @@ def _as_channels_last(feature):
 # Every block is split into its GEOMETRY part (indices; depends on xyz only) and its FEATURE part
 # (the MLP chain).  Called back to back they are the module forward; pipeline.ForwardPipeline runs
 # the geometry of batch i+1 on another stream while the features of batch i are on the matrix cores.
-def sa_geometry(module, xyz):
-    """FPS + centroid gather + ball query of a PointNetSAModule (modules.py:23-26, :41, :238-239)."""
-    B = xyz.shape[0]
-    M, K, radius = module.num_centroids, module.grouper.num_neighbours, module.grouper.radius
-    ctr = pn2_ext.farthest_point_sample(xyz, M)
+def sa_sample(module, xyz):
+    """Furthest point sampling of a PointNetSAModule (modules.py:23-26): the long latency chain."""
+    return pn2_ext.farthest_point_sample(xyz, module.num_centroids)
+
+
+def sa_group(module, xyz, ctr):
+    """Centroid gather + ball query given the sampled indices (modules.py:41, :238-239)."""
+    B, M = ctr.shape
     new_xyz = torch.gather(xyz, 2, ctr[:, None, :].expand(B, 3, M))
-    nbr, _ = pn2_ext.ball_query(xyz, new_xyz, radius, K)
+    nbr, _ = pn2_ext.ball_query(xyz, new_xyz, module.grouper.radius, module.grouper.num_neighbours)
     return {"ctr": ctr, "new_xyz": new_xyz, "nbr": nbr}
+
+
+def sa_geometry(module, xyz, ctr=None):
+    """FPS + centroid gather + ball query of a PointNetSAModule."""
+    return sa_group(module, xyz, sa_sample(module, xyz) if ctr is None else ctr)
 
 
 def sa_features(module, xyz, feature, geo):

@@ -52,12 +52,13 @@ class ForwardPipeline:
     """Software pipeline over a stream of scene batches (inference).
 
     Scenes are independent, and inside one batch the sampling / grouping geometry depends on xyz
-    only.  Furthest point sampling is a latency-bound chain of ~6400 dependent rounds that keeps
-    one CU per scene busy, while the shared-MLP contraction wants the other ~250 CUs; region
-    grouping needs the host for numpy's RNG.  So three stages run concurrently on three HIP
-    streams, each on a different batch:
+    only.  Level-1 furthest point sampling is a latency-bound chain of 5119 dependent rounds that
+    keeps one CU per scene busy for ~10 ms, while the shared-MLP contraction wants the other ~250
+    CUs and region grouping needs the host for numpy's RNG.  So four stages run concurrently on four
+    HIP streams, each on a different batch:
 
-        s_geo : geometry(batch i+1)   FPS x3, ball query x3, 3-NN x3            (~8 CUs)
+        s_fps : sample(batch i+2)     level-1 FPS                               (1 CU per scene)
+        s_geo : geometry(batch i+1)   FPS levels 2-3, ball query x3, 3-NN x3
         s_mlp : features(batch i)     gather / MFMA shared-MLP / pool / head    (matrix cores)
         s_reg : region(batch i-1)     radius grouping, host RNG draws, GRN + refine heads
 
@@ -69,23 +70,34 @@ class ForwardPipeline:
         self.score_net, self.region_net, self.with_region = score_net, region_net, with_region
         dev = next(score_net.parameters()).device
         self.device = dev
-        # Priorities: the region stage is a chain of small kernels separated by host syncs (numpy
-        # RNG draws) and FPS is a single-CU latency chain -- neither may queue behind the big MLP
-        # launches, so both get high-priority HW queues and the MFMA stream the default one.
+        # Priorities: FPS and the region stage are chains of small / single-CU kernels (the latter
+        # separated by host syncs) -- they must not queue behind the big MLP launches.
+        self.s_fps = torch.cuda.Stream(dev, priority=-1)
         self.s_geo = torch.cuda.Stream(dev, priority=-1)
         self.s_mlp = torch.cuda.Stream(dev, priority=0)
         self.s_reg = torch.cuda.Stream(dev, priority=-1)
 
     # -- stages -------------------------------------------------------------------------------
-    def _geometry(self, pc):
+    def _sample(self, pc):
+        with torch.cuda.stream(self.s_fps), torch.no_grad():
+            ctr = self.score_net.sample_level1(pc)
+            done = torch.cuda.Event()
+            done.record(self.s_fps)
+        ctr.record_stream(self.s_geo)
+        ctr.record_stream(self.s_mlp)
+        return {"pc": pc, "ctr": ctr, "fps_done": done}
+
+    def _geometry(self, item):
         from . import fused
         with torch.cuda.stream(self.s_geo), torch.no_grad():
-            plan = self.score_net.plan(pc)
+            self.s_geo.wait_event(item["fps_done"])
+            plan = self.score_net.plan(item["pc"], item["ctr"])
             done = torch.cuda.Event()
             done.record(self.s_geo)
         for t in fused.plan_tensors(plan):
             t.record_stream(self.s_mlp)
-        return {"pc": pc, "plan": plan, "geo_done": done}
+        item.update(plan=plan, geo_done=done)
+        return item
 
     def _features(self, item):
         with torch.cuda.stream(self.s_mlp), torch.no_grad():
@@ -97,6 +109,7 @@ class ForwardPipeline:
         score.record_stream(self.s_reg)
         item.update(all_feature=all_feature, score=score, mlp_done=done)
         item.pop("plan")
+        item.pop("ctr")
         return item
 
     def _region(self, item):
@@ -118,29 +131,83 @@ class ForwardPipeline:
         return out
 
     # -- driver -------------------------------------------------------------------------------
-    def run(self, batches):
+    def run(self, batches, max_pending_regions=3):
         """batches: iterable of (B,N,6) GPU tensors (already resident).  Yields one result dict per
         batch, in order.  The caller must ``result['done'].synchronize()`` (or synchronise the
-        device) before reading results on another stream."""
+        device) before reading results on another stream.
+
+        The region stage blocks its host thread on several device->host syncs (candidate counts for
+        the numpy draws); it therefore runs on ONE worker thread, in batch order (so numpy's global
+        RNG is consumed exactly as in the sequential forward), while this thread keeps the three
+        asynchronous stages fed.  At most ``max_pending_regions`` batches wait for their region stage.
+        """
+        import queue
+        import threading
+
         cur = torch.cuda.current_stream(self.device)
-        for s in (self.s_geo, self.s_mlp, self.s_reg):
+        streams = (self.s_fps, self.s_geo, self.s_mlp, self.s_reg)
+        for s in streams:
             s.wait_stream(cur)
-        stage1 = stage2 = None
-        it = iter(batches)
-        exhausted = False
-        while True:
-            pc = None
-            if not exhausted:
+
+        todo, done = queue.Queue(), queue.Queue()
+
+        def region_worker():
+            torch.cuda.set_device(self.device)
+            while True:
+                item = todo.get()
+                if item is None:
+                    return
                 try:
-                    pc = next(it)
-                except StopIteration:
-                    exhausted = True
-            if pc is None and stage1 is None and stage2 is None:
-                break
-            new1 = self._geometry(pc) if pc is not None else None          # async, s_geo
-            new2 = self._features(stage1) if stage1 is not None else None  # async, s_mlp (after geo event)
-            if stage2 is not None:
-                yield self._region(stage2)                                 # host-heavy, s_reg
-            stage1, stage2 = new1, new2
-        for s in (self.s_geo, self.s_mlp, self.s_reg):
+                    done.put(self._region(item))
+                except BaseException as exc:  # surface the failure in the consumer thread
+                    done.put(exc)
+                    return
+
+        worker = threading.Thread(target=region_worker, name="regnet-region-stage", daemon=True)
+        worker.start()
+        pending = 0
+
+        def collect(block):
+            res = done.get() if block else done.get_nowait()
+            if isinstance(res, BaseException):
+                raise res
+            return res
+
+        try:
+            st_fps = st_geo = None   # items that have been ENQUEUED up to that stage
+            it = iter(batches)
+            exhausted = False
+            while True:
+                pc = None
+                if not exhausted:
+                    try:
+                        pc = next(it)
+                    except StopIteration:
+                        exhausted = True
+                if pc is None and st_fps is None and st_geo is None:
+                    break
+                # enqueue the asynchronous stages, deepest look-ahead first
+                new_fps = self._sample(pc) if pc is not None else None
+                new_geo = self._geometry(st_fps) if st_fps is not None else None
+                if st_geo is not None:
+                    todo.put(self._features(st_geo))
+                    pending += 1
+                st_fps, st_geo = new_fps, new_geo
+                while pending > max_pending_regions:      # back-pressure: wait for the oldest region stage
+                    yield collect(True)
+                    pending -= 1
+                while pending:                             # hand out whatever is already finished
+                    try:
+                        res = collect(False)
+                    except queue.Empty:
+                        break
+                    yield res
+                    pending -= 1
+            while pending:
+                yield collect(True)
+                pending -= 1
+        finally:
+            todo.put(None)
+            worker.join()
+        for s in streams:
             cur.wait_stream(s)

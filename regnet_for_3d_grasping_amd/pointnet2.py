@@ -52,7 +52,16 @@ class PointNet2Seg(nn.Module):
         self.bn_score = nn.BatchNorm1d(self.k_score)
         self.sigmoid = nn.Sigmoid()
 
-    def plan(self, points):
+    def sample_level1(self, points):
+        """Level-1 furthest point sampling only (5120 of N points): the longest latency chain of the
+        forward, separable so a pipeline can run it two batches ahead.  Pass the result to ``plan``."""
+        from . import fused
+        xyz = points[:, :3, :]
+        if not fused.usable(self, xyz):
+            raise RuntimeError("PointNet2Seg.sample_level1 needs eval mode, torch.no_grad() and GPU tensors")
+        return fused.sa_sample(self.sa_modules[0], xyz)
+
+    def plan(self, points, level1_ctr=None):
         """Geometry of a forward pass -- FPS / ball-query / 3-NN indices of every level.  Depends on
         xyz only, so it can be computed ahead of (and concurrently with) the feature pass; hand the
         result to ``forward(points, plan=...)``.  Fused MI355X path only."""
@@ -61,8 +70,8 @@ class PointNet2Seg(nn.Module):
         if not fused.usable(self, xyz):
             raise RuntimeError("PointNet2Seg.plan needs eval mode, torch.no_grad() and GPU tensors")
         levels, sa_geo = [xyz], []
-        for sa in self.sa_modules:
-            geo = fused.sa_geometry(sa, levels[-1])
+        for i, sa in enumerate(self.sa_modules):
+            geo = fused.sa_geometry(sa, levels[-1], level1_ctr if i == 0 else None)
             sa_geo.append(geo)
             levels.append(geo["new_xyz"])
         fp_geo, sparse = [], levels[-1]

@@ -19,9 +19,13 @@ class ScoreNetwork(nn.Module):
         """MSE between predicted and target per-point score (score_network.py:18-29)."""
         return self.criterion_reg(pscore, tscore.float())
 
-    def plan(self, pc):
+    def sample_level1(self, pc):
+        """Level-1 FPS indices for ``pc``; see PointNet2Seg.sample_level1."""
+        return self.extrat_featurePN2.sample_level1(pc[:, :, :6].permute(0, 2, 1))
+
+    def plan(self, pc, level1_ctr=None):
         """Geometry plan (sampling / grouping / 3-NN indices) for ``pc``; see PointNet2Seg.plan."""
-        return self.extrat_featurePN2.plan(pc[:, :, :6].permute(0, 2, 1))
+        return self.extrat_featurePN2.plan(pc[:, :, :6].permute(0, 2, 1), level1_ctr)
 
     def forward(self, pc, pc_score=None, pc_label=None, plan=None):
         points = pc[:, :, :6].permute(0, 2, 1)
