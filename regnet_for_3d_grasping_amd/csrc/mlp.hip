@@ -135,7 +135,7 @@ __global__ __launch_bounds__(MLP_THREADS, AMODE == 2 ? 3 : MLP_MIN_WAVES) void m
       const long long b = rs / p.rows_per_scene;
       const long long j = p.nbr[rs];
       const long long cj = p.ctr[rs / p.group];
-      arow[i] = p.feat ? p.feat + b * p.fb + j * p.fn : nullptr;
+      arow[i] = p.feat ? p.feat + b * p.fb + j * p.fn : p.xyz;  // never dereferenced when Cf == 0
       const float* xb = p.xyz + b * p.xb;
       relx[i] = xb[j * p.xn] - xb[cj * p.xn];
       rely[i] = xb[p.xc + j * p.xn] - xb[p.xc + cj * p.xn];
@@ -164,40 +164,58 @@ __global__ __launch_bounds__(MLP_THREADS, AMODE == 2 ? 3 : MLP_MIN_WAVES) void m
   // made the compiler keep ra/rw in scratch and wait for every global load right after issuing it.)
   float4 ra0, ra1, ra2, ra3, rw0, rw1, rw2, rw3;  // named scalars (arrays here ended up in scratch)
   ra0 = ra1 = ra2 = ra3 = rw0 = rw1 = rw2 = rw3 = make_float4(0.f, 0.f, 0.f, 0.f);
+// All global loads are UNCONDITIONAL (addresses clamped into valid memory, invalid lanes zeroed with
+// selects afterwards): a load inside a branch made the compiler wait for it at the join, i.e. at the
+// top of every k-tile instead of right before the LDS write.
 #define LOAD_PASS(I, RA, RW, KC)                                                                        \
   if ((I) < STAGE_PASSES) {                                                                             \
     constexpr int i = (I) < STAGE_PASSES ? (I) : 0;                                                     \
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);                                                         \
-    if (arow_ok[i]) {                                                                                   \
-      if (FUSE1) {                                                                                      \
-        float e[4];                                                                                     \
+    float4 v;                                                                                           \
+    if (FUSE1) {                                                                                        \
+      float e[4];                                                                                       \
+      _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                   \
+        const float* w = &sW1[((KC) + t) * 10];                                                         \
+        float a1 = w[0] * xin[i][0];                                                                    \
+        _Pragma("unroll") for (int c = 1; c < 8; ++c) a1 += w[c] * xin[i][c];                           \
+        e[t] = fmaxf(a1 * w[8] + w[9], 0.f);                                                            \
+      }                                                                                                 \
+      v = make_float4(e[0], e[1], e[2], e[3]);                                                          \
+    } else if (GATHER) {                                                                                \
+      if (p.feat_vec) { /* wave-uniform branch */                                                       \
+        const bool infeat = (KC) + 4 <= p.Cf;                                                           \
+        v = *reinterpret_cast<const float4*>(arow[i] + (infeat ? (KC) : 0));                            \
+        float e[4] = {v.x, v.y, v.z, v.w};                                                              \
         _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                 \
-          const float* w = &sW1[((KC) + t) * 10];                                                       \
-          float a1 = w[0] * xin[i][0];                                                                  \
-          _Pragma("unroll") for (int c = 1; c < 8; ++c) a1 += w[c] * xin[i][c];                         \
-          e[t] = fmaxf(a1 * w[8] + w[9], 0.f);                                                          \
+          const int col = (KC) + t;                                                                     \
+          float x = infeat ? e[t] : 0.f;                                                                \
+          x = (col == p.Cf) ? relx[i] : x;                                                              \
+          x = (col == p.Cf + 1) ? rely[i] : x;                                                          \
+          x = (col == p.Cf + 2) ? relz[i] : x;                                                          \
+          e[t] = x;                                                                                     \
         }                                                                                               \
         v = make_float4(e[0], e[1], e[2], e[3]);                                                        \
-      } else if (GATHER) {                                                                              \
-        if (p.feat_vec && (KC) + 4 <= p.Cf) {                                                           \
-          v = *reinterpret_cast<const float4*>(arow[i] + (KC));                                         \
-        } else {                                                                                        \
-          float e[4];                                                                                   \
-          _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                               \
-            const int col = (KC) + t;                                                                   \
-            float x = 0.f;                                                                              \
-            if (col < p.Cf) x = arow[i][(long long)col * p.fc];                                         \
-            else if (col == p.Cf) x = relx[i];                                                          \
-            else if (col == p.Cf + 1) x = rely[i];                                                      \
-            else if (col == p.Cf + 2) x = relz[i];                                                      \
-            e[t] = x;                                                                                   \
+      } else {                                                                                          \
+        float e[4];                                                                                     \
+        _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                 \
+          const int col = (KC) + t;                                                                     \
+          float x = 0.f;                                                                                \
+          if (p.Cf > 0) {                                                                               \
+            const float f = arow[i][(long long)min(col, p.Cf - 1) * p.fc];                              \
+            x = col < p.Cf ? f : 0.f;                                                                   \
           }                                                                                             \
-          v = make_float4(e[0], e[1], e[2], e[3]);                                                      \
+          x = (col == p.Cf) ? relx[i] : x;                                                              \
+          x = (col == p.Cf + 1) ? rely[i] : x;                                                          \
+          x = (col == p.Cf + 2) ? relz[i] : x;                                                          \
+          e[t] = x;                                                                                     \
         }                                                                                               \
-      } else if ((KC) < p.Ka) {                                                                         \
-        v = *reinterpret_cast<const float4*>(arow[i] + (KC));                                           \
+        v = make_float4(e[0], e[1], e[2], e[3]);                                                        \
       }                                                                                                 \
+    } else {                                                                                            \
+      const bool incol = (KC) < p.Ka;                                                                   \
+      v = *reinterpret_cast<const float4*>(arow[i] + (incol ? (KC) : 0));                               \
+      if (!incol) v = make_float4(0.f, 0.f, 0.f, 0.f);                                                  \
     }                                                                                                   \
+    if (!arow_ok[i]) v = make_float4(0.f, 0.f, 0.f, 0.f);                                               \
     RA = v;                                                                                             \
     RW = *reinterpret_cast<const float4*>(wrow[i] + (KC));                                              \
   }
