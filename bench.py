@@ -281,7 +281,7 @@ def main():
                        "scorenet_gflop_per_scene": SCORENET_GFLOP_PER_SCENE.get(args.points)},
             "roofline": roofline,
             "mlp_tflops": round(SCORENET_GFLOP_PER_SCENE.get(args.points, 0.0) * total_scenes / world / dt / 1e3, 3),
-            "kernels": kernels[:12],
+            "kernels": kernels[:40],
             "grasps_last_step": int(out["next_grasp"].shape[0]) if "next_grasp" in out else None,
         }
         if world == 1 and args.cpu_scenes > 0:

@@ -151,3 +151,30 @@ def test_fused_modules_equal_unfused_modules(monkeypatch):
     assert tuple(nf1.shape) == tuple(nf0.shape) and tuple(up1.shape) == tuple(up0.shape)
     torch.testing.assert_close(nf1, nf0, rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(up1, up0, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("pool", [0, 64])
+def test_sa_layer12_fused_first_two_layers(pool):
+    """Gather + layer 1 (VALU, in the operand load) + layer 2 (MFMA) == the two layers applied in turn."""
+    from regnet_for_3d_grasping_amd import fused
+    B, N, M, G, C1, C2 = 2, 700, 37, 64, 128, 256
+    rng = np.random.default_rng(11)
+    pc = torch.from_numpy(rng.normal(size=(B, N, 6)).astype(np.float32)).to(DEV)
+    xyz, rgb = pc[:, :, :3].permute(0, 2, 1), pc[:, :, 3:6].permute(0, 2, 1)
+    nbr = torch.from_numpy(rng.integers(0, N, (B, M, G))).to(DEV)
+    ctr = torch.from_numpy(rng.integers(0, N, (B, M))).to(DEV)
+    conv1, bn1, _ = _layer(C1, 6, seed=21)
+    conv2, bn2, layer2 = _layer(C2, C1, seed=22)
+    order = torch.cat([torch.arange(3, 6), torch.arange(3)]).to(DEV)
+    first = fused._pack(conv1, bn1, True, order)
+    assert first.W8 is not None and tuple(first.W8.shape) == (C1, 8)
+    got = fused.sa_layer12(rgb, xyz, nbr, ctr, first, layer2, B, M, G, pool_group=pool)
+    idx = nbr.view(B, 1, M * G)
+    gx = torch.gather(xyz, 2, idx.expand(B, 3, -1)).view(B, 3, M, G)
+    gx = gx - torch.gather(xyz, 2, ctr[:, None, :].expand(B, 3, M)).unsqueeze(-1)
+    gf = torch.gather(rgb, 2, idx.expand(B, 3, -1)).view(B, 3, M, G)
+    grouped = torch.cat([gx, gf], 1).permute(0, 2, 3, 1).reshape(B * M * G, 6)
+    want = _ref(_ref(grouped, conv1, bn1, True).float(), conv2, bn2, True)
+    if pool:
+        want = want.view(B * M, G, C2).max(dim=1)[0]
+    torch.testing.assert_close(got.double(), want, rtol=1e-5, atol=3e-5)
