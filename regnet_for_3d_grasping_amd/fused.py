@@ -296,3 +296,53 @@ def plan_tensors(plan):
     for level in plan["sa"] + plan["fp"]:
         out.extend(v for v in level.values() if isinstance(v, torch.Tensor))
     return out
+
+
+# ---- grasp-region / refine heads (tiny GEMMs: P = #centres; kept on the same kernel so the whole
+#      forward is deterministic and independent of the torch convolution backend) -----------------
+def _packed_named(net, names):
+    """names: list of (conv_attr, bn_attr, relu).  Cached on ``net`` like the SharedMLP stacks."""
+    sig = _signature(net)
+    cache = getattr(net, "_regnet_heads", None)
+    if cache is None or cache[0] != sig:
+        cache = (sig, {c: _pack(getattr(net, c), getattr(net, b), relu) for c, b, relu in names})
+        net._regnet_heads = cache
+    return cache[1]
+
+
+_TWOSTAGE = [("conv", "bn", True), ("conv_cls2", "bn_cls2", True), ("conv_cls3", "bn_cls3", True),
+             ("conv_cls4", "bn_cls4", False), ("conv_reg2", "bn_reg2", True), ("conv_reg3", "bn_reg3", True),
+             ("conv_reg4", "bn_reg4", False)]
+_REFINE = [("conv_formal", "bn_formal", True), ("conv_formal_cls2", "bn_formal_cls2", True),
+           ("conv_formal_cls3", "bn_formal_cls3", False), ("conv_formal_reg2", "bn_formal_reg2", True),
+           ("conv_formal_reg3", "bn_formal_reg3", False)]
+
+
+def _chain(x, layers, names):
+    P = x.shape[0]
+    for n in names:
+        x = mlp_layer(x, layers[n].K, layers[n], P)
+    return x
+
+
+def twostage_forward(net, mp_x):
+    """PointNet2TwoStage.forward after the max-pool (pointnet2.py:174-188): mp_x (n, 256, 1) ->
+    x_cls (n, k_cls), x_reg (n, k_cls, k_reg/k_cls) with sigmoid on channels 7:."""
+    n = mp_x.shape[0]
+    L = _packed_named(net, _TWOSTAGE)
+    x = mp_x.reshape(n, -1).contiguous()
+    h = mlp_layer(x, L["conv"].K, L["conv"], n)
+    x_cls = _chain(h, L, ["conv_cls2", "conv_cls3", "conv_cls4"])
+    x_reg = _chain(h, L, ["conv_reg2", "conv_reg3", "conv_reg4"]).view(n, -1, net.k_reg_no_anchor)
+    x_reg[:, :, 7:] = torch.sigmoid(x_reg[:, :, 7:])
+    return x_cls, x_reg
+
+
+def refine_forward(net, x):
+    """PointNet2Refine.forward after pooling + concat (pointnet2.py:240-253): x (n, 384, 1) ->
+    x_cls (n, 2), x_reg (n, k_reg)."""
+    n = x.shape[0]
+    L = _packed_named(net, _REFINE)
+    h = mlp_layer(x.reshape(n, -1).contiguous(), L["conv_formal"].K, L["conv_formal"], n)
+    return (_chain(h, L, ["conv_formal_cls2", "conv_formal_cls3"]),
+            _chain(h, L, ["conv_formal_reg2", "conv_formal_reg3"]))

@@ -156,6 +156,10 @@ class PointNet2TwoStage(nn.Module):
         mp_x = xyz if pooled else self.mp1(xyz)
         if feature is not None:
             mp_x = torch.cat((mp_x, feature.view(feature.shape[0], feature.shape[1], 1)), dim=1)
+        from . import fused
+        if fused.usable(self, mp_x) and mp_x.shape[1] % 4 == 0:
+            x_cls, x_reg = fused.twostage_forward(self, mp_x)
+            return x_cls, x_reg, mp_x
         x = F.relu(self.bn(self.conv(mp_x)))
         x_cls = self._branch(x, "cls")
         n, c, _ = x_cls.size()
@@ -195,5 +199,8 @@ class PointNet2Refine(nn.Module):
         x = gripper_feature if pooled else self.mp1(gripper_feature)
         if group_feature is not None:
             x = torch.cat((x, group_feature.view(group_feature.shape[0], group_feature.shape[1], 1)), dim=1)
+        from . import fused
+        if fused.usable(self, x) and x.shape[1] % 4 == 0:
+            return fused.refine_forward(self, x)
         x = F.relu(self.bn_formal(self.conv_formal(x)))
         return self._branch(x, "cls"), self._branch(x, "reg")

@@ -178,3 +178,25 @@ def test_sa_layer12_fused_first_two_layers(pool):
     if pool:
         want = want.view(B * M, G, C2).max(dim=1)[0]
     torch.testing.assert_close(got.double(), want, rtol=1e-5, atol=3e-5)
+
+
+def test_region_and_refine_heads_fused_equal_torch(monkeypatch):
+    import regnet_for_3d_grasping_amd.fused as fused
+    from regnet_for_3d_grasping_amd import synthetic
+    from regnet_for_3d_grasping_amd.pointnet2 import PointNet2Refine, PointNet2TwoStage
+    two = PointNet2TwoStage(256, 6, 4, 40, 4).to(DEV).eval()
+    ref = PointNet2Refine(64, 6, 2, 10).to(DEV).eval()
+    two.load_state_dict({k: v.to(DEV) for k, v in synthetic.seeded_state_dict(two, 5).items()})
+    ref.load_state_dict({k: v.to(DEV) for k, v in synthetic.seeded_state_dict(ref, 6).items()})
+    pooled = torch.randn(130, 256, 1, device=DEV)
+    grip, region = torch.randn(37, 256, 1, device=DEV), torch.randn(37, 128, device=DEV)
+    with torch.no_grad():
+        monkeypatch.setattr(fused, "ENABLED", True)
+        c1, r1, _ = two(pooled, None, pooled=True)
+        a1, b1 = ref(grip, region, pooled=True)
+        monkeypatch.setattr(fused, "ENABLED", False)
+        c0, r0, _ = two(pooled, None, pooled=True)
+        a0, b0 = ref(grip, region, pooled=True)
+    for got, want in ((c1, c0), (r1, r0), (a1, a0), (b1, b0)):
+        assert got.shape == want.shape
+        torch.testing.assert_close(got, want, rtol=1e-4, atol=1e-4)
