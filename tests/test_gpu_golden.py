@@ -103,3 +103,26 @@ def test_s3_region_network_on_gpu():
         np.testing.assert_array_equal(final_mask_sthre.cpu().numpy(), exp["final_mask_sthre"])
     else:
         pytest.fail("refine selection differs from the golden run")
+
+
+def test_inference_script_scale_grouping():
+    """test.py-scale region stage (test.py:68-71: 4000 centres, 256 / 2048-point groups) against the
+    oracle-backed mirror on the same scores: exact indices, same numpy stream."""
+    from oracle.install import oracle_backend
+    from regnet_for_3d_grasping_amd import synthetic
+    from regnet_for_3d_grasping_amd.get_regiondataset import get_grasp_allobj
+    N = 12000
+    pc = synthetic.make_batch(9000, 1, N)
+    rng = np.random.default_rng(4)
+    score = torch.from_numpy(rng.uniform(0, 1, (1, N)).astype(np.float32))
+    params = [4000, 0.5, 256, 0.1, 2048, 0.8, 0.08, 0.01, 0.06]
+    with oracle_backend():
+        np.random.seed(21)
+        want = get_grasp_allobj(pc, score, params, [])
+        after = int(np.random.randint(0, 2 ** 31 - 1))
+    np.random.seed(21)
+    got = get_grasp_allobj(pc.to(DEV), score.to(DEV), params, [])
+    assert int(np.random.randint(0, 2 ** 31 - 1)) == after
+    for g, w in zip(got[:6], want[:6]):
+        assert tuple(g.shape) == tuple(w.shape)
+        assert torch.equal(g.cpu(), w)
