@@ -76,6 +76,7 @@ struct MlpArgs {
   long long P;
   int N;
   int relu;
+  int wide_store;  // C rows 16-byte aligned (ldc % 4 == 0): interior tiles use the LDS-transposed dwordx4 epilogue
 };
 
 __device__ __forceinline__ void xcd_tile(int& tm, int& tn, int tiles_m, int tiles_n) {
@@ -93,8 +94,12 @@ __device__ __forceinline__ void xcd_tile(int& tm, int& tn, int tiles_m, int tile
 
 template <int AMODE, bool POOL>
 __global__ __launch_bounds__(MLP_THREADS, AMODE == 2 ? 3 : MLP_MIN_WAVES) void mlp_gemm_kernel(const MlpArgs p) {
-  __shared__ __attribute__((aligned(16))) float sA[2][BM][LDS_LD];
-  __shared__ __attribute__((aligned(16))) float sW[2][BN][LDS_LD];
+  // one LDS block: [2][BM][LDS_LD] A tiles, [2][BN][LDS_LD] W tiles; re-used by the epilogue as
+  // per-wave transposition buffers (4 x 64 x 36 floats)
+  __shared__ __attribute__((aligned(16))) float smem[2 * BM * LDS_LD + 2 * BN * LDS_LD];
+  float (*sA)[BM][LDS_LD] = reinterpret_cast<float (*)[BM][LDS_LD]>(smem);
+  float (*sW)[BN][LDS_LD] = reinterpret_cast<float (*)[BN][LDS_LD]>(smem + 2 * BM * LDS_LD);
+  static_assert(2 * BM * LDS_LD + 2 * BN * LDS_LD >= 4 * 64 * 36, "epilogue staging does not fit");
   __shared__ __attribute__((aligned(16))) float sW1[AMODE == 2 ? 256 * 10 : 4];  // [C1 <= 256][8 weights | scale | shift]
 
   constexpr bool GATHER = AMODE != 0;
@@ -309,7 +314,26 @@ __global__ __launch_bounds__(MLP_THREADS, AMODE == 2 ? 3 : MLP_MIN_WAVES) void m
       float* cp = p.C + first_row * p.ldc + col;
       const long long ld = p.ldc;
       const bool interior = (row0 + BM <= p.P) && (col0 + BN <= p.N);
-      if (interior) {
+      if (interior && p.wide_store) {
+        // Transpose the 64x32 accumulator slab through this wave's LDS region and write 16 bytes
+        // per lane: 8 dwordx4 stores (8 rows x 128 B each) instead of 32 dword stores.
+        float* stage = smem + wave * (64 * 36);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float y = acc[mi][ni][r] * s + t;
+            if (p.relu) y = fmaxf(y, 0.f);
+            stage[(mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh) * 36 + fr] = y;
+          }
+        float* cbase = p.C + (row0 + wr * 64) * p.ldc + (col0 + wc * 64 + ni * 32);
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+          const int row = it * 8 + (lane >> 3), q4 = lane & 7;
+          const float4 v = *reinterpret_cast<const float4*>(&stage[row * 36 + q4 * 4]);
+          *reinterpret_cast<float4*>(cbase + (long long)row * p.ldc + q4 * 4) = v;
+        }
+      } else if (interior) {
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
@@ -337,7 +361,9 @@ __global__ __launch_bounds__(MLP_THREADS, AMODE == 2 ? 3 : MLP_MIN_WAVES) void m
   }
 }
 
-static int launch_gemm(const MlpArgs& a, int amode, bool pool, hipStream_t st) {
+static int launch_gemm(const MlpArgs& a_in, int amode, bool pool, hipStream_t st) {
+  MlpArgs a = a_in;
+  a.wide_store = ((reinterpret_cast<uintptr_t>(a.C) & 15) == 0) && (a.ldc % 4 == 0);
   const long long tiles = ((a.P + BM - 1) / BM) * ((a.N + BN - 1) / BN);
   if (tiles <= 0) return REGNET_OK;
   if (tiles >= (1ll << 31)) return REGNET_ERR_UNSUPPORTED;
