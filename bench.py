@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=8, help="scenes per GPU per step (configs[2]: 8)")
     ap.add_argument("--points", type=int, default=25600)
-    ap.add_argument("--cpu-scenes", type=int, default=2, help="scenes timed for cpu_baseline (0 = skip)")
+    ap.add_argument("--cpu-scenes", type=int, default=4, help="scenes timed for cpu_baseline (0 = skip)")
     ap.add_argument("--score-only", action="store_true", help="configs[1]: ScoreNet forward only")
     return ap.parse_args()
 
