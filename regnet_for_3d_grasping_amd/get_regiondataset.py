@@ -9,8 +9,10 @@ the small-radius pass first, then the large-radius pass -- get_regiondataset.py:
 seeded numpy RNG yields the same groups.  One device->host sync per pass instead of one per
 centre.
 
-Training labels (``_get_center_grasp``, get_regiondataset.py:45-134) need the dataset's grasp
-pickles and are outside this round's scope: ``data_paths`` must be empty.
+Training labels (``_get_center_grasp`` / ``_transform_grasp``, get_regiondataset.py:45-199): every
+centre is matched to the nearest ground-truth grasp and the 4x4 frame is re-expressed as
+(centre, closing axis, angle, scores).  ``data_paths`` holds one entry per scene -- a path to the
+dataset's pickled dict or the dict itself (keys ``frame`` + ``antipodal_score``, or the ``select_*`` set).
 """
 import numpy as np
 import torch
@@ -31,9 +33,110 @@ def get_grasp_allobj(pc, predict_score, params, data_paths, use_theta=True):
                                              r_time_group)
     pc_group_more_index, pc_group_more = _get_group_pc(pc, center_pc, center_pc_index, group_num_more, width,
                                                        height, depth, r_time_group_more)
+    grasp_labels = None
     if len(data_paths) > 0:
-        raise NotImplementedError("grasp-label matching (_get_center_grasp) is not part of the forward hot path")
-    return center_pc, center_pc_index, pc_group_index, pc_group, pc_group_more_index, pc_group_more, None
+        grasp_labels = _get_center_grasp(center_pc_index, center_pc, data_paths, depth, use_theta)
+    return center_pc, center_pc_index, pc_group_index, pc_group, pc_group_more_index, pc_group_more, grasp_labels
+
+
+NO_GRASP_SQ_DISTANCE = 0.005   # a centre further than this (SQUARED distance) from every grasp has no label (:120)
+
+
+def _load_grasp_record(entry):
+    """One scene's ground-truth grasps -> (frames (G,4,4), score, antipodal, centre-score) float32
+    tensors (get_regiondataset.py:66-86).  With only ``frame`` / ``antipodal_score`` present all three
+    scores are the antipodal score."""
+    data = entry if isinstance(entry, dict) else np.load(entry, allow_pickle=True)
+
+    def as_tensor(v):
+        return torch.tensor(np.asarray(v), dtype=torch.float32) if not isinstance(v, torch.Tensor) else v.float()
+
+    if "frame" in data.keys():
+        frames = as_tensor(data["frame"])
+        score = as_tensor(data["antipodal_score"])
+        return frames, score, score, score
+    return (as_tensor(data["select_frame"]), as_tensor(data["select_antipodal_score"]),
+            as_tensor(data["select_antipodal_score"]), as_tensor(data["select_center_score"]))
+
+
+def _compute_distance(points1, points2):
+    """Squared distances (len(points1), len(points2)) by the expansion -2ab + |b|^2 + |a|^2, returned
+    as float64 like the reference (get_regiondataset.py:271-277)."""
+    a = points1[:, :3]
+    d = -2 * a.mm(points2.transpose(1, 0))
+    d = d + torch.sum(points2 * points2, 1).view(1, -1)
+    d = d + torch.sum(a * a, 1).view(-1, 1)
+    return d.double()
+
+
+def _get_center_grasp(center_pc_index, center_pc, data_paths, depth, use_theta=True):
+    """Match every centre to its nearest ground-truth grasp (get_regiondataset.py:45-134).
+    Returns (B, Nc, 10) = centre(3) | closing axis(3) | angle | score | antipodal | centre-score with
+    -1 rows for centres without a grasp; (B, Nc, 13) raw-frame layout when ``use_theta`` is False."""
+    B, Nc = center_pc_index.shape
+    dev = center_pc.device
+    label = torch.full((B, Nc, 3, 4), -1.0, device=dev)
+    score_l = torch.full((B, Nc), -1.0, device=dev)
+    anti_l = torch.full((B, Nc), -1.0, device=dev)
+    cen_l = torch.full((B, Nc), -1.0, device=dev)
+    for i, entry in enumerate(data_paths):
+        frames, score, anti, cen = (t.to(dev) for t in _load_grasp_record(entry))
+        approach = frames[:, :3, 0]
+        # the reference shifts the grasp centre along the approach by `depth` and back again (:91-92)
+        contact = ((frames[:, :3, 3] + approach * depth).float() - approach * depth).float()
+        dist, nearest = torch.min(_compute_distance(center_pc[i], contact), dim=1)
+        has = dist <= NO_GRASP_SQ_DISTANCE
+        minus = torch.full((), -1.0, device=dev)
+        label[i] = torch.where(has.view(-1, 1, 1), frames[nearest, :3, :4], minus)
+        score_l[i] = torch.where(has, score[nearest], minus)
+        anti_l[i] = torch.where(has, anti[nearest], minus)
+        cen_l[i] = torch.where(has, cen[nearest], minus)
+    if use_theta:
+        return _transform_grasp(label, score_l, anti_l, cen_l)
+    flat = label.view(-1, 3, 4).clone()
+    flip = flat[:, 0, 1] < 0
+    flat[flip, :, 1:2] = -flat[flip, :, 1:2]
+    out = torch.full((B, Nc, 13), -1.0, device=dev)
+    out[:, :, :12] = flat.transpose(2, 1).contiguous().view(B, Nc, 12)
+    out[:, :, 12] = score_l
+    return out
+
+
+def _wrap_angle(theta):
+    """The reference's four in-place wrap steps (get_regiondataset.py:163-166), in its order."""
+    two_pi = 2 * np.pi
+    theta = torch.where(theta >= two_pi, theta - two_pi, theta)
+    theta = torch.where(theta <= -two_pi, theta + two_pi, theta)
+    theta = torch.where(theta > np.pi, theta - two_pi, theta)
+    theta = torch.where(theta <= -np.pi, theta + two_pi, theta)
+    return theta
+
+
+def _transform_grasp(grasp_ori, grasp_score_ori, antipodal_score_ori, center_score_ori):
+    """(B,Nc,3,4) frames [x|y|z|c] -> (centre, y axis with y.x >= 0, angle = atan2(x_z, z_z) [mirrored
+    to pi - angle when y was flipped, wrapped to (-pi, pi]], scores)  (get_regiondataset.py:136-199).
+    8 channels when no antipodal score is present at all, else 10."""
+    B, Nc = grasp_score_ori.shape
+    wide = bool((antipodal_score_ori != -1).any())
+    axis_x = grasp_ori[:, :, :3, 0].reshape(B * Nc, 3)
+    axis_y = grasp_ori[:, :, :3, 1].reshape(B * Nc, 3)
+    axis_z = grasp_ori[:, :, :3, 2].reshape(B * Nc, 3)
+    missing = (axis_x == -1).all(dim=1)
+    angle = torch.atan2(axis_x[:, 2], axis_z[:, 2])
+    flip = axis_y[:, 0] < 0
+    angle = torch.where(flip, np.pi - angle, angle)
+    axis_y = torch.where(flip.view(-1, 1), -axis_y, axis_y)
+    angle = _wrap_angle(angle)
+    angle = torch.where(missing, torch.full_like(angle, -1.0), angle)
+    out = torch.full((B, Nc, 10 if wide else 8), -1.0, device=grasp_ori.device)
+    out[:, :, :3] = grasp_ori[:, :, :3, 3]
+    out[:, :, 3:6] = axis_y.view(B, Nc, 3)
+    out[:, :, 6] = angle.view(B, Nc)
+    out[:, :, 7] = grasp_score_ori
+    if wide:
+        out[:, :, 8] = antipodal_score_ori
+        out[:, :, 9] = center_score_ori
+    return out
 
 
 def _select_score_center(pc, pre_score, center_num, score_thre):

@@ -12,8 +12,8 @@ Reference quirks that are reproduced on purpose (SURVEY.md §7 "hard parts"):
   * the refine stage re-views the pooled (n,256,1) region feature as 128-wide rows (:343);
   * ``gripper_pc`` / index tensors are created by ``torch.full(..., -1)`` as int64 (:517-520).
 
-Training losses (``ground_grasp`` given; :92-184, :233-309) are plain torch elementwise code
-outside this round's forward hot path and raise NotImplementedError.
+The training losses (``ground_grasp`` given; :92-184, :233-309) are plain torch code (not kernel
+targets); they draw their class-balancing samples from numpy's global RNG like the reference.
 """
 import math
 
@@ -65,38 +65,132 @@ class GripperRegionNetwork(nn.Module):
         tmpl = self.templates.float().view(1, self.anchor_number, 4).expand(n, -1, -1)
         return torch.cat([centers.view(n, 1, 3).expand(-1, self.anchor_number, -1), tmpl], dim=-1)
 
-    def compute_loss(self, first_grasp, anchors, first_cls, ground):
-        """Decode the regression of the arg-max anchor of every centre into a grasp
-        (gripper_region_network.py:69-90):  centre = delta*radius + anchor, orientation
-        re-normalised, theta = pi*(delta + anchor), remaining channels passed through."""
-        if ground is not None:
-            raise NotImplementedError("stage-2 training loss is outside the forward hot path")
-        n = first_grasp.shape[0]
-        gmask = torch.arange(0, n, device=first_grasp.device)
-        pick = torch.max(first_cls, dim=1)[1]
-        sel = pick.view(n, 1, 1)
-        grasp = torch.gather(first_grasp, 1, sel.expand(n, 1, first_grasp.shape[2])).squeeze(1)
-        anchor = torch.gather(anchors.detach(), 1, sel.expand(n, 1, 7)).squeeze(1)
+    def _decode(self, grasp, anchor):
+        """(delta, anchor) -> grasp: centre = delta*radius + anchor, closing axis re-normalised,
+        theta = pi*(delta + anchor), remaining channels passed through (:76-90)."""
         axis = grasp[:, 3:6] + anchor[:, 3:6]
         norm = torch.sqrt(torch.sum(torch.mul(axis, axis), dim=1).add_(1e-12)).view(-1, 1)
-        next_grasp = torch.cat((grasp[:, :3] * self.radius + anchor[:, :3],
-                                torch.div(axis, norm),
-                                np.pi * (grasp[:, 6:7] + anchor[:, 6:7]),
-                                grasp[:, 7:]), dim=-1)
-        return next_grasp, (None, None), (None, None, None, None), None, None, gmask
+        return (grasp[:, :3] * self.radius + anchor[:, :3], torch.div(axis, norm),
+                np.pi * (grasp[:, 6:7] + anchor[:, 6:7]), grasp[:, 7:], norm)
+
+    def compute_loss(self, first_grasp, anchors, first_cls, ground):
+        """Stage-2 decode (+ loss when ``ground`` (B,Nc,10) labels are given)
+        (gripper_region_network.py:46-184).
+
+        Decode: the regression of the arg-max anchor of every labelled centre becomes ``next_grasp``.
+        Loss: anchors are classified against the template whose axis is closest (cosine) to the
+        label's, with class-balanced sampling (numpy RNG); the regression of THAT anchor is trained
+        with smooth-L1 terms: 10*centre + 5*(delta_r*|r|) + theta + score + CE."""
+        n = first_grasp.shape[0]
+        dev = first_grasp.device
+        if ground is not None:
+            gmask = torch.nonzero(ground.view(-1, ground.shape[2])[:, -1] != -1).view(-1).to(dev)
+        else:
+            gmask = torch.arange(0, n, device=dev)
+        anchors = anchors[gmask].detach()
+        first_grasp, first_cls = first_grasp[gmask], first_cls[gmask]
+        m, A = first_cls.shape
+        rows = torch.arange(m, device=dev)
+
+        pick = torch.max(first_cls, dim=1)[1]
+        g_pre, a_pre = first_grasp[rows, pick], anchors[rows, pick]
+        center_pre, r_pre, angle_pre, score_pre, _ = self._decode(g_pre, a_pre)
+        next_grasp = torch.cat((center_pre, r_pre, angle_pre, score_pre), dim=-1)
+        if ground is None:
+            return next_grasp, (None, None), (None, None, None, None), None, None, gmask
+
+        labels = ground.view(-1, ground.shape[2])[gmask]
+        gt7, gt_score = labels[:, :7], labels[:, 7:]
+        # anchor whose orientation template is most similar to the label's closing axis
+        sim = torch.stack([compute_cos_sim(anchors[:, a, 3:6], gt7[:, 3:6]).view(-1) for a in range(A)], dim=1)
+        ground_8 = torch.sort(sim, dim=1, descending=False)[1][:, 0]
+
+        # class-balanced subset: the same number of centres per (non-empty) anchor class
+        counts = [int((ground_8 == a).sum()) for a in range(A)]
+        per_class = max(int(min(counts)), 1)
+        chosen = []
+        for a in range(A):
+            members = torch.nonzero(ground_8 == a).view(-1)
+            if len(members) == 0:
+                continue
+            chosen.append(members[np.random.choice(len(members), per_class, replace=False)])
+        balanced = torch.cat(chosen).long()
+        loss_class = self.criterion_cls(first_cls[balanced], ground_8[balanced].long())
+        correct_tuple = ((ground_8 == pick).sum().float(), (ground_8 != pick).sum().float())
+
+        g_gt, a_gt = first_grasp[rows, ground_8], anchors[rows, ground_8]
+        center_gt, r_gt, angle_gt, score_gt, norm_gt = self._decode(g_gt, a_gt)
+        sl1 = nn.functional.smooth_l1_loss
+        l_center = sl1(g_gt[:, :3], (gt7[:, :3] - a_gt[:, :3]) / self.radius, reduction="mean")
+        l_axis = sl1(torch.mul(g_gt[:, 3:6], norm_gt), gt7[:, 3:6] - a_gt[:, 3:6], reduction="mean")
+        l_theta = sl1(g_gt[:, 6:7], (gt7[:, 6:7] - a_gt[:, 6:7]) / np.pi, reduction="mean")
+        l_score = sl1(g_gt[:, 7:], gt_score, reduction="mean")
+
+        # all-ones target; the reference passes an (m,1) tensor, which its torch 1.8 broadcast to the same value
+        ones = torch.ones(m, device=dev)
+        with torch.no_grad():  # monitoring terms of the arg-max ("pre") decode, never back-propagated (.data in the reference)
+            mon = (sl1(center_pre, gt7[:, :3], reduction="mean"), self.criterion_cos(r_pre, gt7[:, 3:6], ones),
+                   sl1(angle_pre, gt7[:, 6:7], reduction="mean"), sl1(score_pre, gt_score, reduction="mean"))
+        next_gt = torch.cat((gt7, gt_score), dim=1)
+        loss = l_center * 10 + l_axis * 5 + l_theta + l_score + loss_class
+        loss_tuple = (loss, loss_class.data, l_center.data, l_axis.data, l_theta.data, l_score.data) + mon
+        return next_grasp, loss_tuple, correct_tuple, next_gt, a_gt, gmask
 
     def compute_loss_refine(self, next_grasp, next_x_cls, next_x_reg, next_gt):
-        """Apply the refine deltas and select class-1 grasps (gripper_region_network.py:201-215)."""
-        if next_gt is not None:
-            raise NotImplementedError("refine training loss is outside the forward hot path")
+        """Apply the refine deltas, select class-1 grasps, and -- with labels -- the refine loss
+        (gripper_region_network.py:186-309): a grasp is a positive when its stage-2 centre is within
+        2.5 cm, its axis within 60 deg (1 - cos < 0.5) and its angle within 1.047 rad of the label;
+        CE on a class-balanced subset (numpy RNG) + four smooth-L1 terms on the positives."""
+        dev = next_grasp.device
         final_grasp = next_grasp.clone()
         final_grasp[:, :3] = final_grasp[:, :3] + next_x_reg[:, :3] * self.radius
         final_grasp[:, 3:] = final_grasp[:, 3:] + next_x_reg[:, 3:]
         predicted = torch.max(next_x_cls, dim=-1)[1]
         class_select = torch.nonzero(predicted == 1).view(-1)
         score_select = torch.nonzero((predicted == 1) & (final_grasp[:, 7] > self.grasp_score_thre)).view(-1)
-        return (final_grasp[class_select].data, final_grasp[score_select].data, next_grasp[class_select].data,
-                class_select, score_select, (None, None), (None, None, None, None))
+        sel_class, sel_score = final_grasp[class_select].data, final_grasp[score_select].data
+        sel_class_stage2 = next_grasp[class_select].data
+        if next_gt is None:
+            return (sel_class, sel_score, sel_class_stage2, class_select, score_select, (None, None),
+                    (None, None, None, None))
+
+        offset = next_grasp[:, :3] - next_gt[:, :3]
+        near = torch.sqrt(offset[:, 0] * offset[:, 0] + offset[:, 1] * offset[:, 1] + offset[:, 2] * offset[:, 2]) < 0.025
+        aligned = compute_cos_sim(next_grasp[:, 3:6], next_gt[:, 3:6]).view(-1) < 0.5
+        same_angle = torch.abs(next_grasp[:, 6] - next_gt[:, 6]) < 1.047
+        gt_class = (near & aligned & same_angle).float()
+        pos = torch.nonzero(gt_class == 1).view(-1)
+        neg = torch.nonzero(gt_class == 0).view(-1)
+        num = min(len(neg), len(pos))
+
+        zero = torch.tensor(0.0, device=dev)
+        loss = loss_class = l_center = l_axis = l_theta = l_score = zero
+        sl1 = nn.functional.smooth_l1_loss
+        if num > 0:
+            idx0 = neg[np.random.choice(len(neg), num, replace=False)].view(-1)
+            idx1 = pos[np.random.choice(len(pos), num, replace=False)].view(-1)
+            index = torch.cat((idx0, idx1), dim=-1)
+            loss_class = self.criterion_cls(next_x_cls.view(-1, 2)[index], gt_class.view(-1)[index].long())
+            l_center = sl1(next_x_reg[pos, :3], (next_gt[pos, :3] - next_grasp[pos, :3]) / self.radius, reduction="mean")
+            l_axis = sl1(next_x_reg[pos, 3:6], next_gt[pos, 3:6] - next_grasp[pos, 3:6], reduction="mean")
+            l_theta = sl1(next_x_reg[pos, 6], next_gt[pos, 6] - next_grasp[pos, 6], reduction="mean")
+            l_score = sl1(next_x_reg[pos, 7:], next_gt[pos, 7:] - next_grasp[pos, 7:], reduction="mean")
+            loss = loss_class + l_center + l_axis + l_theta + l_score
+
+        mon = [zero] * 12   # stage2 | stage3-class | stage3-score monitoring terms (centre, axis, theta, score)
+        if len(class_select) > 0:
+            with torch.no_grad():
+                def terms(pred, sel):
+                    gt = next_gt[sel]
+                    return [sl1(pred[:, :3], gt[:, :3], reduction="mean"),
+                            self.criterion_cos(pred[:, 3:6], gt[:, 3:6], torch.ones(len(pred), device=dev)),
+                            sl1(pred[:, 6], gt[:, 6], reduction="mean"), sl1(pred[:, 7:], gt[:, 7:], reduction="mean")]
+                mon = terms(sel_class_stage2, class_select) + terms(sel_class, class_select) + \
+                    terms(sel_score, score_select)
+        flat_pred = predicted.view(-1)
+        counts = tuple(((gt_class == g) & (flat_pred == p)).sum().float() for g, p in ((1, 1), (0, 0), (0, 1), (1, 0)))
+        loss_refine_tuple = (loss, loss_class.data, l_center.data, l_axis.data, l_theta.data, l_score) + tuple(mon)
+        return sel_class, sel_score, sel_class_stage2, class_select, score_select, loss_refine_tuple, counts
 
     def refine_forward(self, pc_group_more_xyz, pc_group_more_index, true_mask, all_feature, group_feature_mp,
                        next_grasp, gripper_params, next_gt=None):

@@ -103,3 +103,25 @@ def calibrate_score_head(score_net, pc):
         seg.bn_score.weight.fill_(2.0)
         seg.bn_score.bias.fill_(0.0)
     return mean, var
+
+
+def make_grasp_labels(scene, seed, every=20):
+    """Synthetic ground-truth grasps for a ``make_scene`` cloud, in the dataset's pickle layout
+    (get_regiondataset.py:66-71): ``frame`` (G,4,4) with columns [approach | closing axis | normal |
+    contact point] and ``antipodal_score`` (G,).  One grasp at every ``every``-th point above the table
+    plane (z > 0.7525): the approach points mostly downwards with a random tilt, the closing axis is a
+    random direction orthogonal to it."""
+    rng = np.random.default_rng([seed, 77])
+    xyz = np.asarray(scene)[:, :3].astype(np.float64)
+    obj = np.nonzero(xyz[:, 2] > 0.7525)[0][::every]
+    G = len(obj)
+    approach = np.stack([rng.normal(0, 0.3, G), rng.normal(0, 0.3, G), -np.ones(G)], 1)
+    approach /= np.linalg.norm(approach, axis=1, keepdims=True)
+    rand = rng.normal(size=(G, 3))
+    axis_y = rand - (rand * approach).sum(1, keepdims=True) * approach
+    axis_y /= np.linalg.norm(axis_y, axis=1, keepdims=True)
+    axis_z = np.cross(approach, axis_y)
+    frame = np.zeros((G, 4, 4), np.float64)
+    frame[:, :3, 0], frame[:, :3, 1], frame[:, :3, 2], frame[:, :3, 3] = approach, axis_y, axis_z, xyz[obj]
+    frame[:, 3, 3] = 1.0
+    return {"frame": frame.astype(np.float32), "antipodal_score": rng.uniform(0, 1, G).astype(np.float32)}

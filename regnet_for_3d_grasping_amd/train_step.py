@@ -59,3 +59,61 @@ class ScoreTrainer:
 
     def end_epoch(self):
         self.scheduler.step()
+
+
+class RefineTrainer:
+    """The reference's full training iteration (``--mode train``, train.py:347-384): ScoreNet and the
+    grasp-region/refine network are trained together, one Adam + StepLR each,
+    ``loss_total = score_loss + stage-2 loss (+ refine loss)``.  Like the reference, a failure inside
+    the region stage (e.g. no labelled centre in the batch) falls back to the ScoreNet loss alone.
+    One flat gradient all-reduce per network when ``torch.distributed`` is initialised."""
+
+    def __init__(self, score_net, region_net, params, gripper_params, lr=0.001, reduce="sum"):
+        self.score_net, self.region_net = score_net, region_net
+        self.params, self.gripper_params, self.reduce = params, gripper_params, reduce
+        self.opt_score = torch.optim.Adam([{"params": score_net.parameters(), "initial_lr": lr}], lr=lr)
+        self.opt_region = torch.optim.Adam([{"params": region_net.parameters(), "initial_lr": lr}], lr=lr)
+        self.sched_score = torch.optim.lr_scheduler.StepLR(self.opt_score, step_size=5, gamma=0.5)
+        self.sched_region = torch.optim.lr_scheduler.StepLR(self.opt_region, step_size=5, gamma=0.5)
+
+    def forward_losses(self, pc, pc_score, grasp_records):
+        """-> (loss_total, parts) with parts = dict(score=..., stage2=... or None, refine=... or None)."""
+        import contextlib
+        import io
+
+        from .get_regiondataset import get_grasp_allobj
+        all_feature, output_score, loss = self.score_net(pc, pc_score, None)
+        parts = {"score": loss, "stage2": None, "refine": None}
+        total = loss.sum()
+        try:
+            with contextlib.redirect_stdout(io.StringIO()):
+                g = get_grasp_allobj(pc, output_score, self.params, grasp_records)
+                res = self.region_net(g[3], g[5], g[2], g[4], g[0], g[1], pc, all_feature, self.gripper_params, g[6],
+                                      grasp_records)
+            loss_tuple, loss_refine_tuple = res[3], res[13]
+            total = total + loss_tuple[0].sum()
+            parts["stage2"] = loss_tuple[0]
+            if len(loss_refine_tuple) > 2:
+                total = total + loss_refine_tuple[0].sum()
+                parts["refine"] = loss_refine_tuple[0]
+        except (RuntimeError, IndexError, ValueError) as exc:   # the reference uses a bare except (train.py:430)
+            parts["region_error"] = repr(exc)
+        return total, parts
+
+    def step(self, pc, pc_score, grasp_records):
+        self.score_net.train()
+        self.region_net.train()
+        self.opt_score.zero_grad()
+        self.opt_region.zero_grad()
+        with torch.enable_grad():
+            total, parts = self.forward_losses(pc, pc_score, grasp_records)
+            total.backward()
+        allreduce_gradients(list(self.score_net.parameters()), self.reduce)
+        allreduce_gradients(list(self.region_net.parameters()), self.reduce)
+        self.opt_score.step()
+        self.opt_region.step()
+        return total.detach(), parts
+
+    def end_epoch(self):
+        self.sched_score.step()
+        self.sched_region.step()

@@ -89,3 +89,33 @@ class OpRecorder:
             assert sha(outs[0]) == exp["index_sha256"], "%s index mismatch" % name
             if exp["aux_sha256"] is not None and name == "ball_query":
                 assert sha(outs[1]) == exp["aux_sha256"], "%s count mismatch" % name
+
+
+def loss_inputs(seed, n=96, A=4):
+    """Seeded inputs for the stand-alone loss checks (shared with tests/test_golden_cpu.py)."""
+    rng = np.random.default_rng(seed)
+    f = lambda *s: torch.from_numpy(rng.normal(0, 1, s).astype(np.float32))
+    centres = f(n, 3) * 0.2
+    ground = torch.full((2, n // 2, 10), -1.0)
+    has = torch.from_numpy(rng.uniform(0, 1, n) < 0.8)
+    g = torch.cat([centres + f(n, 3) * 0.01, torch.nn.functional.normalize(f(n, 3), dim=1), f(n, 1) * 0.8,
+                   torch.from_numpy(rng.uniform(0, 1, (n, 3)).astype(np.float32))], 1)
+    g[:, 3:6] = torch.where(g[:, 3:4] < 0, -g[:, 3:6], g[:, 3:6])
+    ground.view(-1, 10)[has] = g[has]
+    stage2 = dict(first_grasp=f(n, A, 10) * 0.3, first_cls=f(n, A), centres=centres, ground=ground)
+    m = 80
+    next_gt = torch.cat([f(m, 3) * 0.2, torch.nn.functional.normalize(f(m, 3), dim=1), f(m, 1) * 0.8,
+                         torch.from_numpy(rng.uniform(0, 1, (m, 3)).astype(np.float32))], 1)
+    next_grasp = next_gt.clone()
+    far = torch.from_numpy(rng.uniform(0, 1, m) < 0.5)
+    next_grasp[far, :3] += 0.05
+    next_grasp[:, :3] += f(m, 3) * 0.004
+    next_grasp[:, 3:6] = torch.nn.functional.normalize(next_grasp[:, 3:6] + f(m, 3) * 0.2, dim=1)
+    next_grasp[:, 6] += f(m) * 0.3
+    refine = dict(next_grasp=next_grasp, next_x_cls=f(m, 2), next_x_reg=f(m, 10) * 0.1, next_gt=next_gt)
+    return stage2, refine
+
+
+def meta_train():
+    with open(os.path.join(GOLDEN, "s4_meta.json")) as f:
+        return json.load(f)
