@@ -57,7 +57,9 @@ class ForwardPipeline:
     CUs and region grouping needs the host for numpy's RNG.  So four stages run concurrently on four
     HIP streams, each on a different batch:
 
-        s_fps : sample(batch i+2)     level-1 FPS                               (1 CU per scene)
+        s_fps : sample(batch i+2, i+3) level-1 FPS, two batches at a time on two streams: a launch is a
+                                      ~10 ms latency chain on ONE CU per scene, so two of them in
+                                      flight double the sampling throughput at no cost to the MLPs
         s_geo : geometry(batch i+1)   FPS levels 2-3, ball query x3, 3-NN x3
         s_mlp : features(batch i)     gather / MFMA shared-MLP / pool / head    (matrix cores)
         s_reg : region(batch i-1)     radius grouping, host RNG draws, GRN + refine heads
@@ -72,17 +74,20 @@ class ForwardPipeline:
         self.device = dev
         # Priorities: FPS and the region stage are chains of small / single-CU kernels (the latter
         # separated by host syncs) -- they must not queue behind the big MLP launches.
-        self.s_fps = torch.cuda.Stream(dev, priority=-1)
+        self.s_fps = [torch.cuda.Stream(dev, priority=-1), torch.cuda.Stream(dev, priority=-1)]
+        self._n_sampled = 0
         self.s_geo = torch.cuda.Stream(dev, priority=-1)
         self.s_mlp = torch.cuda.Stream(dev, priority=0)
         self.s_reg = torch.cuda.Stream(dev, priority=-1)
 
     # -- stages -------------------------------------------------------------------------------
     def _sample(self, pc):
-        with torch.cuda.stream(self.s_fps), torch.no_grad():
+        stream = self.s_fps[self._n_sampled % len(self.s_fps)]
+        self._n_sampled += 1
+        with torch.cuda.stream(stream), torch.no_grad():
             ctr = self.score_net.sample_level1(pc)
             done = torch.cuda.Event()
-            done.record(self.s_fps)
+            done.record(stream)
         ctr.record_stream(self.s_geo)
         ctr.record_stream(self.s_mlp)
         return {"pc": pc, "ctr": ctr, "fps_done": done}
@@ -145,7 +150,7 @@ class ForwardPipeline:
         import threading
 
         cur = torch.cuda.current_stream(self.device)
-        streams = (self.s_fps, self.s_geo, self.s_mlp, self.s_reg)
+        streams = tuple(self.s_fps) + (self.s_geo, self.s_mlp, self.s_reg)
         for s in streams:
             s.wait_stream(cur)
 
@@ -174,7 +179,9 @@ class ForwardPipeline:
             return res
 
         try:
-            st_fps = st_geo = None   # items that have been ENQUEUED up to that stage
+            import collections
+            sampled = collections.deque()   # batches whose level-1 FPS is enqueued (up to len(s_fps) of them)
+            st_geo = None                   # batch whose remaining geometry is enqueued
             it = iter(batches)
             exhausted = False
             while True:
@@ -184,15 +191,18 @@ class ForwardPipeline:
                         pc = next(it)
                     except StopIteration:
                         exhausted = True
-                if pc is None and st_fps is None and st_geo is None:
+                if pc is None and not sampled and st_geo is None:
                     break
                 # enqueue the asynchronous stages, deepest look-ahead first
-                new_fps = self._sample(pc) if pc is not None else None
-                new_geo = self._geometry(st_fps) if st_fps is not None else None
+                if pc is not None:
+                    sampled.append(self._sample(pc))
+                new_geo = None
+                if len(sampled) > len(self.s_fps) or (exhausted and sampled):
+                    new_geo = self._geometry(sampled.popleft())
                 if st_geo is not None:
                     todo.put(self._features(st_geo))
                     pending += 1
-                st_fps, st_geo = new_fps, new_geo
+                st_geo = new_geo
                 while pending > max_pending_regions:      # back-pressure: wait for the oldest region stage
                     yield collect(True)
                     pending -= 1
