@@ -58,6 +58,20 @@ int regnet_ball_query_f32(const float* xyz, int64_t sb, int64_t sc, int64_t sn,
                           int64_t N1, int64_t N2, float radius, int64_t K, int64_t* index,
                           int64_t* count, void* stream);
 
+/* ---- uniform-grid variants of the two all-pairs scans (same results, fewer distance evaluations) ----
+ * The source points (keys of the 3-NN search / the cloud of the ball query) are binned into cubic cells
+ * inside a caller-provided workspace of regnet_grid_workspace_bytes(B, N_source) bytes (16-byte aligned);
+ * outputs are bit-identical to regnet_three_nn_f32 / regnet_ball_query_f32.  The ball-query variant
+ * supports K <= 64 (REGNET_ERR_UNSUPPORTED otherwise: use the plain entry point).                    */
+int64_t regnet_grid_workspace_bytes(int64_t B, int64_t N_source);
+int regnet_three_nn_grid_f32(const float* query, int64_t qb, int64_t qc, int64_t qn, const float* key,
+                             int64_t kb, int64_t kc, int64_t kn, int64_t B, int64_t N1, int64_t N2,
+                             int64_t* index, float* dist2, void* workspace, void* stream);
+int regnet_ball_query_grid_f32(const float* xyz, int64_t sb, int64_t sc, int64_t sn,
+                               const float* centroids, int64_t cb, int64_t cc, int64_t cn, int64_t B,
+                               int64_t N1, int64_t N2, float radius, int64_t K, int64_t* index,
+                               int64_t* count, void* workspace, void* stream);
+
 /* ---- pn2_ext.group_points_forward / backward  (csrc/grouping.h:7-14) ------------------------
  * forward : input (B,C,N1) strided, index (B,N2,K) contiguous -> out (B,C,N2,K) contiguous.
  * backward: grad_out (B,C,N2,K) strided -> grad_in (B,C,N1) contiguous, zero-filled by callee. */

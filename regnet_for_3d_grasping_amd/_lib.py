@@ -21,6 +21,11 @@ SIGNATURES = {
     "regnet_fps_workspace_bytes": (_i64, [_i64, _i64, _i64]),
     "regnet_ball_query_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _f32, _i64,
                                      _vp, _vp, _vp]),
+    "regnet_grid_workspace_bytes": (_i64, [_i64, _i64]),
+    "regnet_three_nn_grid_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp,
+                                        _vp]),
+    "regnet_ball_query_grid_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _f32, _i64,
+                                          _vp, _vp, _vp, _vp]),
     "regnet_group_points_fwd_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp]),
     "regnet_group_points_bwd_f32": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _i64, _i64, _vp,
                                            _vp]),

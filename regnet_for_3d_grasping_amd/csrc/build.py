@@ -19,6 +19,7 @@ SOURCES = [
     ("geometry.hip", ["-ffp-contract=off", "-fno-slp-vectorize"]),  # packed f32 VALU slows the FPS scan (measured -7%)
     ("gather.hip", []),
     ("region.hip", ["-ffp-contract=off"]),
+    ("grid.hip", ["-ffp-contract=off"]),
     ("mlp.hip", []),
     ("np_random.hip", []),
 ]

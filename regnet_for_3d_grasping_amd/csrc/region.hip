@@ -16,34 +16,66 @@
 #define RG_WAVES 4
 
 // cand[(b*NC + c)*cap + pos] = pos-th point (ascending) of scene b with d2(point, centre c) <= thr.
+// One workgroup per centre; its four waves own consecutive quarters of the cloud.  Pass 1 counts the
+// members of each quarter, pass 2 re-tests (the cloud is L2-resident by then) and writes them behind the
+// earlier quarters' totals.  Four 64-point chunks are in flight per wave and iteration.
+#define RG_UNROLL 4
+__device__ __forceinline__ unsigned long long rg_hits(const float* __restrict__ p, int64_t pn, int j, int end,
+                                                      float cx, float cy, float cz, float thr) {
+  bool hit = false;
+  if (j < end) {
+    const float* r = p + (int64_t)j * pn;
+    hit = sqdist3(r[0], r[1], r[2], cx, cy, cz) <= thr;  // point minus centre, inclusive
+  }
+  return __ballot(hit);
+}
+
 __global__ __launch_bounds__(RG_WAVES * 64) void radius_group_kernel(
     const float* __restrict__ pc, int64_t pb, int64_t pn, const float* __restrict__ ctr, int64_t cb, int64_t cn,
     int N, int NC, float thr, int64_t cap, int32_t* __restrict__ cand, int32_t* __restrict__ count) {
-  const int lane = threadIdx.x & 63;
-  const int c = blockIdx.x * RG_WAVES + (threadIdx.x >> 6);
+  __shared__ int wave_cnt[RG_WAVES];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x;
   const int b = blockIdx.y;
-  if (c >= NC) return;
   const float* p = pc + (int64_t)b * pb;
   const float* q = ctr + (int64_t)b * cb + (int64_t)c * cn;
   const float cx = q[0], cy = q[1], cz = q[2];
   int32_t* out = cand + ((int64_t)b * NC + c) * cap;
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  const int per = ((N + RG_WAVES - 1) / RG_WAVES + 63) / 64 * 64;
+  const int beg = min(N, wave * per), end = min(N, beg + per);
   int cnt = 0;
-  for (int j0 = 0; j0 < N; j0 += 64) {
-    const int j = j0 + lane;
-    bool hit = false;
-    if (j < N) {
-      const float* r = p + (int64_t)j * pn;
-      hit = sqdist3(r[0], r[1], r[2], cx, cy, cz) <= thr;  // point minus centre, inclusive
-    }
-    const unsigned long long mask = __ballot(hit);
-    if (hit) {
-      const int pos = cnt + (int)__popcll(mask & lt_mask);
-      if (pos < cap) out[pos] = j;
-    }
-    cnt += (int)__popcll(mask);
+  for (int j0 = beg; j0 < end; j0 += 64 * RG_UNROLL) {
+    unsigned long long m[RG_UNROLL];
+#pragma unroll
+    for (int u = 0; u < RG_UNROLL; ++u) m[u] = rg_hits(p, pn, j0 + 64 * u + lane, end, cx, cy, cz, thr);
+#pragma unroll
+    for (int u = 0; u < RG_UNROLL; ++u) cnt += (int)__popcll(m[u]);
   }
-  if (lane == 0) count[(int64_t)b * NC + c] = cnt;
+  if (lane == 0) wave_cnt[wave] = cnt;
+  __syncthreads();
+  int base = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < RG_WAVES; ++w) {
+    const int v = wave_cnt[w];
+    base += w < wave ? v : 0;
+    total += v;
+  }
+  if (threadIdx.x == 0) count[(int64_t)b * NC + c] = total;
+  if (cnt == 0 || base >= cap) return;   // wave-uniform
+  for (int j0 = beg; j0 < end; j0 += 64 * RG_UNROLL) {
+    unsigned long long m[RG_UNROLL];
+#pragma unroll
+    for (int u = 0; u < RG_UNROLL; ++u) m[u] = rg_hits(p, pn, j0 + 64 * u + lane, end, cx, cy, cz, thr);
+#pragma unroll
+    for (int u = 0; u < RG_UNROLL; ++u) {
+      if ((m[u] >> lane) & 1ull) {
+        const int pos = base + (int)__popcll(m[u] & lt_mask);
+        if (pos < cap) out[pos] = j0 + 64 * u + lane;
+      }
+      base += (int)__popcll(m[u]);
+    }
+  }
 }
 
 extern "C" int regnet_radius_group_f32(const float* pc, int64_t pb, int64_t pn, const float* centres, int64_t cb,
@@ -53,7 +85,8 @@ extern "C" int regnet_radius_group_f32(const float* pc, int64_t pb, int64_t pn, 
   if (N >= (int64_t)1 << 31 || B > 65535) return REGNET_ERR_UNSUPPORTED;
   if (B == 0 || NC == 0) return REGNET_OK;
   if (!centres || !count || (cap > 0 && !cand) || (N > 0 && !pc)) return REGNET_ERR_NULL;
-  dim3 grid((unsigned)((NC + RG_WAVES - 1) / RG_WAVES), (unsigned)B);
+  if (NC >= (int64_t)1 << 31) return REGNET_ERR_UNSUPPORTED;
+  dim3 grid((unsigned)NC, (unsigned)B);
   hipLaunchKernelGGL(radius_group_kernel, grid, dim3(RG_WAVES * 64), 0, as_stream(stream), pc, pb, pn, centres, cb,
                      cn, (int)N, (int)NC, d2_threshold, cap, cand, count);
   REGNET_LAUNCH_CHECK();

@@ -13,6 +13,11 @@ from . import _lib
 _check = _lib.check
 _L = _lib.lib
 
+# Source clouds with at least this many points are binned into a uniform grid first (csrc/grid.hip);
+# smaller ones are cheaper to scan exhaustively from LDS.  Results are identical either way.
+GRID_MIN_POINTS = 2048        # 3-NN keys
+GRID_MIN_POINTS_BALL = 8192   # ball-query cloud (measured break-even between 5 120 and 25 600 points)
+
 
 def _stream(t):
     return torch.cuda.current_stream(t.device).cuda_stream
@@ -78,9 +83,16 @@ def ball_query(points, centroids, radius, num_neighbours):
     with torch.cuda.device(points.device):
         index = torch.empty((B, N2, K), dtype=torch.int64, device=points.device)
         count = torch.empty((B, N2), dtype=torch.int64, device=points.device)
-        _check(_L.regnet_ball_query_f32(points.data_ptr(), *points.stride(), centroids.data_ptr(),
-                                        *centroids.stride(), B, N1, N2, float(radius), K, index.data_ptr(),
-                                        count.data_ptr(), _stream(points)), "ball_query")
+        if N1 >= GRID_MIN_POINTS_BALL and K <= 64 and B > 0 and float(radius) > 0:
+            ws = torch.empty((_L.regnet_grid_workspace_bytes(B, N1),), dtype=torch.uint8, device=points.device)
+            _check(_L.regnet_ball_query_grid_f32(points.data_ptr(), *points.stride(), centroids.data_ptr(),
+                                                 *centroids.stride(), B, N1, N2, float(radius), K,
+                                                 index.data_ptr(), count.data_ptr(), ws.data_ptr(),
+                                                 _stream(points)), "ball_query")
+        else:
+            _check(_L.regnet_ball_query_f32(points.data_ptr(), *points.stride(), centroids.data_ptr(),
+                                            *centroids.stride(), B, N1, N2, float(radius), K, index.data_ptr(),
+                                            count.data_ptr(), _stream(points)), "ball_query")
     return [index, count]
 
 
@@ -137,9 +149,15 @@ def point_search(query_xyz, key_xyz, num_neighbours):
     with torch.cuda.device(query_xyz.device):
         index = torch.empty((B, N1, 3), dtype=torch.int64, device=query_xyz.device)
         dist = torch.empty((B, N1, 3), dtype=torch.float32, device=query_xyz.device)
-        _check(_L.regnet_three_nn_f32(query_xyz.data_ptr(), *query_xyz.stride(), key_xyz.data_ptr(),
-                                      *key_xyz.stride(), B, N1, N2, index.data_ptr(), dist.data_ptr(),
-                                      _stream(query_xyz)), "point_search")
+        if N2 >= GRID_MIN_POINTS and B > 0:
+            ws = torch.empty((_L.regnet_grid_workspace_bytes(B, N2),), dtype=torch.uint8, device=query_xyz.device)
+            _check(_L.regnet_three_nn_grid_f32(query_xyz.data_ptr(), *query_xyz.stride(), key_xyz.data_ptr(),
+                                               *key_xyz.stride(), B, N1, N2, index.data_ptr(), dist.data_ptr(),
+                                               ws.data_ptr(), _stream(query_xyz)), "point_search")
+        else:
+            _check(_L.regnet_three_nn_f32(query_xyz.data_ptr(), *query_xyz.stride(), key_xyz.data_ptr(),
+                                          *key_xyz.stride(), B, N1, N2, index.data_ptr(), dist.data_ptr(),
+                                          _stream(query_xyz)), "point_search")
     return [index, dist]
 
 

@@ -282,3 +282,72 @@ def test_region_ops_match_oracle():
     feat = torch.from_numpy(rng.normal(size=(2 * 6144, 256)).astype(np.float32))
     rows = torch.from_numpy(rng.integers(0, 2 * 6144, (128, 256)))
     assert torch.equal(region_ops.gather_max(feat.to(DEV), rows.to(DEV)).cpu(), region_oracle.gather_max(feat, rows))
+
+
+# ---- uniform-grid variants: must reproduce the exhaustive kernels bit for bit -------------------------
+def _grid_vs_plain(monkeypatch, fn):
+    from regnet_for_3d_grasping_amd import pn2_ext as ext
+    monkeypatch.setattr(ext, "GRID_MIN_POINTS", 1 << 40)
+    monkeypatch.setattr(ext, "GRID_MIN_POINTS_BALL", 1 << 40)
+    plain = fn(ext)
+    monkeypatch.setattr(ext, "GRID_MIN_POINTS", 1)
+    monkeypatch.setattr(ext, "GRID_MIN_POINTS_BALL", 1)
+    grid = fn(ext)
+    return plain, grid
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["scene", "uniform", "line", "duplicates", "lattice", "far_queries", "big_coords"])
+def test_grid_three_nn_matches_exhaustive(case, monkeypatch):
+    import numpy as np
+    from regnet_for_3d_grasping_amd import synthetic
+    rng = np.random.default_rng(5)
+    if case == "scene":
+        pc = synthetic.make_batch(77, 2, 6000)[..., :3].numpy()
+        q, k = pc, pc[:, ::5]
+    elif case == "uniform":
+        q = rng.uniform(-1, 1, (2, 3000, 3)); k = rng.uniform(-1, 1, (2, 700, 3))
+    elif case == "line":          # degenerate extent on two axes
+        k = np.zeros((1, 500, 3)); k[..., 0] = rng.uniform(0, 1, (1, 500)); q = rng.uniform(-0.2, 1.2, (1, 900, 3)) * [1, 0.01, 0.01]
+    elif case == "duplicates":    # all keys identical -> ties resolved by index
+        k = np.tile(np.array([[0.3, 0.2, 0.1]]), (1, 64, 1)).reshape(1, 64, 3); q = rng.uniform(0, 1, (1, 300, 3))
+    elif case == "lattice":       # many exactly equal distances
+        g = np.stack(np.meshgrid(np.arange(12), np.arange(12), np.arange(6), indexing="ij"), -1).reshape(1, -1, 3) * 0.25
+        k = g[:, rng.permutation(g.shape[1])]; q = g[:, rng.permutation(g.shape[1])] + 0.125
+    elif case == "far_queries":   # queries well outside the key bounding box
+        k = rng.uniform(0, 0.1, (2, 400, 3)); q = rng.uniform(-5, 5, (2, 1000, 3))
+    else:                         # coordinates in millimetres
+        k = rng.uniform(0, 800, (1, 900, 3)) + 5000; q = rng.uniform(0, 800, (1, 2500, 3)) + 5000
+    qt = torch.tensor(q, dtype=torch.float32, device="cuda").permute(0, 2, 1)
+    kt = torch.tensor(k, dtype=torch.float32, device="cuda").permute(0, 2, 1)
+    plain, grid = _grid_vs_plain(monkeypatch, lambda ext: ext.point_search(qt, kt, 3))
+    assert torch.equal(plain[0], grid[0])
+    assert torch.equal(plain[1], grid[1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case,radius,K", [("scene", 0.02, 64), ("scene", 0.08, 64), ("scene", 0.3, 64),
+                                           ("scene", 0.05, 16), ("uniform", 0.15, 32), ("lattice", 0.25, 64),
+                                           ("empty", 0.01, 8), ("big_coords", 40.0, 64), ("all", 10.0, 64)])
+def test_grid_ball_query_matches_exhaustive(case, radius, K, monkeypatch):
+    import numpy as np
+    from regnet_for_3d_grasping_amd import synthetic
+    rng = np.random.default_rng(6)
+    if case == "scene":
+        p = synthetic.make_batch(78, 2, 8000)[..., :3].numpy(); c = p[:, :700]
+    elif case == "uniform":
+        p = rng.uniform(-1, 1, (2, 5000, 3)); c = rng.uniform(-1.1, 1.1, (2, 333, 3))
+    elif case == "lattice":       # points exactly at distance == radius must be excluded (strict <)
+        g = np.stack(np.meshgrid(np.arange(12), np.arange(12), np.arange(6), indexing="ij"), -1).reshape(1, -1, 3) * 0.25
+        p = g[:, rng.permutation(g.shape[1])]; c = p[:, :200]
+    elif case == "empty":
+        p = rng.uniform(0, 1, (1, 3000, 3)); c = rng.uniform(3, 4, (1, 50, 3))
+    elif case == "big_coords":
+        p = rng.uniform(0, 800, (1, 4000, 3)) + 5000; c = p[:, :300]
+    else:                         # every point inside every ball: first K indices
+        p = rng.uniform(0, 1, (1, 2500, 3)); c = p[:, :40]
+    pt = torch.tensor(p, dtype=torch.float32, device="cuda").permute(0, 2, 1)
+    ct = torch.tensor(c, dtype=torch.float32, device="cuda").permute(0, 2, 1)
+    plain, grid = _grid_vs_plain(monkeypatch, lambda ext: ext.ball_query(pt, ct, radius, K))
+    assert torch.equal(plain[1], grid[1])
+    assert torch.equal(plain[0], grid[0])
