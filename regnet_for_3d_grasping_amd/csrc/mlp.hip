@@ -33,6 +33,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
                    // extra resident waves cover the global-load latency of the short-K layers)
 #endif
 #define BK MLP_BK
+#ifndef MLP_ABLATE
+#define MLP_ABLATE 0  // timing experiments only (scripts/ablate): 1 no global loads after tile 0, 2 also no LDS
+                      // refill / barrier, 3 no epilogue, 4 = 2 + 3; results are wrong for anything but 0
+#endif
 #define LDS_LD (BK + 4)  // +4 floats: the 16-lane service groups of ds_read_b128 then hit 64 distinct banks
 #define ROWS_PER_PASS (MLP_THREADS / (BK / 4))  // rows one staging pass of the 256 threads covers
 #define STAGE_PASSES (BM / ROWS_PER_PASS)
@@ -169,13 +173,15 @@ __global__ __launch_bounds__(MLP_THREADS, AMODE == 2 ? 3 : MLP_MIN_WAVES) void m
   // made the compiler keep ra/rw in scratch and wait for every global load right after issuing it.)
   float4 ra0, ra1, ra2, ra3, rw0, rw1, rw2, rw3;  // named scalars (arrays here ended up in scratch)
   ra0 = ra1 = ra2 = ra3 = rw0 = rw1 = rw2 = rw3 = make_float4(0.f, 0.f, 0.f, 0.f);
-// All global loads are UNCONDITIONAL (addresses clamped into valid memory, invalid lanes zeroed with
-// selects afterwards): a load inside a branch made the compiler wait for it at the join, i.e. at the
-// top of every k-tile instead of right before the LDS write.
+// All global loads are UNCONDITIONAL and their results are not touched until STORE_TILE: addresses
+// are clamped into valid memory and the fix-ups (zero columns, relative-xyz columns of a gathered
+// row) are applied right before the LDS write, one k-tile of MFMAs later.  (A select directly after
+// the load made every wave sit out the full memory latency at the top of each k-tile: -11 %.)
+//   * rows >= P read row 0: they produce accumulator rows the epilogue never stores;
+//   * plain mode, columns >= Ka read columns 0..3 of the row: W is zero there (packed, zero padded).
 #define LOAD_PASS(I, RA, RW, KC)                                                                        \
   if ((I) < STAGE_PASSES) {                                                                             \
     constexpr int i = (I) < STAGE_PASSES ? (I) : 0;                                                     \
-    float4 v;                                                                                           \
     if (FUSE1) {                                                                                        \
       float e[4];                                                                                       \
       _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                   \
@@ -184,45 +190,35 @@ __global__ __launch_bounds__(MLP_THREADS, AMODE == 2 ? 3 : MLP_MIN_WAVES) void m
         _Pragma("unroll") for (int c = 1; c < 8; ++c) a1 += w[c] * xin[i][c];                           \
         e[t] = fmaxf(a1 * w[8] + w[9], 0.f);                                                            \
       }                                                                                                 \
-      v = make_float4(e[0], e[1], e[2], e[3]);                                                          \
+      RA = make_float4(e[0], e[1], e[2], e[3]);                                                         \
     } else if (GATHER) {                                                                                \
       if (p.feat_vec) { /* wave-uniform branch */                                                       \
-        const bool infeat = (KC) + 4 <= p.Cf;                                                           \
-        v = *reinterpret_cast<const float4*>(arow[i] + (infeat ? (KC) : 0));                            \
-        float e[4] = {v.x, v.y, v.z, v.w};                                                              \
-        _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                 \
-          const int col = (KC) + t;                                                                     \
-          float x = infeat ? e[t] : 0.f;                                                                \
-          x = (col == p.Cf) ? relx[i] : x;                                                              \
-          x = (col == p.Cf + 1) ? rely[i] : x;                                                          \
-          x = (col == p.Cf + 2) ? relz[i] : x;                                                          \
-          e[t] = x;                                                                                     \
-        }                                                                                               \
-        v = make_float4(e[0], e[1], e[2], e[3]);                                                        \
-      } else {                                                                                          \
-        float e[4];                                                                                     \
-        _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                 \
-          const int col = (KC) + t;                                                                     \
-          float x = 0.f;                                                                                \
-          if (p.Cf > 0) {                                                                               \
-            const float f = arow[i][(long long)min(col, p.Cf - 1) * p.fc];                              \
-            x = col < p.Cf ? f : 0.f;                                                                   \
-          }                                                                                             \
-          x = (col == p.Cf) ? relx[i] : x;                                                              \
-          x = (col == p.Cf + 1) ? rely[i] : x;                                                          \
-          x = (col == p.Cf + 2) ? relz[i] : x;                                                          \
-          e[t] = x;                                                                                     \
-        }                                                                                               \
-        v = make_float4(e[0], e[1], e[2], e[3]);                                                        \
+        RA = *reinterpret_cast<const float4*>(arow[i] + ((KC) + 4 <= p.Cf ? (KC) : 0));                 \
+      } else if (p.Cf > 0) {                                                                            \
+        RA.x = arow[i][(long long)min((KC) + 0, p.Cf - 1) * p.fc];                                      \
+        RA.y = arow[i][(long long)min((KC) + 1, p.Cf - 1) * p.fc];                                      \
+        RA.z = arow[i][(long long)min((KC) + 2, p.Cf - 1) * p.fc];                                      \
+        RA.w = arow[i][(long long)min((KC) + 3, p.Cf - 1) * p.fc];                                      \
       }                                                                                                 \
     } else {                                                                                            \
-      const bool incol = (KC) < p.Ka;                                                                   \
-      v = *reinterpret_cast<const float4*>(arow[i] + (incol ? (KC) : 0));                               \
-      if (!incol) v = make_float4(0.f, 0.f, 0.f, 0.f);                                                  \
+      RA = *reinterpret_cast<const float4*>(arow[i] + ((KC) < p.Ka ? (KC) : 0));                        \
     }                                                                                                   \
-    if (!arow_ok[i]) v = make_float4(0.f, 0.f, 0.f, 0.f);                                               \
-    RA = v;                                                                                             \
     RW = *reinterpret_cast<const float4*>(wrow[i] + (KC));                                              \
+  }
+// gather mode: columns [0, Cf) are features, Cf..Cf+2 the relative xyz, the rest zero
+#define FIX_PASS(I, RA, KC)                                                                             \
+  if (GATHER && !FUSE1 && (I) < STAGE_PASSES) {                                                         \
+    constexpr int i = (I) < STAGE_PASSES ? (I) : 0;                                                     \
+    float e[4] = {RA.x, RA.y, RA.z, RA.w};                                                              \
+    _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                     \
+      const int col = (KC) + t;                                                                         \
+      float x = col < p.Cf ? e[t] : 0.f;                                                                \
+      x = (col == p.Cf) ? relx[i] : x;                                                                  \
+      x = (col == p.Cf + 1) ? rely[i] : x;                                                              \
+      x = (col == p.Cf + 2) ? relz[i] : x;                                                              \
+      e[t] = x;                                                                                         \
+    }                                                                                                   \
+    RA = make_float4(e[0], e[1], e[2], e[3]);                                                           \
   }
 #define LOAD_TILE(K0)                  \
   do {                                 \
@@ -237,8 +233,13 @@ __global__ __launch_bounds__(MLP_THREADS, AMODE == 2 ? 3 : MLP_MIN_WAVES) void m
     *reinterpret_cast<float4*>(&sA[BUF][sr + ROWS_PER_PASS * (I)][4 * c4]) = RA;            \
     *reinterpret_cast<float4*>(&sW[BUF][sr + ROWS_PER_PASS * (I)][4 * c4]) = RW;            \
   }
-#define STORE_TILE(BUF)                \
+#define STORE_TILE(BUF, K0)            \
   do {                                 \
+    const int kf_ = (K0) + 4 * c4;     \
+    FIX_PASS(0, ra0, kf_)              \
+    FIX_PASS(1, ra1, kf_)              \
+    FIX_PASS(2, ra2, kf_)              \
+    FIX_PASS(3, ra3, kf_)              \
     STORE_PASS(0, ra0, rw0, BUF)       \
     STORE_PASS(1, ra1, rw1, BUF)       \
     STORE_PASS(2, ra2, rw2, BUF)       \
@@ -256,12 +257,12 @@ __global__ __launch_bounds__(MLP_THREADS, AMODE == 2 ? 3 : MLP_MIN_WAVES) void m
 
   const int KT = p.Kpad / BK;
   LOAD_TILE(0);
-  STORE_TILE(0);
+  STORE_TILE(0, 0);
   __syncthreads();
   const int fr = lane & 31, fh = lane >> 5;
   for (int kt = 0; kt < KT; ++kt) {
     const int buf = kt & 1;
-    if (kt + 1 < KT) LOAD_TILE((kt + 1) * BK);
+    if (kt + 1 < KT && !(MLP_ABLATE == 1 || MLP_ABLATE == 2 || MLP_ABLATE == 4)) LOAD_TILE((kt + 1) * BK);
 #pragma unroll
     for (int kk = 0; kk < BK / 8; ++kk) {
       float4 a[2], b[2];
@@ -281,8 +282,20 @@ __global__ __launch_bounds__(MLP_THREADS, AMODE == 2 ? 3 : MLP_MIN_WAVES) void m
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].w, b[ni].w, acc[mi][ni], 0, 0, 0);
         }
     }
-    if (kt + 1 < KT) STORE_TILE(buf ^ 1);
+    if (MLP_ABLATE == 2 || MLP_ABLATE == 4) continue;
+    if (kt + 1 < KT) STORE_TILE(buf ^ 1, (kt + 1) * BK);
     __syncthreads();
+  }
+  if (MLP_ABLATE >= 3) {   // keep the accumulators live without the store traffic
+    float keep = 0.f;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) keep += acc[mi][ni][r];
+    if (keep == 1.2345e-30f) p.C[0] = keep;
+    return;
   }
 
   // ---- epilogue: folded BN affine + ReLU (+ max over the 64 rows of a group) -------------
