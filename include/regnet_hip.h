@@ -171,6 +171,20 @@ int regnet_sa_layer12_f32(const float* feat, int64_t fb, int64_t fn, int64_t fc,
                           int64_t Kpad, const float* scale, const float* shift, float* C, int64_t ldc,
                           int64_t N, int relu, int pool_group, void* stream);
 
+/* ---- set-abstraction layers 1+2 with layer 1 evaluated per SOURCE point ---------------------------
+ * The first SharedMLP layer of a set-abstraction block (pn2_utils/modules.py:44-55: conv over
+ * [xyz_j - xyz_c | feature_j]) is linear in the gathered row, so
+ *   scale1 * W1 [f_j | x_j - x_c] + shift1 = U[j] - V[c],   U = scale1 * W1 [f | x]  (B*Nsrc rows),
+ *                                                             V = scale1 * W1x x_c - shift1 (B*M rows),
+ * both produced by regnet_mlp_layer_f32 (relu = 0).  This entry point gathers, applies the ReLU and
+ * multiplies by layer 2:  A[p][k] = max(U[b*Nsrc + nbr[p]][k] - V[p / group][k], 0), k < C1 (C1 % 4 == 0);
+ * C = epilogue(A . W^T) exactly as regnet_mlp_layer_f32 (pool_group 0 or 64).  Same values as the
+ * gather-then-multiply form up to fp32 rounding of the re-associated sum.                          */
+int regnet_sa_premul_layer_f32(const float* U, int64_t ldu, const float* V, int64_t ldv, int64_t C1,
+                               const int64_t* nbr, int64_t B, int64_t Nsrc, int64_t M, int64_t group,
+                               const float* W, int64_t Kpad, const float* scale, const float* shift,
+                               float* C, int64_t ldc, int64_t N, int relu, int pool_group, void* stream);
+
 /* regnet_interp_concat_f32: FeatureInterpolator.forward (modules.py:104-131) channels-last:
  * out[b*Nd+n] = [sum_k w_k * sparse[b, idx[b,n,k], 0:Cs] | dense[b,n,0:Cd] | 0...], w from squared
  * distances (inv = 1/max(d2,eps), w = inv/sum).  sparse (b,n,:) at sparse[b*sb + n*sn + c];

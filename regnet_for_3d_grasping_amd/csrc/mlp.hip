@@ -74,6 +74,13 @@ struct MlpArgs {
   const float* W1;
   const float* scale1;
   const float* shift1;
+  // ---- gather mode over PRE-MULTIPLIED source rows (AMODE 3).  The first layer of a set-abstraction
+  //      block is linear in its gathered input, W1 [f_j | x_j - x_c] = (W1 [f_j | x_j]) - (W1x x_c), so it is
+  //      evaluated once per SOURCE point (U = scale1 * W1 [f | x], rows b*Nsrc + j, via `feat`/`fb`/`fn`) and
+  //      once per CENTRE (V = scale1 * W1x x_c - shift1) instead of once per (centre, neighbour) pair:
+  //        A[p][k] = relu(U[b, nbr[p]][k] - V[p / group][k]).
+  const float* V;
+  long long ldv;
   // ---- output
   float* C;
   long long ldc;
@@ -106,8 +113,9 @@ __global__ __launch_bounds__(MLP_THREADS, AMODE == 2 ? 3 : MLP_MIN_WAVES) void m
   static_assert(2 * BM * LDS_LD + 2 * BN * LDS_LD >= 4 * 64 * 36, "epilogue staging does not fit");
   __shared__ __attribute__((aligned(16))) float sW1[AMODE == 2 ? 256 * 10 : 4];  // [C1 <= 256][8 weights | scale | shift]
 
-  constexpr bool GATHER = AMODE != 0;
+  constexpr bool GATHER = AMODE == 1 || AMODE == 2;
   constexpr bool FUSE1 = AMODE == 2;
+  constexpr bool PREMUL = AMODE == 3;
   const int tid = threadIdx.x;
   if (FUSE1) {
     for (int k = tid; k < p.Kpad; k += MLP_THREADS) {
@@ -135,12 +143,19 @@ __global__ __launch_bounds__(MLP_THREADS, AMODE == 2 ? 3 : MLP_MIN_WAVES) void m
   bool arow_ok[STAGE_PASSES];
   float relx[STAGE_PASSES], rely[STAGE_PASSES], relz[STAGE_PASSES];
   float xin[STAGE_PASSES][8];  // FUSE1: the gathered layer-1 input row [feat | rel xyz | 0]
+  const float* vrow[STAGE_PASSES];  // PREMUL: the centre's row of V
 #pragma unroll
   for (int i = 0; i < STAGE_PASSES; ++i) {
     const long long row = row0 + sr + ROWS_PER_PASS * i;
     arow_ok[i] = row < p.P;
     const long long rs = arow_ok[i] ? row : 0;
-    if (GATHER) {
+    vrow[i] = nullptr;
+    if (PREMUL) {
+      const long long b = rs / p.rows_per_scene;
+      arow[i] = p.feat + b * p.fb + p.nbr[rs] * p.fn;
+      vrow[i] = p.V + (rs / p.group) * p.ldv;
+      relx[i] = rely[i] = relz[i] = 0.f;
+    } else if (GATHER) {
       const long long b = rs / p.rows_per_scene;
       const long long j = p.nbr[rs];
       const long long cj = p.ctr[rs / p.group];
@@ -172,17 +187,23 @@ __global__ __launch_bounds__(MLP_THREADS, AMODE == 2 ? 3 : MLP_MIN_WAVES) void m
   // Staging registers.  (Kept as plain locals + an inlined helper macro: a by-reference lambda
   // made the compiler keep ra/rw in scratch and wait for every global load right after issuing it.)
   float4 ra0, ra1, ra2, ra3, rw0, rw1, rw2, rw3;  // named scalars (arrays here ended up in scratch)
+  float4 rv0, rv1, rv2, rv3;                        // PREMUL: the V chunk that goes with ra*
   ra0 = ra1 = ra2 = ra3 = rw0 = rw1 = rw2 = rw3 = make_float4(0.f, 0.f, 0.f, 0.f);
+  rv0 = rv1 = rv2 = rv3 = make_float4(0.f, 0.f, 0.f, 0.f);
 // All global loads are UNCONDITIONAL and their results are not touched until STORE_TILE: addresses
 // are clamped into valid memory and the fix-ups (zero columns, relative-xyz columns of a gathered
 // row) are applied right before the LDS write, one k-tile of MFMAs later.  (A select directly after
 // the load made every wave sit out the full memory latency at the top of each k-tile: -11 %.)
 //   * rows >= P read row 0: they produce accumulator rows the epilogue never stores;
 //   * plain mode, columns >= Ka read columns 0..3 of the row: W is zero there (packed, zero padded).
-#define LOAD_PASS(I, RA, RW, KC)                                                                        \
+#define LOAD_PASS(I, RA, RW, RV, KC)                                                                    \
   if ((I) < STAGE_PASSES) {                                                                             \
     constexpr int i = (I) < STAGE_PASSES ? (I) : 0;                                                     \
-    if (FUSE1) {                                                                                        \
+    if (PREMUL) {                                                                                       \
+      const int kc_u = (KC) < p.Ka ? (KC) : 0;                                                          \
+      RA = *reinterpret_cast<const float4*>(arow[i] + kc_u);                                            \
+      RV = *reinterpret_cast<const float4*>(vrow[i] + kc_u);                                            \
+    } else if (FUSE1) {                                                                                        \
       float e[4];                                                                                       \
       _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                   \
         const float* w = &sW1[((KC) + t) * 10];                                                         \
@@ -206,7 +227,11 @@ __global__ __launch_bounds__(MLP_THREADS, AMODE == 2 ? 3 : MLP_MIN_WAVES) void m
     RW = *reinterpret_cast<const float4*>(wrow[i] + (KC));                                              \
   }
 // gather mode: columns [0, Cf) are features, Cf..Cf+2 the relative xyz, the rest zero
-#define FIX_PASS(I, RA, KC)                                                                             \
+#define FIX_PASS(I, RA, RV, KC)                                                                         \
+  if (PREMUL && (I) < STAGE_PASSES) {                                                                   \
+    RA = make_float4(fmaxf(RA.x - RV.x, 0.f), fmaxf(RA.y - RV.y, 0.f), fmaxf(RA.z - RV.z, 0.f),         \
+                     fmaxf(RA.w - RV.w, 0.f));                                                          \
+  }                                                                                                     \
   if (GATHER && !FUSE1 && (I) < STAGE_PASSES) {                                                         \
     constexpr int i = (I) < STAGE_PASSES ? (I) : 0;                                                     \
     float e[4] = {RA.x, RA.y, RA.z, RA.w};                                                              \
@@ -223,10 +248,10 @@ __global__ __launch_bounds__(MLP_THREADS, AMODE == 2 ? 3 : MLP_MIN_WAVES) void m
 #define LOAD_TILE(K0)                  \
   do {                                 \
     const int kc_ = (K0) + 4 * c4;     \
-    LOAD_PASS(0, ra0, rw0, kc_)        \
-    LOAD_PASS(1, ra1, rw1, kc_)        \
-    LOAD_PASS(2, ra2, rw2, kc_)        \
-    LOAD_PASS(3, ra3, rw3, kc_)        \
+    LOAD_PASS(0, ra0, rw0, rv0, kc_)   \
+    LOAD_PASS(1, ra1, rw1, rv1, kc_)   \
+    LOAD_PASS(2, ra2, rw2, rv2, kc_)   \
+    LOAD_PASS(3, ra3, rw3, rv3, kc_)   \
   } while (0)
 #define STORE_PASS(I, RA, RW, BUF)                                                          \
   if ((I) < STAGE_PASSES) {                                                                 \
@@ -236,10 +261,10 @@ __global__ __launch_bounds__(MLP_THREADS, AMODE == 2 ? 3 : MLP_MIN_WAVES) void m
 #define STORE_TILE(BUF, K0)            \
   do {                                 \
     const int kf_ = (K0) + 4 * c4;     \
-    FIX_PASS(0, ra0, kf_)              \
-    FIX_PASS(1, ra1, kf_)              \
-    FIX_PASS(2, ra2, kf_)              \
-    FIX_PASS(3, ra3, kf_)              \
+    FIX_PASS(0, ra0, rv0, kf_)         \
+    FIX_PASS(1, ra1, rv1, kf_)         \
+    FIX_PASS(2, ra2, rv2, kf_)         \
+    FIX_PASS(3, ra3, rv3, kf_)         \
     STORE_PASS(0, ra0, rw0, BUF)       \
     STORE_PASS(1, ra1, rw1, BUF)       \
     STORE_PASS(2, ra2, rw2, BUF)       \
@@ -381,7 +406,9 @@ static int launch_gemm(const MlpArgs& a_in, int amode, bool pool, hipStream_t st
   if (tiles <= 0) return REGNET_OK;
   if (tiles >= (1ll << 31)) return REGNET_ERR_UNSUPPORTED;
   dim3 grid((unsigned)tiles), block(MLP_THREADS);
-  if (amode == 2 && pool) hipLaunchKernelGGL((mlp_gemm_kernel<2, true>), grid, block, 0, st, a);
+  if (amode == 3 && pool) hipLaunchKernelGGL((mlp_gemm_kernel<3, true>), grid, block, 0, st, a);
+  else if (amode == 3) hipLaunchKernelGGL((mlp_gemm_kernel<3, false>), grid, block, 0, st, a);
+  else if (amode == 2 && pool) hipLaunchKernelGGL((mlp_gemm_kernel<2, true>), grid, block, 0, st, a);
   else if (amode == 2) hipLaunchKernelGGL((mlp_gemm_kernel<2, false>), grid, block, 0, st, a);
   else if (amode == 1 && pool) hipLaunchKernelGGL((mlp_gemm_kernel<1, true>), grid, block, 0, st, a);
   else if (amode == 1) hipLaunchKernelGGL((mlp_gemm_kernel<1, false>), grid, block, 0, st, a);
@@ -450,6 +477,30 @@ extern "C" int regnet_sa_layer12_f32(const float* feat, int64_t fb, int64_t fn, 
   a.W = W; a.Kpad = (int)Kpad; a.scale = scale; a.shift = shift;
   a.C = C; a.ldc = ldc; a.P = P; a.N = (int)N; a.relu = relu;
   return launch_gemm(a, 2, pool_group != 0, as_stream(stream));
+}
+
+// Layer 2 of a set-abstraction block over pre-multiplied layer-1 rows (AMODE 3, see MlpArgs::V):
+//   U (B*Nsrc, ldu) = scale1 * W1 [f | x] per source point, V (B*M, ldv) = scale1 * W1x x_c - shift1 per centre,
+//   A[p][k] = relu(U[b*Nsrc + nbr[p]][k] - V[p / group][k]) for k < C1;  C = epilogue(A . W^T).
+extern "C" int regnet_sa_premul_layer_f32(const float* U, int64_t ldu, const float* V, int64_t ldv, int64_t C1,
+                                          const int64_t* nbr, int64_t B, int64_t Nsrc, int64_t M, int64_t group,
+                                          const float* W, int64_t Kpad, const float* scale, const float* shift,
+                                          float* C, int64_t ldc, int64_t N, int relu, int pool_group, void* stream) {
+  if (B < 0 || M < 0 || Nsrc <= 0 || group <= 0 || N <= 0 || C1 <= 0 || (C1 & 3) || C1 > Kpad || Kpad % BK || (ldu & 3) ||
+      (ldv & 3) || ldu < C1 || ldv < C1)
+    return REGNET_ERR_SHAPE;
+  if (pool_group != 0 && (pool_group != 64 || group != 64)) return REGNET_ERR_UNSUPPORTED;
+  const long long P = B * M * group;
+  if (P == 0) return REGNET_OK;
+  if (!U || !V || !nbr || !W || !scale || !shift || !C) return REGNET_ERR_NULL;
+  if (!aligned16(U) || !aligned16(V) || !aligned16(W)) return REGNET_ERR_SHAPE;
+  MlpArgs a = {};
+  a.feat = U; a.fb = Nsrc * ldu; a.fn = ldu; a.fc = 1; a.Ka = (int)C1;
+  a.V = V; a.ldv = ldv; a.nbr = (const long long*)nbr;
+  a.group = (int)group; a.rows_per_scene = M * group;
+  a.W = W; a.Kpad = (int)Kpad; a.scale = scale; a.shift = shift;
+  a.C = C; a.ldc = ldc; a.P = P; a.N = (int)N; a.relu = relu;
+  return launch_gemm(a, 3, pool_group != 0, as_stream(stream));
 }
 
 // ---------------------------------------------------------------------------------------

@@ -17,6 +17,7 @@ import torch
 from . import _lib, pn2_ext
 
 ENABLED = True
+PREMUL = True   # evaluate the first layer of wide set-abstraction blocks per source point (see sa_features)
 
 _check = _lib.check
 _L = _lib.lib
@@ -37,7 +38,7 @@ def _round_up(x, m):
 class _Layer:
     """One conv(1x1, bias-free or biased) + eval BatchNorm (+ReLU) packed for the GEMM kernel."""
 
-    __slots__ = ("W", "W8", "scale", "shift", "N", "K", "Kpad", "relu")
+    __slots__ = ("W", "W8", "scale", "shift", "N", "K", "Kpad", "relu", "premul")
 
 
 def _pack(conv, bn, relu, col_order=None):
@@ -60,6 +61,7 @@ def _pack(conv, bn, relu, col_order=None):
         shift = shift + conv.bias.detach().float() * scale
     L.W, L.scale, L.shift = Wp.contiguous(), scale.contiguous(), shift.contiguous()
     L.W8 = None
+    L.premul = None
     if K <= 8:  # narrow first layer: also keep the [N][8] form consumed by the layer-1-fused gather kernel
         W8 = torch.zeros((N, 8), dtype=torch.float32, device=w.device)
         W8[:, :K] = w
@@ -130,6 +132,33 @@ def sa_layer12(feature, xyz, nbr, ctr, first, layer, B, M, group, pool_group=0):
     return out
 
 
+def _premul_layers(first, Cf):
+    """Derived packings of a set-abstraction block's first layer (columns [feature | xyz]) for the
+    per-source-point evaluation: ``u`` = scale * W [f | x] (no shift, no ReLU) and ``v`` = scale * Wx x_c - shift."""
+    if first.premul is None:
+        u, v = _Layer(), _Layer()
+        u.W, u.W8, u.premul, u.scale, u.N, u.K, u.Kpad, u.relu = first.W, None, None, first.scale, first.N, first.K, first.Kpad, 0
+        u.shift = torch.zeros_like(first.shift)
+        Wx = torch.zeros((first.W.shape[0], 16), dtype=torch.float32, device=first.W.device)
+        Wx[:, :3] = first.W[:, Cf:Cf + 3]
+        v.W, v.W8, v.premul, v.scale, v.N, v.K, v.Kpad, v.relu = Wx.contiguous(), None, None, first.scale, first.N, 3, 16, 0
+        v.shift = (-first.shift).contiguous()
+        first.premul = (u, v)
+    return first.premul
+
+
+def sa_premul_layer(U, V, nbr, layer, B, Nsrc, M, group, pool_group=0):
+    """Layer 2 of a set-abstraction block over pre-multiplied layer-1 rows: relu(U[nbr] - V[centre]) . W."""
+    P = B * M * group
+    rows = P // pool_group if pool_group else P
+    out = torch.empty((rows, layer.N), dtype=torch.float32, device=U.device)
+    _check(_L.regnet_sa_premul_layer_f32(U.data_ptr(), U.stride(0), V.data_ptr(), V.stride(0), U.size(1),
+                                         nbr.data_ptr(), B, Nsrc, M, group, layer.W.data_ptr(), layer.Kpad,
+                                         layer.scale.data_ptr(), layer.shift.data_ptr(), out.data_ptr(),
+                                         out.stride(0), layer.N, layer.relu, pool_group, _stream(U)), "sa_premul_layer")
+    return out
+
+
 def interp_concat(sparse_cl, idx, dist2, eps, dense_feature, B, Nd):
     """sparse_cl: (B,Ns,Cs) channels-last contiguous; dense_feature (B,Cd,Nd) any strides or None.
     Returns the (B*Nd, round_up(Cs+Cd,4)) channels-last operand of the first FP layer and its valid width."""
@@ -179,6 +208,8 @@ def _flop_meta(P, K, N):
 TIMED_OPS = {
     "mlp_layer": lambda A, Ka, layer, P, pool_group=0: _flop_meta(P, layer.K, layer.N),
     "sa_layer1": lambda feature, xyz, nbr, ctr, layer, B, M, group: _flop_meta(B * M * group, layer.K, layer.N),
+    "sa_premul_layer": lambda U, V, nbr, layer, B, Nsrc, M, group, pool_group=0:
+        _flop_meta(B * M * group, layer.K, layer.N),
     "sa_layer12": lambda feature, xyz, nbr, ctr, first, layer, B, M, group, pool_group=0:
         "P%d K%d N%d flop%d" % (B * M * group, layer.K, layer.N,
                                 2 * B * M * group * (layer.K * layer.N + first.K * first.N)),
@@ -234,6 +265,25 @@ def sa_features(module, xyz, feature, geo):
             pooled = sa_layer12(feature, xyz, geo["nbr"], geo["ctr"], layers[0], layers[1], B, M, K, pool_group=K)
             return geo["new_xyz"], pooled.view(B, M, -1).transpose(1, 2)
         h = sa_layer12(feature, xyz, geo["nbr"], geo["ctr"], layers[0], layers[1], B, M, K)
+        rest = layers[2:]
+    elif PREMUL and feature is not None and layers[0].relu and layers[0].N % 4 == 0 and layers[1].K == layers[0].N:
+        # wide gathered input (levels 2+): layer 1 is linear in [f_j | x_j - x_c], so it is evaluated once
+        # per source point and once per centre (N + M rows instead of M * 64) and the gather, the
+        # subtraction and the ReLU happen inside layer 2's operand load
+        first, N1 = layers[0], xyz.shape[2]
+        u_layer, v_layer = _premul_layers(first, Cf)
+        width = _round_up(Cf + 3, 4)
+        src = torch.zeros((B, N1, width), dtype=torch.float32, device=xyz.device)
+        src[:, :, :Cf] = feature.transpose(1, 2)
+        src[:, :, Cf:Cf + 3] = xyz.transpose(1, 2)
+        U = mlp_layer(src.view(B * N1, width), width, u_layer, B * N1)
+        cxyz = torch.zeros((B, M, 4), dtype=torch.float32, device=xyz.device)
+        cxyz[:, :, :3] = geo["new_xyz"].transpose(1, 2)
+        V = mlp_layer(cxyz.view(B * M, 4), 4, v_layer, B * M)
+        if len(layers) == 2:
+            pooled = sa_premul_layer(U, V, geo["nbr"], layers[1], B, N1, M, K, pool_group=K)
+            return geo["new_xyz"], pooled.view(B, M, -1).transpose(1, 2)
+        h = sa_premul_layer(U, V, geo["nbr"], layers[1], B, N1, M, K)
         rest = layers[2:]
     else:
         h = sa_layer1(feature, xyz, geo["nbr"], geo["ctr"], layers[0], B, M, K)

@@ -200,3 +200,36 @@ def test_region_and_refine_heads_fused_equal_torch(monkeypatch):
     for got, want in ((c1, c0), (r1, r0), (a1, a0), (b1, b0)):
         assert got.shape == want.shape
         torch.testing.assert_close(got, want, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("n_layers", [2, 3])
+def test_sa_premultiplied_first_layer_equals_gathered_form(n_layers, monkeypatch):
+    """Wide set-abstraction block: layer 1 evaluated per source point (U[nbr] - V[centre]) == layer 1 over the
+    gathered [xyz_j - xyz_c | feature_j] rows (modules.py:44-55), for 2- and 3-layer stacks."""
+    import regnet_for_3d_grasping_amd.fused as fused
+    from regnet_for_3d_grasping_amd import synthetic
+    from regnet_for_3d_grasping_amd.pn2_utils.modules import PointNetSAModule
+    torch.manual_seed(3)
+    pc = synthetic.make_batch(1010, 2, 3000, device=DEV)
+    xyz = pc.permute(0, 2, 1)[:, :3, :]
+    feat = torch.randn(2, 128, 3000, device=DEV)
+    channels = (128, 256) if n_layers == 2 else (128, 128, 256)
+    sa = PointNetSAModule(128, channels, 300, 0.08, 64, True).to(DEV).eval()
+    for m in sa.modules():
+        if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+            with torch.no_grad():
+                m.running_mean.normal_(0, 0.1)
+                m.running_var.uniform_(0.5, 1.5)
+                m.weight.uniform_(0.8, 1.2)
+                m.bias.normal_(0, 0.1)
+    with torch.no_grad():
+        monkeypatch.setattr(fused, "ENABLED", True)
+        monkeypatch.setattr(fused, "PREMUL", True)
+        nx2, nf2 = sa(xyz, feat)
+        monkeypatch.setattr(fused, "PREMUL", False)
+        nx1, nf1 = sa(xyz, feat)
+        monkeypatch.setattr(fused, "ENABLED", False)
+        nx0, nf0 = sa(xyz, feat)
+    assert torch.equal(nx0, nx2) and torch.equal(nx1, nx2)
+    torch.testing.assert_close(nf2, nf1, rtol=1e-5, atol=2e-5)
+    torch.testing.assert_close(nf2, nf0, rtol=1e-4, atol=1e-4)
