@@ -120,6 +120,15 @@ int regnet_radius_group_f32(const float* pc, int64_t pb, int64_t pn, const float
                             float d2_threshold, int64_t cap, int32_t* cand, int32_t* count,
                             void* stream);
 
+/* regnet_select_positive_f32: dataset_utils/get_regiondataset.py:354-434 (the `score > thr` mask +
+ * torch.nonzero per scene of the centre picker).  pc (B,N,*) rows with xyz first (strides pb,pn),
+ * score (B,N) (row stride sb) -> index (B,N) int64: first count[b] entries = ascending ids of the
+ * points with score > threshold (strict); xyz_out (B,3,N) contiguous: their coordinates in that
+ * order, slots >= count[b] repeat the first positive; count (B) int32.                          */
+int regnet_select_positive_f32(const float* pc, int64_t pb, int64_t pn, const float* score, int64_t sb,
+                               int64_t B, int64_t N, float threshold, int64_t* index, float* xyz_out,
+                               int32_t* count, void* stream);
+
 /* regnet_box_crop_f32: multi_model/gripper_region_network.py:508-544 (the per-grasp torch.nonzero
  * loop).  group_points (n,G,*) rows with xyz first (strides gb,gn), centre (n,3), rot (n,3,3)
  * row-major = [approach; axis_y; minor_normal], xlim/ylim (n) per-grasp half extents, zlim

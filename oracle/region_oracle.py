@@ -26,6 +26,25 @@ def radius_candidates(pc, centres, radius):
     return cand, count
 
 
+def select_positive(pc, score, threshold):
+    """dataset_utils/get_regiondataset.py:372-377,:400-405: positives = torch.nonzero(score > thr), ascending.
+    Same outputs as region_ops.select_positive: index (B,N) int64, xyz (B,3,N) padded with the first
+    positive, count (B) int32."""
+    B, N, _ = pc.shape
+    index = torch.zeros((B, max(N, 1)), dtype=torch.int64)
+    xyz = torch.zeros((B, 3, max(N, 1)), dtype=torch.float32)
+    count = torch.zeros((B,), dtype=torch.int32)
+    for b in range(B):
+        members = torch.nonzero(score[b] > threshold).view(-1)
+        n = members.numel()
+        count[b] = n
+        if n:
+            index[b, :n] = members
+            xyz[b, :, :n] = pc[b, members, :3].t()
+            xyz[b, :, n:] = pc[b, members[0], :3].view(3, 1)
+    return index, xyz, count
+
+
 def box_candidates(group_points, centre, rot, xlim, ylim, zlim):
     """multi_model/gripper_region_network.py:508-528: t = R (p - c), six strict box tests;
     products summed left to right in fp32 (numpy float32 ops round individually)."""

@@ -36,6 +36,7 @@ SIGNATURES = {
     "regnet_gather_knn_bwd_f32": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp]),
     "regnet_radius_group_f32": (_int, [_vp, _i64, _i64, _vp, _i64, _i64, _i64, _i64, _i64, _f32, _i64, _vp, _vp,
                                        _vp]),
+    "regnet_select_positive_f32": (_int, [_vp, _i64, _i64, _vp, _i64, _i64, _i64, _f32, _vp, _vp, _vp, _vp]),
     "regnet_box_crop_f32": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _f32, _i64, _i64, _vp, _vp, _vp]),
     "regnet_gather_max_f32": (_int, [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _vp]),
     "regnet_mlp_layer_f32": (_int, [_vp, _i64, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _int, _int, _vp]),

@@ -139,6 +139,9 @@ def _transform_grasp(grasp_ori, grasp_score_ori, antipodal_score_ori, center_sco
     return out
 
 
+_FPS_PAD_MIN = 1024   # scenes with more positives than this share one padded sampling launch
+
+
 def _select_score_center(pc, pre_score, center_num, score_thre):
     """Pick ``center_num`` grasp centres per scene among points scoring > ``score_thre``
     (get_regiondataset.py:354-434): FPS over the positive subset when there are more than
@@ -146,19 +149,40 @@ def _select_score_center(pc, pre_score, center_num, score_thre):
     with random repeats when 0 < P <= center_num; random points when P == 0.  The B == 1 and
     B > 1 branches of the reference implement the same rule and draw the same numpy variates.
 
-    One host sync for the whole batch (the positive counts); the ascending positive indices of
-    every scene come from one stable argsort instead of a ``torch.nonzero`` per scene."""
+    One host sync for the whole batch (the positive counts).  The ascending positive ids and their
+    coordinates come from one compaction kernel, and the scenes that need sampling share ONE
+    furthest-point-sampling launch over a common prefix length: the compacted coordinates are padded
+    with copies of the scene's first positive, which is the sampler's start point -- the copies stay at
+    distance 0 from the selected set and are never picked, and above 512 points the reference's tie
+    order does not depend on the length, so each scene gets exactly its own per-scene result."""
     B, N, C = pc.shape
-    positive = pre_score.to(pc.device) > score_thre
-    order = torch.argsort((~positive).to(torch.uint8), dim=1, stable=True)   # positives first, ascending
-    counts = positive.sum(1).cpu().tolist()
+    score = pre_score.to(pc.device)
+    if score.dtype != torch.float32:
+        score = score.float()
+    order, sub_xyz, count = region_ops.select_positive(pc, score.view(B, N), score_thre)
+    counts = count.cpu().tolist()
     index = torch.empty((B, center_num), dtype=torch.int64, device=pc.device)
+    # scenes sampled together: enough positives for the padding argument above to hold
+    batched = [b for b in range(B) if counts[b] > max(center_num, _FPS_PAD_MIN)]
+    if len(batched) > 1:
+        pmax = max(counts[b] for b in batched)
+        rows = torch.tensor(batched, device=pc.device)
+        xyz_b = sub_xyz[:, :, :pmax] if len(batched) == B else sub_xyz[rows][:, :, :pmax]
+        local = _F.farthest_point_sample(xyz_b, center_num)                  # (len(batched), center_num)
+        picked = torch.gather(order if len(batched) == B else order[rows], 1, local)
+        if len(batched) == B:
+            index.copy_(picked)
+        else:
+            index[rows] = picked
+    else:
+        batched = []
     for b in range(B):
+        if b in batched:
+            continue
         P = int(counts[b])
         map_index = order[b, :P]
         if P > center_num:
-            sub_xyz = pc[b, map_index, :3].view(1, P, 3).transpose(2, 1)
-            index[b] = map_index[_F.farthest_point_sample(sub_xyz, center_num).view(-1)]
+            index[b] = map_index[_F.farthest_point_sample(sub_xyz[b:b + 1, :, :P], center_num).view(-1)]
         elif P > 0:
             extra = np.random.choice(P, center_num - P, replace=True)
             local = torch.cat([torch.arange(P), torch.from_numpy(np.asarray(extra, dtype=np.int64))])

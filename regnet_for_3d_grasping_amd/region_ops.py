@@ -47,6 +47,27 @@ def radius_candidates(pc, centres, radius):
     return cand, count
 
 
+def select_positive(pc, score, threshold):
+    """pc (B,N,C>=3), score (B,N) float32, threshold -> index (B,N) int64 (ascending ids of the points
+    with score > threshold in the first ``count[b]`` slots), xyz (B,3,N) (their coordinates, padded with
+    the first positive), count (B) int32."""
+    _need_f32(pc, "pc")
+    _need_f32(score, "score")
+    if pc.stride(2) != 1:
+        pc = pc.contiguous()
+    if score.stride(1) != 1:
+        score = score.contiguous()
+    B, N, _ = pc.shape
+    with torch.cuda.device(pc.device):
+        index = torch.empty((B, max(N, 1)), dtype=torch.int64, device=pc.device)
+        xyz = torch.empty((B, 3, max(N, 1)), dtype=torch.float32, device=pc.device)
+        count = torch.empty((B,), dtype=torch.int32, device=pc.device)
+        _check(_L.regnet_select_positive_f32(pc.data_ptr(), pc.stride(0), pc.stride(1), score.data_ptr(),
+                                             score.stride(0), B, N, float(threshold), index.data_ptr(),
+                                             xyz.data_ptr(), count.data_ptr(), _stream(pc)), "select_positive")
+    return index, xyz, count
+
+
 def box_candidates(group_points, centre, rot, xlim, ylim, zlim):
     """group_points (n,G,C>=3), centre (n,3), rot (n,3,3), xlim/ylim (n) float32, zlim float ->
     cand (n,G) int32 ascending in-box positions, count (n) int32."""
