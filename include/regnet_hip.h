@@ -203,6 +203,22 @@ int regnet_interp_concat_f32(const float* sparse, int64_t sb, int64_t sn, int64_
                              int64_t db, int64_t dn, int64_t dc, int64_t Cd, int64_t B, int64_t Nd,
                              float* out, int64_t ldo, int64_t Cout, void* stream);
 
+/* ---- feature propagation with the first SharedMLP layer applied BEFORE the interpolation -------------
+ * The layer is linear in [sum_k w_k sparse[idx_k] | dense] (pn2_utils/modules.py:117-131), hence
+ *   out[p][n] = relu(scale[n] * (sum_k w_k Ys[b, idx_k[p]][n] + Yd[p][n]) + shift[n]),
+ * Ys (B,Ns,C) = Ws . sparse per SPARSE point (strides sb,sn; channel stride 1), Yd (B*Nd, ldd) = Wd . dense
+ * per dense point or NULL, both from regnet_mlp_layer_f32 with scale 1 / shift 0 / relu 0; w_k as in
+ * regnet_interp_concat_f32 (from squared distances).  A narrow skip input (Cd_small <= 4 channels, e.g.
+ * rgb; element (b,c,n) at dense_small[b*db + c*dc + n*dn]) is multiplied in place with its weight columns
+ * Wd4 (C x 4, zero padded) instead of going through Yd; pass NULL when unused.
+ * C % 4 == 0, C/4 must divide 256.  out (B*Nd, ldo).                                                   */
+int regnet_interp_affine_f32(const float* ys, int64_t sb, int64_t sn, const int64_t* idx,
+                             const float* dist2, float eps, const float* yd, int64_t ldd,
+                             const float* dense_small, int64_t db, int64_t dn, int64_t dc,
+                             int64_t Cd_small, const float* Wd4, const float* scale, const float* shift,
+                             int relu, int64_t B, int64_t Nd, int64_t C, float* out, int64_t ldo,
+                             void* stream);
+
 /* regnet_score_head_f32: score = sigmoid(bn_score(conv_score(x))) (utils/pointnet2.py:117-119),
  * x (P,C) channels-last, w (C), bn folded to (bn_scale, bn_shift).                                */
 int regnet_score_head_f32(const float* x, int64_t ldx, int64_t C, const float* w, float bias,

@@ -560,6 +560,96 @@ extern "C" int regnet_interp_concat_f32(const float* sparse, int64_t sb, int64_t
 }
 
 // ---------------------------------------------------------------------------------------
+// First layer of a feature-propagation block evaluated BEFORE the interpolation.  The layer is linear in
+// its input [sum_k w_k sparse[idx_k] | dense]  (pn2_utils/modules.py:117-131), so with Ys = Ws . sparse
+// (one row per SPARSE point) and Yd = Wd . dense (one row per dense point, optional):
+//   out[p][n] = relu(scale[n] * (sum_k w_k Ys[b, idx_k][n] + Yd[p][n]) + shift[n])
+// (a skip input of <= 4 channels, e.g. rgb, is multiplied right here instead: + Wd4[n][0:4] . dense[p])
+// -- the wide GEMM runs over the few sparse rows instead of the many dense ones.  Weights as above
+// (from squared distances, k order of the reference's interpolation kernel).  Threads walk channels in
+// float4 steps so every gathered row is one coalesced read.
+__global__ __launch_bounds__(256) void interp_affine_kernel(
+    const float* __restrict__ ys, long long sb, long long sn, const long long* __restrict__ idx,
+    const float* __restrict__ dist2, float eps, const float* __restrict__ yd, long long ldd,
+    const float* __restrict__ dsm, long long db, long long dn, long long dc, int Cdsm, const float* __restrict__ wd4,
+    const float* __restrict__ scale, const float* __restrict__ shift, int relu, long long Nd, int C,
+    float* __restrict__ out, long long ldo, long long P) {
+  const int lanes_per_row = C / 4;                       // C % 4 == 0, <= 256
+  const int rows_per_pass = 256 / lanes_per_row;         // launcher guarantees lanes_per_row divides 256
+  const int r_in = threadIdx.x / lanes_per_row, c4 = threadIdx.x % lanes_per_row;
+  const float4 sc = *reinterpret_cast<const float4*>(scale + 4 * c4);
+  const float4 sh = *reinterpret_cast<const float4*>(shift + 4 * c4);
+  float4 wq[4];   // narrow skip input (<= 4 channels, e.g. rgb): its weight columns for this thread's 4 outputs
+#pragma unroll
+  for (int q = 0; q < 4; ++q) wq[q] = dsm ? *reinterpret_cast<const float4*>(wd4 + (4 * c4 + q) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const long long row_base = (long long)blockIdx.x * (IC_ROWS * rows_per_pass);
+#pragma unroll
+  for (int rr = 0; rr < IC_ROWS; ++rr) {
+    const long long p = row_base + (long long)rr * rows_per_pass + r_in;
+    if (p >= P) continue;
+    const long long b = p / Nd;
+    const long long j0 = idx[p * 3], j1 = idx[p * 3 + 1], j2 = idx[p * 3 + 2];
+    const float i0 = 1.0f / fmaxf(dist2[p * 3], eps), i1 = 1.0f / fmaxf(dist2[p * 3 + 1], eps),
+                i2 = 1.0f / fmaxf(dist2[p * 3 + 2], eps);
+    const float norm = (i0 + i1) + i2;
+    const float w0 = i0 / norm, w1 = i1 / norm, w2 = i2 / norm;
+    const float4 a0 = *reinterpret_cast<const float4*>(ys + b * sb + j0 * sn + 4 * c4);
+    const float4 a1 = *reinterpret_cast<const float4*>(ys + b * sb + j1 * sn + 4 * c4);
+    const float4 a2 = *reinterpret_cast<const float4*>(ys + b * sb + j2 * sn + 4 * c4);
+    float4 v;
+    v.x = (a0.x * w0 + a1.x * w1) + a2.x * w2;
+    v.y = (a0.y * w0 + a1.y * w1) + a2.y * w2;
+    v.z = (a0.z * w0 + a1.z * w1) + a2.z * w2;
+    v.w = (a0.w * w0 + a1.w * w1) + a2.w * w2;
+    if (yd) {
+      const float4 d = *reinterpret_cast<const float4*>(yd + p * ldd + 4 * c4);
+      v.x += d.x; v.y += d.y; v.z += d.z; v.w += d.w;
+    }
+    if (dsm) {
+      const float* dp = dsm + b * db + (p - b * Nd) * dn;
+      float d[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) d[c] = c < Cdsm ? dp[(long long)min(c, Cdsm - 1) * dc] : 0.f;
+      v.x += ((wq[0].x * d[0] + wq[0].y * d[1]) + wq[0].z * d[2]) + wq[0].w * d[3];
+      v.y += ((wq[1].x * d[0] + wq[1].y * d[1]) + wq[1].z * d[2]) + wq[1].w * d[3];
+      v.z += ((wq[2].x * d[0] + wq[2].y * d[1]) + wq[2].z * d[2]) + wq[2].w * d[3];
+      v.w += ((wq[3].x * d[0] + wq[3].y * d[1]) + wq[3].z * d[2]) + wq[3].w * d[3];
+    }
+    v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+    if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    *reinterpret_cast<float4*>(out + p * ldo + 4 * c4) = v;
+  }
+}
+
+extern "C" int regnet_interp_affine_f32(const float* ys, int64_t sb, int64_t sn, const int64_t* idx,
+                                        const float* dist2, float eps, const float* yd, int64_t ldd,
+                                        const float* dense_small, int64_t db, int64_t dn, int64_t dc,
+                                        int64_t Cd_small, const float* Wd4, const float* scale, const float* shift,
+                                        int relu, int64_t B, int64_t Nd, int64_t C, float* out, int64_t ldo,
+                                        void* stream) {
+  if (B < 0 || Nd < 0 || C <= 0 || (C & 3) || ldo < C || (ldo & 3) || (sn & 3) || (sb & 3) || (yd && (ldd < C || (ldd & 3))) ||
+      (dense_small && (Cd_small < 1 || Cd_small > 4)))
+    return REGNET_ERR_SHAPE;
+  // a row is walked by C/4 lanes; the block holds a whole number of rows
+  if (C / 4 > 256 || 256 % (C / 4) != 0) return REGNET_ERR_UNSUPPORTED;
+  const long long P = B * Nd;
+  if (P == 0) return REGNET_OK;
+  if (!ys || !idx || !dist2 || !scale || !shift || !out || (dense_small && !Wd4)) return REGNET_ERR_NULL;
+  if (!aligned16(ys) || !aligned16(out) || !aligned16(scale) || !aligned16(shift) || (yd && !aligned16(yd)) ||
+      (dense_small && !aligned16(Wd4)))
+    return REGNET_ERR_SHAPE;
+  const long long rows_per_block = (long long)IC_ROWS * (256 / (C / 4));
+  const long long blocks = (P + rows_per_block - 1) / rows_per_block;
+  if (blocks >= (1ll << 31)) return REGNET_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(interp_affine_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), ys, (long long)sb,
+                     (long long)sn, (const long long*)idx, dist2, eps, yd, (long long)ldd, dense_small, (long long)db,
+                     (long long)dn, (long long)dc, (int)Cd_small, Wd4, scale, shift, relu, (long long)Nd, (int)C, out,
+                     (long long)ldo, P);
+  REGNET_LAUNCH_CHECK();
+  return REGNET_OK;
+}
+
+// ---------------------------------------------------------------------------------------
 // Score head: score[p] = sigmoid(bn(dot(x[p], w) + bias))  (pointnet2.py:116-119), x channels-last.
 // One wave per point: 64 lanes stride the channels, DPP-free shuffle reduction.
 __global__ __launch_bounds__(256) void score_head_kernel(const float* __restrict__ x, long long ldx, int C,

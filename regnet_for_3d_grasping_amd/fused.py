@@ -176,6 +176,47 @@ def interp_concat(sparse_cl, idx, dist2, eps, dense_feature, B, Nd):
     return out, width
 
 
+def _fp_split_layers(first, Cs):
+    """Derived packings of a feature-propagation block's first layer (columns [interpolated | skip]):
+    ``s`` = W[:, :Cs] and ``d`` = W[:, Cs:], both without affine / ReLU (applied after the interpolation)."""
+    if first.premul is None:
+        def part(cols):
+            L = _Layer()
+            K = cols.shape[1]
+            L.N, L.K, L.Kpad, L.relu, L.W8, L.premul = first.N, K, _round_up(max(K, 1), 16), 0, None, None
+            Wp = torch.zeros((first.W.shape[0], L.Kpad), dtype=torch.float32, device=first.W.device)
+            Wp[:, :K] = cols
+            L.W = Wp.contiguous()
+            L.scale = torch.ones_like(first.scale)
+            L.shift = torch.zeros_like(first.shift)
+            return L
+        Cd = first.K - Cs
+        wd4 = None
+        if 0 < Cd <= 4:   # narrow skip input (rgb): multiplied inside the interpolation kernel
+            wd4 = torch.zeros((first.N, 4), dtype=torch.float32, device=first.W.device)
+            wd4[:, :Cd] = first.W[:first.N, Cs:first.K]
+            wd4 = wd4.contiguous()
+        first.premul = (part(first.W[:, :Cs]), part(first.W[:, Cs:first.K]) if Cd > 4 else None, wd4)
+    return first.premul
+
+
+def interp_affine(Ys, idx, dist2, eps, Yd, dense_small, wd4, layer, B, Ns, Nd):
+    """relu(scale * (sum_k w_k Ys[idx_k] + Yd + Wd4 . dense_small) + shift): the 3-NN interpolation of
+    pre-multiplied sparse rows.  ``dense_small``: (B,Cd<=4,Nd) any strides, or None."""
+    C = layer.N
+    out = torch.empty((B * Nd, C), dtype=torch.float32, device=Ys.device)
+    if dense_small is None:
+        dptr, db, dc, dn, Cd, wptr = None, 0, 0, 0, 0, None
+    else:
+        dptr, (db, dc, dn), Cd, wptr = dense_small.data_ptr(), dense_small.stride(), dense_small.size(1), wd4.data_ptr()
+    _check(_L.regnet_interp_affine_f32(Ys.data_ptr(), Ns * Ys.stride(0), Ys.stride(0), idx.data_ptr(),
+                                       dist2.data_ptr(), float(eps), None if Yd is None else Yd.data_ptr(),
+                                       0 if Yd is None else Yd.stride(0), dptr, db, dn, dc, Cd, wptr,
+                                       layer.scale.data_ptr(), layer.shift.data_ptr(), layer.relu, B, Nd, C,
+                                       out.data_ptr(), out.stride(0), _stream(Ys)), "interp_affine")
+    return out
+
+
 def _packed_head(seg):
     """conv_score weight + folded bn_score scalars, cached like the layer stacks (reading the
     scalars costs a device sync, so do it once per weight version, not per forward)."""
@@ -309,6 +350,25 @@ def fp_features(module, dense_xyz, dense_feature, sparse_feature, geo):
     """Interpolate + concat + SharedMLP of a PointnetFPModule (modules.py:117-131, :507)."""
     B, _, Nd = dense_xyz.shape
     layers = _packed_stack(module, module.mlp)
+    Cs, Ns = sparse_feature.size(1), sparse_feature.size(2)
+    Cd = 0 if dense_feature is None else dense_feature.size(1)
+    first = layers[0]
+    if (PREMUL and first.N % 4 == 0 and 256 % (first.N // 4) == 0 and Cs % 4 == 0 and (Cd % 4 == 0 or Cd <= 4)
+            and Ns < Nd and first.K == Cs + Cd and (dense_feature is None or dense_feature.dtype == torch.float32)):
+        # layer 1 is linear in [interpolated | skip]: multiply the SPARSE rows (and the skip rows by their own
+        # weight columns), interpolate the products
+        lay_s, lay_d, wd4 = _fp_split_layers(first, Cs)
+        Ys = mlp_layer(_as_channels_last(sparse_feature).view(B * Ns, Cs), Cs, lay_s, B * Ns)
+        Yd = None
+        if lay_d is not None:
+            Yd = mlp_layer(_as_channels_last(dense_feature).view(B * Nd, Cd), Cd, lay_d, B * Nd)
+        h = interp_affine(Ys, geo["idx"], geo["dist2"], module.interpolator._eps, Yd,
+                          dense_feature if wd4 is not None else None, wd4, first, B, Ns, Nd)
+        Ka, P = first.N, B * Nd
+        for layer in layers[1:]:
+            h = mlp_layer(h, Ka, layer, P)
+            Ka = layer.N
+        return h.view(B, Nd, -1).transpose(1, 2)
     A, width = interp_concat(_as_channels_last(sparse_feature), geo["idx"], geo["dist2"], module.interpolator._eps,
                              dense_feature, B, Nd)
     P = B * Nd

@@ -233,3 +233,35 @@ def test_sa_premultiplied_first_layer_equals_gathered_form(n_layers, monkeypatch
     assert torch.equal(nx0, nx2) and torch.equal(nx1, nx2)
     torch.testing.assert_close(nf2, nf1, rtol=1e-5, atol=2e-5)
     torch.testing.assert_close(nf2, nf0, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("Cd", [0, 3, 64])
+def test_fp_premultiplied_first_layer_equals_interpolate_then_multiply(Cd, monkeypatch):
+    """Feature propagation: W . [interp(sparse) | skip] == interp(Ws . sparse) + Wd . skip (modules.py:117-131)."""
+    import regnet_for_3d_grasping_amd.fused as fused
+    from regnet_for_3d_grasping_amd import synthetic
+    from regnet_for_3d_grasping_amd.pn2_utils.modules import PointnetFPModule
+    torch.manual_seed(5)
+    pc = synthetic.make_batch(1020, 2, 3000, device=DEV)
+    dense_xyz = pc.permute(0, 2, 1)[:, :3, :]
+    sparse_xyz = dense_xyz[:, :, ::6].contiguous()
+    sparse_feat = torch.randn(2, 256, sparse_xyz.size(2), device=DEV)
+    dense_feat = torch.randn(2, Cd, 3000, device=DEV) if Cd else None
+    fp = PointnetFPModule(256 + Cd, (256, 128), 3).to(DEV).eval()
+    for m in fp.modules():
+        if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+            with torch.no_grad():
+                m.running_mean.normal_(0, 0.1)
+                m.running_var.uniform_(0.5, 1.5)
+                m.weight.uniform_(0.8, 1.2)
+                m.bias.normal_(0, 0.1)
+    with torch.no_grad():
+        monkeypatch.setattr(fused, "ENABLED", True)
+        monkeypatch.setattr(fused, "PREMUL", True)
+        up2 = fp(dense_xyz, sparse_xyz, dense_feat, sparse_feat)
+        monkeypatch.setattr(fused, "PREMUL", False)
+        up1 = fp(dense_xyz, sparse_xyz, dense_feat, sparse_feat)
+        monkeypatch.setattr(fused, "ENABLED", False)
+        up0 = fp(dense_xyz, sparse_xyz, dense_feat, sparse_feat)
+    torch.testing.assert_close(up2, up1, rtol=1e-5, atol=2e-5)
+    torch.testing.assert_close(up2, up0, rtol=1e-4, atol=1e-4)
