@@ -19,9 +19,11 @@ import json
 import sys
 
 FAMILY = [("mlp_gemm_kernel", "mlp_gemm_kernel"), ("fps_", "fps_kernel"), ("ball_query_kernel", "ball_query_kernel"),
-          ("three_nn_kernel", "three_nn_kernel"), ("interp_concat_kernel", "interp_concat_kernel"),
-          ("gather_max_kernel", "gather_max_kernel"), ("radius_group_kernel", "radius_group_kernel")]
-WIDE_STREAM = {"mlp_gemm_kernel", "interp_concat_kernel"}
+          ("ball_query_grid_kernel", "ball_query_grid_kernel"), ("three_nn_kernel", "three_nn_kernel"),
+          ("three_nn_grid_kernel", "three_nn_grid_kernel"), ("interp_concat_kernel", "interp_concat_kernel"),
+          ("interp_affine_kernel", "interp_affine_kernel"), ("gather_max_kernel", "gather_max_kernel"),
+          ("radius_group_kernel", "radius_group_kernel"), ("select_positive_kernel", "select_positive_kernel")]
+WIDE_STREAM = {"mlp_gemm_kernel", "interp_concat_kernel", "interp_affine_kernel"}
 WRITE_CAL = {"mlp_gemm_kernel": 1310720.0 / 2140420.25}
 
 
