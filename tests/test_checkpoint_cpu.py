@@ -1,0 +1,88 @@
+"""checkpoint compatibility with the reference's whole-object pickles.
+
+Fixtures ``tests/golden/ckpt_*_7.model.gz`` were written by the REFERENCE's classes (tests/golden/make_golden_ckpt.py,
+authoring container); here they are restored with only this repo on the path."""
+import gzip
+import os
+import shutil
+import sys
+import zlib
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+
+def _pattern(key, shape, dtype):
+    n = 1
+    for s in shape:
+        n *= s
+    phase = zlib.crc32(key.encode()) % 11
+    if dtype in (torch.int64, torch.int32):
+        return torch.full(shape, phase, dtype=dtype)
+    base = ((torch.arange(n, dtype=torch.int64) + phase) % 13 - 6).to(torch.float32) / 16.0
+    out = base.view(shape).to(dtype) if n else torch.zeros(shape, dtype=dtype)
+    return out.abs() + 0.5 if key.endswith("running_var") else out
+
+
+def _unzip(name, tmp_path):
+    dst = os.path.join(str(tmp_path), name[:-3].replace("ckpt_", ""))      # score_7.model / region_7.model
+    with gzip.open(os.path.join(HERE, "golden", name), "rb") as src, open(dst, "wb") as out:
+        shutil.copyfileobj(src, out)
+    return dst
+
+
+def _check_state(model):
+    state = model.state_dict()
+    assert len(state) > 50
+    for key, value in state.items():
+        assert torch.equal(value, _pattern(key, tuple(value.shape), value.dtype)), key
+
+
+def test_reference_scorenet_checkpoint_restores(tmp_path):
+    from regnet_for_3d_grasping_amd import checkpoint
+    path = _unzip("ckpt_score_7.model.gz", tmp_path)
+    # the pickle is a DataParallel-wrapped reference ScoreNetwork: it must unpickle onto this repo's classes
+    obj = torch.load(path, map_location="cpu", weights_only=False)
+    assert type(obj).__name__ == "DataParallel"
+    from regnet_for_3d_grasping_amd.score_network import ScoreNetwork
+    assert isinstance(obj.module, ScoreNetwork)
+    assert all(k.startswith("module.") for k in obj.state_dict())
+    model, resume = checkpoint.construct_scorenet(True, obj_class_num=2, model_path=path, map_location="cpu")
+    assert resume == 8                                  # utils.py:71: epoch in the file name + 1
+    _check_state(model)
+    fresh, resume0 = checkpoint.construct_scorenet(False, model_path=path)
+    assert resume0 == 0 and isinstance(fresh, ScoreNetwork)
+
+
+def test_reference_region_checkpoint_restores(tmp_path):
+    from regnet_for_3d_grasping_amd import checkpoint
+    path = _unzip("ckpt_region_7.model.gz", tmp_path)
+    model, resume = checkpoint.construct_rnet(True, True, 256, 64, 0.5, 0.06, 10, model_path=path, map_location="cpu")
+    assert resume == 8
+    _check_state(model)
+
+
+def test_saved_checkpoint_names_reference_class_paths(tmp_path):
+    """A checkpoint written here is laid out like the reference's: only ``multi_model.*`` (and torch) class paths."""
+    import pickletools
+    import zipfile
+    from regnet_for_3d_grasping_amd import checkpoint
+    from regnet_for_3d_grasping_amd.gripper_region_network import GripperRegionNetwork
+    net = GripperRegionNetwork(training=True, group_num=256, gripper_num=64, grasp_score_threshold=0.5, radius=0.06,
+                               reg_channel=10)
+    path = os.path.join(str(tmp_path), "region_0.model")
+    checkpoint.save_model(net, path)
+    assert GripperRegionNetwork.__module__ == "regnet_for_3d_grasping_amd.gripper_region_network"   # restored
+    with zipfile.ZipFile(path) as z:
+        data = z.read([n for n in z.namelist() if n.endswith("data.pkl")][0])
+    strings = [arg for op, arg, _ in pickletools.genops(data) if isinstance(arg, str)]
+    assert any(s.startswith("multi_model.gripper_region_network") for s in strings)
+    assert not any("regnet_for_3d_grasping_amd" in s for s in strings)
+    restored, resume = checkpoint.construct_rnet(True, True, 256, 64, 0.5, 0.06, 10, model_path=path, map_location="cpu")
+    assert resume == 1
+    for (k0, v0), (k1, v1) in zip(net.state_dict().items(), restored.state_dict().items()):
+        assert k0 == k1 and torch.equal(v0, v1)
