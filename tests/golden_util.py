@@ -119,3 +119,36 @@ def loss_inputs(seed, n=96, A=4):
 def meta_train():
     with open(os.path.join(GOLDEN, "s4_meta.json")) as f:
         return json.load(f)
+
+
+# ---- stage S5: dataset records (tests/golden/make_golden_dataset.py, tests/test_scoredataset_cpu.py) ----------
+# case -> (directory layout, split tag, data_seed, all_points_num)
+DATASET_CASES = {
+    "train": ("training", "train", 1, 256),
+    "validate": ("training", "validate", 1, 256),
+    "test": ("training", "test", 1, 512),
+    "eval_train": ("eval", "train", 3, 192),
+    "eval_heldout": ("eval", "validate", 3, 512),
+}
+DATASET_ITEMS = (0, 5, 11)
+
+
+def dataset_records(tmp):
+    """Writes the synthetic record trees and returns {'training': root, 'eval': root} (roots as handed to
+    ScoreDataset).  90 + 7 + 90 records of 150..400 points; deterministic."""
+    import os
+    import numpy as np
+    from regnet_for_3d_grasping_amd import scoredataset, synthetic
+    rng = np.random.default_rng(515)
+    roots = {"training": os.path.join(tmp, "data"), "eval": os.path.join(tmp, "eval_data")}
+    layout = (("data/training_data", 90), ("data/training_data_test", 7), ("eval_data", 90))
+    for sub, count in layout:
+        os.makedirs(os.path.join(tmp, sub))
+        for i in range(count):
+            n = int(rng.integers(150, 400))
+            scene = synthetic.make_scene(int(rng.integers(0, 1 << 30)), n)
+            label = (scene[:, 2] > 0.7525).astype(np.float32) * rng.integers(1, 9, n)
+            score = rng.uniform(0, 1.5, n) * (label > 0)
+            scoredataset.write_record(os.path.join(tmp, sub, "scene_%04d.p" % i), scene, score, label,
+                                      synthetic.make_grasp_labels(scene, i, every=5))
+    return roots
