@@ -180,6 +180,22 @@ int regnet_sa_layer12_f32(const float* feat, int64_t fb, int64_t fn, int64_t fc,
                           int64_t Kpad, const float* scale, const float* shift, float* C, int64_t ldc,
                           int64_t N, int relu, int pool_group, void* stream);
 
+/* regnet_sa_chain3_f32: a WHOLE narrow-input set-abstraction block in one kernel (pn2_utils/modules.py:210-246
+ * for the level-1 block of PointNet2Seg, pointnet2.py:40-42): gather [feat | xyz - centre] (Cf + 3 <= 8) ->
+ * layer 1 (W1 [C1][8], VALU) -> layer 2 (W2 packed [128][K2pad = 128]) -> layer 3 (W3 packed [C3pad][K3pad = 128],
+ * C3 % 32 == 0) -> max over the group's 64 neighbours -> out (B*M, ldo).  Layers 1 and 2 always apply their folded
+ * BN affine + ReLU, layer 3 its affine and ReLU if relu3.  The products are formed transposed (channels x points)
+ * so each layer's MFMA accumulator is the next layer's B operand: no activation is written to LDS or HBM.
+ * Supported: group == 64, C1 == C2 == 128; anything else returns REGNET_ERR_UNSUPPORTED (use the layer-wise
+ * entry points).  Same values as regnet_sa_layer12_f32 + regnet_mlp_layer_f32(pool) up to fp32 summation order. */
+int regnet_sa_chain3_f32(const float* feat, int64_t fb, int64_t fn, int64_t fc, int64_t Cf, const float* xyz,
+                         int64_t xb, int64_t xc, int64_t xn, const int64_t* nbr, const int64_t* ctr,
+                         int64_t B, int64_t M, int64_t group, const float* W1, const float* scale1,
+                         const float* shift1, int64_t C1, const float* W2, int64_t K2pad,
+                         const float* scale2, const float* shift2, int64_t C2, const float* W3,
+                         int64_t K3pad, const float* scale3, const float* shift3, int64_t C3, int relu3,
+                         float* out, int64_t ldo, void* stream);
+
 /* ---- set-abstraction layers 1+2 with layer 1 evaluated per SOURCE point ---------------------------
  * The first SharedMLP layer of a set-abstraction block (pn2_utils/modules.py:44-55: conv over
  * [xyz_j - xyz_c | feature_j]) is linear in the gathered row, so

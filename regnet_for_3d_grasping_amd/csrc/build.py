@@ -21,6 +21,7 @@ SOURCES = [
     ("region.hip", ["-ffp-contract=off"]),
     ("grid.hip", ["-ffp-contract=off"]),
     ("mlp.hip", []),
+    ("sa_chain.hip", []),
     ("np_random.hip", []),
 ]
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",

@@ -1,0 +1,260 @@
+// sa_chain.hip -- a whole narrow-input set-abstraction block (gather -> layer 1 -> layer 2 -> layer 3 -> max
+// over the 64 neighbours) in ONE kernel whose activations never leave the register file (gfx950).
+//
+// Reference behaviour restated (paths relative to /root/reference/multi_model/utils): QueryGrouper.forward
+// pn2_utils/modules.py:39-56 (group, xyz - centre, cat), SharedMLP = [1x1 conv -> BatchNorm -> ReLU]*
+// pn2_utils/nn/modules/mlp.py:55-114, max over K pn2_utils/modules.py:244-245 -- the level-1 block of
+// PointNet2Seg (pointnet2.py:40-42: 6 gathered inputs -> 128 -> 128 -> 256 over 5120 x 64 rows per scene).
+//
+// Why the products are computed TRANSPOSED.  v_mfma_f32_32x32x2_f32 computes D[32x32] += A[32x2] * B[2x32] with
+//   A: lane l supplies A[i = l & 31][k = l >> 5]       B: lane l supplies B[k = l >> 5][j = l & 31]
+//   D: element r of lane l is D[i = (r & 3) + 8 (r >> 2) + 4 (l >> 5)][j = l & 31].
+// With rows = output CHANNELS and columns = POINTS (D = W . X^T), the accumulator of one layer IS a valid B
+// operand of the next: register r of the layer-2 accumulator holds, in lane l, channel d0(r) + 4 (l >> 5) of
+// point l & 31 -- exactly "k = l >> 5 selects one of two channels, j = l & 31 the point".  The two channels of
+// such a step are d0 and d0 + 4 instead of consecutive ones; a dot product does not care, the A operand (the
+// next layer's weights) just reads the same two columns: element (r & 3) of the 16-byte chunk
+// W[e][32 dt + 8 (r >> 2) + 4 (l >> 5) ..], i.e. the same ds_read_b128 fragment pattern as mlp.hip.  So:
+//   layer 1 (<= 8 inputs)  VALU, per (point, channel), straight into the B operand of layer 2
+//   layer 2                64 k-steps x (4 channel tiles x 2 point tiles) MFMAs -> 128 accumulator VGPRs
+//   BN + ReLU              in place on those registers
+//   layer 3                per 32-channel output tile: 64 k-steps x 2 point tiles, B = the registers above
+//   max over 64 points     = over the 2 point tiles (in-register) and the 32 lanes of a half-wave (5 DPP steps)
+// A wave owns one neighbourhood (64 points); the (P x 128) activations of layers 1 and 2 (1.3 GB each per batch
+// of 8 scenes) are never written.  W2 stays in LDS for the life of the workgroup, W3 streams through a double
+// buffer one 32-channel tile at a time (the 8 waves of a workgroup share it, one barrier per tile).
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define CH_WAVES 8
+#define CH_THREADS (CH_WAVES * 64)
+#define CH_C 128            // width of layers 1 and 2
+#define CH_LD (CH_C + 4)    // LDS row stride: the 16-lane service groups of ds_read_b128 hit 64 distinct banks
+
+struct ChainArgs {
+  const float* feat; long long fb, fn, fc; int Cf;
+  const float* xyz; long long xb, xc, xn;
+  const long long* nbr;   // (groups, 64)
+  const long long* ctr;   // (groups)
+  long long groups, groups_per_scene;
+  const float* W1;        // [128][8]  columns [feat | rel xyz | 0]
+  const float* scale1; const float* shift1;
+  const float* W2;        // [128][128] row-major
+  const float* scale2; const float* shift2;
+  const float* W3;        // [C3][128] row-major, C3 % 32 == 0
+  const float* scale3; const float* shift3;
+  int C3, relu3;
+  float* out; long long ldo;   // (groups, C3)
+};
+
+#define DPP_MAX(v, CTRL, ROWMASK)                                                                          \
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v),           \
+                                                                     __builtin_bit_cast(int, v), CTRL,     \
+                                                                     ROWMASK, 0xf, false)))
+
+// max over the 32 lanes of each half-wave; valid in lanes 16..31 (lower half) and 48..63 (upper half)
+__device__ __forceinline__ float half_wave_max(float v) {
+  DPP_MAX(v, 0xB1, 0xf);    // quad_perm [1,0,3,2]
+  DPP_MAX(v, 0x4E, 0xf);    // quad_perm [2,3,0,1]
+  DPP_MAX(v, 0x141, 0xf);   // row_half_mirror
+  DPP_MAX(v, 0x140, 0xf);   // row_mirror: every lane of a 16-lane row now holds the row maximum
+  DPP_MAX(v, 0x142, 0xa);   // row_bcast15 into rows 1 and 3: max with the previous row's lane 15
+  return v;
+}
+
+__global__ __launch_bounds__(CH_THREADS, 2) void sa_chain_kernel(const ChainArgs p) {
+  __shared__ __attribute__((aligned(16))) float sW2[CH_C * CH_LD];
+  __shared__ __attribute__((aligned(16))) float sW3[2][32 * CH_LD];
+  __shared__ __attribute__((aligned(16))) float sW1[CH_C * 12];   // [c][w0..w7 | scale | shift | 0 0]
+  __shared__ __attribute__((aligned(16))) float sS2[CH_C], sT2[CH_C];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 31, fh = lane >> 5;
+
+  // ---- stage the weights -----------------------------------------------------------------------------------------
+  for (int i = tid; i < CH_C * (CH_C / 4); i += CH_THREADS) {
+    const float4 v = reinterpret_cast<const float4*>(p.W2)[i];
+    *reinterpret_cast<float4*>(&sW2[(i / (CH_C / 4)) * CH_LD + (i % (CH_C / 4)) * 4]) = v;
+  }
+  for (int c = tid; c < CH_C; c += CH_THREADS) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sW1[c * 12 + k] = p.W1[c * 8 + k];
+    sW1[c * 12 + 8] = p.scale1[c];
+    sW1[c * 12 + 9] = p.shift1[c];
+    sW1[c * 12 + 10] = 0.f;
+    sW1[c * 12 + 11] = 0.f;
+    sS2[c] = p.scale2[c];
+    sT2[c] = p.shift2[c];
+  }
+  // W3 tile: 32 rows x 128 floats = 1024 float4, two per thread
+  const int t_row0 = tid / (CH_C / 4), t_c4 = tid % (CH_C / 4);   // rows t_row0 and t_row0 + 16
+  float4 w3a = reinterpret_cast<const float4*>(p.W3)[tid];
+  float4 w3b = reinterpret_cast<const float4*>(p.W3)[tid + CH_THREADS];
+  *reinterpret_cast<float4*>(&sW3[0][t_row0 * CH_LD + t_c4 * 4]) = w3a;
+  *reinterpret_cast<float4*>(&sW3[0][(t_row0 + 16) * CH_LD + t_c4 * 4]) = w3b;
+
+  // ---- gather this wave's neighbourhood: lane -> point fr of point tile pt (both half-waves hold the same points)
+  const long long g = (long long)blockIdx.x * CH_WAVES + wave;
+  const bool valid = g < p.groups;
+  const long long gs = valid ? g : 0;
+  const long long b = gs / p.groups_per_scene;
+  const float* xb = p.xyz + b * p.xb;
+  const long long cj = p.ctr[gs];
+  const float cx = xb[cj * p.xn], cy = xb[p.xc + cj * p.xn], cz = xb[2 * p.xc + cj * p.xn];
+  float x[2][8];
+#pragma unroll
+  for (int pt = 0; pt < 2; ++pt) {
+    const long long j = p.nbr[gs * 64 + pt * 32 + fr];
+    const float rx = xb[j * p.xn] - cx, ry = xb[p.xc + j * p.xn] - cy, rz = xb[2 * p.xc + j * p.xn] - cz;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      float v = 0.f;
+      if (c < p.Cf) v = p.feat[b * p.fb + j * p.fn + (long long)c * p.fc];
+      else if (c == p.Cf) v = rx;
+      else if (c == p.Cf + 1) v = ry;
+      else if (c == p.Cf + 2) v = rz;
+      x[pt][c] = v;
+    }
+  }
+  __syncthreads();
+
+  // ---- layer 2 (layer 1 on the fly): acc2[dt][pt] = W2[32 dt .., :] . h1[:, 32 pt ..] ------------------------------
+  f32x16 acc2[4][2];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc2[dt][pt][r] = 0.f;
+#pragma unroll 2
+  for (int s = 0; s < CH_C / 8; ++s) {
+    float4 a[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) a[dt] = *reinterpret_cast<const float4*>(&sW2[(dt * 32 + fr) * CH_LD + 8 * s + 4 * fh]);
+    float h[2][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float* w = &sW1[(8 * s + 4 * fh + j) * 12];   // one address per half-wave: broadcast reads
+      const float4 w0 = *reinterpret_cast<const float4*>(w), w1 = *reinterpret_cast<const float4*>(w + 4);
+      const float2 st = *reinterpret_cast<const float2*>(w + 8);
+#pragma unroll
+      for (int pt = 0; pt < 2; ++pt) {
+        float v = w0.x * x[pt][0];
+        v += w0.y * x[pt][1]; v += w0.z * x[pt][2]; v += w0.w * x[pt][3];
+        v += w1.x * x[pt][4]; v += w1.y * x[pt][5]; v += w1.z * x[pt][6]; v += w1.w * x[pt][7];
+        h[pt][j] = fmaxf(v * st.x + st.y, 0.f);
+      }
+    }
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int pt = 0; pt < 2; ++pt) {
+        acc2[dt][pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[dt].x, h[pt][0], acc2[dt][pt], 0, 0, 0);
+        acc2[dt][pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[dt].y, h[pt][1], acc2[dt][pt], 0, 0, 0);
+        acc2[dt][pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[dt].z, h[pt][2], acc2[dt][pt], 0, 0, 0);
+        acc2[dt][pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[dt].w, h[pt][3], acc2[dt][pt], 0, 0, 0);
+      }
+  }
+  // ---- BN + ReLU of layer 2, in place: register r of lane l is channel 32 dt + (r & 3) + 8 (r >> 2) + 4 fh ---------
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 sc = *reinterpret_cast<const float4*>(&sS2[dt * 32 + 8 * q + 4 * fh]);
+      const float4 sh = *reinterpret_cast<const float4*>(&sT2[dt * 32 + 8 * q + 4 * fh]);
+#pragma unroll
+      for (int pt = 0; pt < 2; ++pt) {
+        acc2[dt][pt][4 * q + 0] = fmaxf(acc2[dt][pt][4 * q + 0] * sc.x + sh.x, 0.f);
+        acc2[dt][pt][4 * q + 1] = fmaxf(acc2[dt][pt][4 * q + 1] * sc.y + sh.y, 0.f);
+        acc2[dt][pt][4 * q + 2] = fmaxf(acc2[dt][pt][4 * q + 2] * sc.z + sh.z, 0.f);
+        acc2[dt][pt][4 * q + 3] = fmaxf(acc2[dt][pt][4 * q + 3] * sc.w + sh.w, 0.f);
+      }
+    }
+
+  // ---- layer 3, one 32-channel output tile at a time ------------------------------------------------------------------
+  const int tiles = p.C3 / 32;
+  float* orow = p.out + gs * p.ldo;
+  for (int et = 0; et < tiles; ++et) {
+    const int buf = et & 1;
+    if (et + 1 < tiles) {   // next W3 tile: registers now, LDS after this tile's MFMAs
+      w3a = reinterpret_cast<const float4*>(p.W3)[(et + 1) * 1024 + tid];
+      w3b = reinterpret_cast<const float4*>(p.W3)[(et + 1) * 1024 + tid + CH_THREADS];
+    }
+    f32x16 acc3[2];
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc3[pt][r] = 0.f;
+    const float* wt = &sW3[buf][fr * CH_LD + 4 * fh];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 a = *reinterpret_cast<const float4*>(wt + dt * 32 + 8 * q);
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) {
+          acc3[pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, acc2[dt][pt][4 * q + 0], acc3[pt], 0, 0, 0);
+          acc3[pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, acc2[dt][pt][4 * q + 1], acc3[pt], 0, 0, 0);
+          acc3[pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, acc2[dt][pt][4 * q + 2], acc3[pt], 0, 0, 0);
+          acc3[pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, acc2[dt][pt][4 * q + 3], acc3[pt], 0, 0, 0);
+        }
+      }
+    // BN (+ReLU), max over the two point tiles, then over the 32 lanes of the half-wave
+    float keep = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 sc = *reinterpret_cast<const float4*>(p.scale3 + et * 32 + 8 * q + 4 * fh);
+      const float4 sh = *reinterpret_cast<const float4*>(p.shift3 + et * 32 + 8 * q + 4 * fh);
+      const float scj[4] = {sc.x, sc.y, sc.z, sc.w}, shj[4] = {sh.x, sh.y, sh.z, sh.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float y0 = acc3[0][4 * q + j] * scj[j] + shj[j], y1 = acc3[1][4 * q + j] * scj[j] + shj[j];
+        float m = fmaxf(y0, y1);
+        if (p.relu3) m = fmaxf(m, 0.f);
+        m = half_wave_max(m);
+        keep = ((lane & 15) == 4 * q + j) ? m : keep;   // lane 16 + r (48 + r) keeps channel slot r
+      }
+    }
+    if ((lane & 16) && valid) {
+      const int r = lane & 15;
+      orow[et * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh] = keep;
+    }
+    if (et + 1 < tiles) {
+      *reinterpret_cast<float4*>(&sW3[buf ^ 1][t_row0 * CH_LD + t_c4 * 4]) = w3a;
+      *reinterpret_cast<float4*>(&sW3[buf ^ 1][(t_row0 + 16) * CH_LD + t_c4 * 4]) = w3b;
+    }
+    __syncthreads();
+  }
+}
+
+static bool aligned16c(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+extern "C" int regnet_sa_chain3_f32(const float* feat, int64_t fb, int64_t fn, int64_t fc, int64_t Cf, const float* xyz,
+                                    int64_t xb, int64_t xc, int64_t xn, const int64_t* nbr, const int64_t* ctr,
+                                    int64_t B, int64_t M, int64_t group, const float* W1, const float* scale1,
+                                    const float* shift1, int64_t C1, const float* W2, int64_t K2pad,
+                                    const float* scale2, const float* shift2, int64_t C2, const float* W3,
+                                    int64_t K3pad, const float* scale3, const float* shift3, int64_t C3, int relu3,
+                                    float* out, int64_t ldo, void* stream) {
+  if (B < 0 || M < 0 || Cf < 0 || C3 <= 0 || ldo < C3) return REGNET_ERR_SHAPE;
+  if (group != 64 || Cf + 3 > 8 || C1 != CH_C || C2 != CH_C || K2pad != CH_C || K3pad != CH_C || (C3 & 31))
+    return REGNET_ERR_UNSUPPORTED;
+  const long long groups = B * M;
+  if (groups == 0) return REGNET_OK;
+  if (!xyz || !nbr || !ctr || !W1 || !scale1 || !shift1 || !W2 || !scale2 || !shift2 || !W3 || !scale3 || !shift3 ||
+      !out || (Cf > 0 && !feat))
+    return REGNET_ERR_NULL;
+  if (!aligned16c(W2) || !aligned16c(W3) || !aligned16c(scale3) || !aligned16c(shift3)) return REGNET_ERR_SHAPE;
+  const long long blocks = (groups + CH_WAVES - 1) / CH_WAVES;
+  if (blocks >= (1ll << 31)) return REGNET_ERR_UNSUPPORTED;
+  ChainArgs a = {};
+  a.feat = Cf > 0 ? feat : nullptr; a.fb = fb; a.fn = fn; a.fc = fc; a.Cf = (int)Cf;
+  a.xyz = xyz; a.xb = xb; a.xc = xc; a.xn = xn;
+  a.nbr = (const long long*)nbr; a.ctr = (const long long*)ctr; a.groups = groups; a.groups_per_scene = M;
+  a.W1 = W1; a.scale1 = scale1; a.shift1 = shift1; a.W2 = W2; a.scale2 = scale2; a.shift2 = shift2;
+  a.W3 = W3; a.scale3 = scale3; a.shift3 = shift3; a.C3 = (int)C3; a.relu3 = relu3;
+  a.out = out; a.ldo = ldo;
+  hipLaunchKernelGGL(sa_chain_kernel, dim3((unsigned)blocks), dim3(CH_THREADS), 0, as_stream(stream), a);
+  REGNET_LAUNCH_CHECK();
+  return REGNET_OK;
+}

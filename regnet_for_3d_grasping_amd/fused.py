@@ -17,6 +17,7 @@ import torch
 from . import _lib, pn2_ext
 
 ENABLED = True
+CHAIN3 = True   # level-1 set-abstraction block as one register-chained kernel (see sa_features)
 PREMUL = True   # evaluate the first layer of wide set-abstraction blocks per source point (see sa_features)
 
 _check = _lib.check
@@ -159,6 +160,21 @@ def sa_premul_layer(U, V, nbr, layer, B, Nsrc, M, group, pool_group=0):
     return out
 
 
+def sa_chain3(feature, xyz, nbr, ctr, l1, l2, l3, B, M, group):
+    """Whole narrow-input SA block (gather, three layers, max over the neighbours) in one kernel; -> (B*M, C3)."""
+    out = torch.empty((B * M, l3.N), dtype=torch.float32, device=xyz.device)
+    if feature is None:
+        fptr, fb, fn, fc, Cf = None, 0, 0, 0, 0
+    else:
+        fptr, (fb, fc, fn), Cf = feature.data_ptr(), feature.stride(), feature.size(1)
+    _check(_L.regnet_sa_chain3_f32(fptr, fb, fn, fc, Cf, xyz.data_ptr(), *xyz.stride(), nbr.data_ptr(), ctr.data_ptr(),
+                                   B, M, group, l1.W8.data_ptr(), l1.scale.data_ptr(), l1.shift.data_ptr(), l1.N,
+                                   l2.W.data_ptr(), l2.Kpad, l2.scale.data_ptr(), l2.shift.data_ptr(), l2.N,
+                                   l3.W.data_ptr(), l3.Kpad, l3.scale.data_ptr(), l3.shift.data_ptr(), l3.N, l3.relu,
+                                   out.data_ptr(), out.stride(0), _stream(xyz)), "sa_chain3")
+    return out
+
+
 def interp_concat(sparse_cl, idx, dist2, eps, dense_feature, B, Nd):
     """sparse_cl: (B,Ns,Cs) channels-last contiguous; dense_feature (B,Cd,Nd) any strides or None.
     Returns the (B*Nd, round_up(Cs+Cd,4)) channels-last operand of the first FP layer and its valid width."""
@@ -251,6 +267,9 @@ TIMED_OPS = {
     "sa_layer1": lambda feature, xyz, nbr, ctr, layer, B, M, group: _flop_meta(B * M * group, layer.K, layer.N),
     "sa_premul_layer": lambda U, V, nbr, layer, B, Nsrc, M, group, pool_group=0:
         _flop_meta(B * M * group, layer.K, layer.N),
+    "sa_chain3": lambda feature, xyz, nbr, ctr, l1, l2, l3, B, M, group:
+        "P%d K%d N%d flop%d" % (B * M * group, l3.K, l3.N,
+                                2 * B * M * group * (l1.K * l1.N + l2.K * l2.N + l3.K * l3.N)),
     "sa_layer12": lambda feature, xyz, nbr, ctr, first, layer, B, M, group, pool_group=0:
         "P%d K%d N%d flop%d" % (B * M * group, layer.K, layer.N,
                                 2 * B * M * group * (layer.K * layer.N + first.K * first.N)),
@@ -302,6 +321,11 @@ def sa_features(module, xyz, feature, geo):
     if layers[0].W8 is not None and layers[0].N % 16 == 0 and layers[0].relu:
         # narrow gathered input (level 1: rgb + xyz): layer 1 is recomputed on the VALU inside layer 2's
         # operand load, its (P x C1) activation never exists in HBM
+        if (CHAIN3 and len(layers) == 3 and layers[0].N == 128 and layers[1].N == 128 and layers[1].relu
+                and layers[2].N % 32 == 0):
+            # the whole block in one kernel, activations in registers (csrc/sa_chain.hip)
+            pooled = sa_chain3(feature, xyz, geo["nbr"], geo["ctr"], layers[0], layers[1], layers[2], B, M, K)
+            return geo["new_xyz"], pooled.view(B, M, -1).transpose(1, 2)
         if len(layers) == 2:
             pooled = sa_layer12(feature, xyz, geo["nbr"], geo["ctr"], layers[0], layers[1], B, M, K, pool_group=K)
             return geo["new_xyz"], pooled.view(B, M, -1).transpose(1, 2)

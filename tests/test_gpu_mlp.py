@@ -265,3 +265,37 @@ def test_fp_premultiplied_first_layer_equals_interpolate_then_multiply(Cd, monke
         up0 = fp(dense_xyz, sparse_xyz, dense_feat, sparse_feat)
     torch.testing.assert_close(up2, up1, rtol=1e-5, atol=2e-5)
     torch.testing.assert_close(up2, up0, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("M,C3,Cf", [(37, 256, 3), (8, 64, 0), (3, 160, 5)])
+def test_sa_chain3_whole_block_in_registers(M, C3, Cf):
+    """Register-chained level-1 SA block == gather + three (conv, BN, ReLU) layers + max over the 64 neighbours."""
+    from regnet_for_3d_grasping_amd import fused
+    B, N, G = 2, 900, 64
+    rng = np.random.default_rng(31)
+    pc = torch.from_numpy(rng.normal(size=(B, N, 3 + max(Cf, 1))).astype(np.float32)).to(DEV)
+    xyz = pc[:, :, :3].permute(0, 2, 1)
+    feat = pc[:, :, 3:3 + Cf].permute(0, 2, 1) if Cf else None
+    nbr = torch.from_numpy(rng.integers(0, N, (B, M, G))).to(DEV)
+    ctr = torch.from_numpy(rng.integers(0, N, (B, M))).to(DEV)
+    conv1, bn1, _ = _layer(128, Cf + 3, seed=41)
+    conv2, bn2, layer2 = _layer(128, 128, seed=42)
+    conv3, bn3, layer3 = _layer(C3, 128, seed=43)
+    order = torch.cat([torch.arange(3, 3 + Cf), torch.arange(3)]).to(DEV)
+    first = fused._pack(conv1, bn1, True, order)
+    got = fused.sa_chain3(feat, xyz, nbr, ctr, first, layer2, layer3, B, M, G)
+    idx = nbr.view(B, 1, M * G)
+    gx = torch.gather(xyz, 2, idx.expand(B, 3, -1)).view(B, 3, M, G)
+    gx = gx - torch.gather(xyz, 2, ctr[:, None, :].expand(B, 3, M)).unsqueeze(-1)
+    parts = [gx]
+    if Cf:
+        parts.append(torch.gather(feat, 2, idx.expand(B, Cf, -1)).view(B, Cf, M, G))
+    grouped = torch.cat(parts, 1).permute(0, 2, 3, 1).reshape(B * M * G, Cf + 3)
+    h = _ref(_ref(grouped, conv1, bn1, True).float(), conv2, bn2, True).float()
+    want = _ref(h, conv3, bn3, True).view(B * M, G, C3).max(dim=1)[0]
+    assert tuple(got.shape) == (B * M, C3)
+    torch.testing.assert_close(got.double(), want, rtol=1e-5, atol=5e-5)
+    # and against the layer-wise kernels
+    h2 = fused.sa_layer12(feat, xyz, nbr, ctr, first, layer2, B, M, G)
+    want2 = fused.mlp_layer(h2, layer3.K, layer3, B * M * G, pool_group=G)
+    torch.testing.assert_close(got, want2, rtol=1e-5, atol=3e-5)
