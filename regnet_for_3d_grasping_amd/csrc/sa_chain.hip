@@ -18,8 +18,9 @@
 //   layer 1 (<= 8 inputs)  VALU, per (point, channel), straight into the B operand of layer 2
 //   layer 2                64 k-steps x (4 channel tiles x 2 point tiles) MFMAs -> 128 accumulator VGPRs
 //   BN + ReLU              in place on those registers
-//   layer 3                per 32-channel output tile: 64 k-steps x 2 point tiles, B = the registers above
-//   max over 64 points     = over the 2 point tiles (in-register) and the 32 lanes of a half-wave (5 DPP steps)
+//   layer 3                per 32-channel output tile: 64 k-steps x 2 point tiles, the registers above as the A operand
+//                          (A and B fragments have the same lane layout), so D3 is [point][channel] again and the
+//   max over 64 points     is a max over accumulator registers + one cross-half exchange
 // A wave owns one neighbourhood (64 points); the (P x 128) activations of layers 1 and 2 (1.3 GB each per batch
 // of 8 scenes) are never written.  W2 stays in LDS for the life of the workgroup, W3 streams through a double
 // buffer one 32-channel tile at a time (the 8 waves of a workgroup share it, one barrier per tile).
@@ -47,21 +48,6 @@ struct ChainArgs {
   int C3, relu3;
   float* out; long long ldo;   // (groups, C3)
 };
-
-#define DPP_MAX(v, CTRL, ROWMASK)                                                                          \
-  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v),           \
-                                                                     __builtin_bit_cast(int, v), CTRL,     \
-                                                                     ROWMASK, 0xf, false)))
-
-// max over the 32 lanes of each half-wave; valid in lanes 16..31 (lower half) and 48..63 (upper half)
-__device__ __forceinline__ float half_wave_max(float v) {
-  DPP_MAX(v, 0xB1, 0xf);    // quad_perm [1,0,3,2]
-  DPP_MAX(v, 0x4E, 0xf);    // quad_perm [2,3,0,1]
-  DPP_MAX(v, 0x141, 0xf);   // row_half_mirror
-  DPP_MAX(v, 0x140, 0xf);   // row_mirror: every lane of a 16-lane row now holds the row maximum
-  DPP_MAX(v, 0x142, 0xa);   // row_bcast15 into rows 1 and 3: max with the previous row's lane 15
-  return v;
-}
 
 __global__ __launch_bounds__(CH_THREADS, 2) void sa_chain_kernel(const ChainArgs p) {
   __shared__ __attribute__((aligned(16))) float sW2[CH_C * CH_LD];
@@ -186,38 +172,34 @@ __global__ __launch_bounds__(CH_THREADS, 2) void sa_chain_kernel(const ChainArgs
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc3[pt][r] = 0.f;
     const float* wt = &sW3[buf][fr * CH_LD + 4 * fh];
+    // Layer 3 is formed the other way round, D3[point][channel] = h2 . W3^T: the layer-2 registers serve as the A
+    // operand just as well (lane -> point l & 31, k -> channel pair), and the max over the points then is a max over
+    // the accumulator's registers + one cross-half exchange instead of a 32-lane reduction per register (which cost
+    // 6 % of the kernel: VALU work is not free next to MFMAs, scripts/ablate/chain_ablate -DCH_ABLATE).
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const float4 a = *reinterpret_cast<const float4*>(wt + dt * 32 + 8 * q);
+        const float4 w = *reinterpret_cast<const float4*>(wt + dt * 32 + 8 * q);
 #pragma unroll
         for (int pt = 0; pt < 2; ++pt) {
-          acc3[pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, acc2[dt][pt][4 * q + 0], acc3[pt], 0, 0, 0);
-          acc3[pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, acc2[dt][pt][4 * q + 1], acc3[pt], 0, 0, 0);
-          acc3[pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, acc2[dt][pt][4 * q + 2], acc3[pt], 0, 0, 0);
-          acc3[pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, acc2[dt][pt][4 * q + 3], acc3[pt], 0, 0, 0);
+          acc3[pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(acc2[dt][pt][4 * q + 0], w.x, acc3[pt], 0, 0, 0);
+          acc3[pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(acc2[dt][pt][4 * q + 1], w.y, acc3[pt], 0, 0, 0);
+          acc3[pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(acc2[dt][pt][4 * q + 2], w.z, acc3[pt], 0, 0, 0);
+          acc3[pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(acc2[dt][pt][4 * q + 3], w.w, acc3[pt], 0, 0, 0);
         }
       }
-    // BN (+ReLU), max over the two point tiles, then over the 32 lanes of the half-wave
-    float keep = 0.f;
+    // lane l holds channel et*32 + (l & 31) of 16 points per point tile (+ the other 16 in lane l ^ 32)
+    {
+      const float sc = p.scale3[et * 32 + fr], sh = p.shift3[et * 32 + fr];
+      float m = -__builtin_inff();
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float4 sc = *reinterpret_cast<const float4*>(p.scale3 + et * 32 + 8 * q + 4 * fh);
-      const float4 sh = *reinterpret_cast<const float4*>(p.shift3 + et * 32 + 8 * q + 4 * fh);
-      const float scj[4] = {sc.x, sc.y, sc.z, sc.w}, shj[4] = {sh.x, sh.y, sh.z, sh.w};
+      for (int pt = 0; pt < 2; ++pt)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float y0 = acc3[0][4 * q + j] * scj[j] + shj[j], y1 = acc3[1][4 * q + j] * scj[j] + shj[j];
-        float m = fmaxf(y0, y1);
-        if (p.relu3) m = fmaxf(m, 0.f);
-        m = half_wave_max(m);
-        keep = ((lane & 15) == 4 * q + j) ? m : keep;   // lane 16 + r (48 + r) keeps channel slot r
-      }
-    }
-    if ((lane & 16) && valid) {
-      const int r = lane & 15;
-      orow[et * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh] = keep;
+        for (int r = 0; r < 16; ++r) m = fmaxf(m, acc3[pt][r] * sc + sh);
+      if (p.relu3) m = fmaxf(m, 0.f);
+      m = fmaxf(m, __shfl_xor(m, 32, 64));
+      if (fh == 0 && valid) orow[et * 32 + fr] = m;
     }
     if (et + 1 < tiles) {
       *reinterpret_cast<float4*>(&sW3[buf ^ 1][t_row0 * CH_LD + t_c4 * 4]) = w3a;
