@@ -129,7 +129,7 @@ def algorithmic_work(name, meta):
 
 # host wrapper -> device kernel it launches (for grouping launches into kernel families)
 KERNEL_OF = {"mlp_layer": "mlp_gemm_kernel", "sa_layer1": "mlp_gemm_kernel", "sa_layer12": "mlp_gemm_kernel",
-             "sa_premul_layer": "mlp_gemm_kernel", "sa_chain3": "mlp_gemm_kernel",
+             "sa_premul_layer": "mlp_gemm_kernel", "sa_chain3": "sa_chain_kernel",
              "farthest_point_sample": "fps_kernel", "ball_query": "ball_query_kernel",
              "point_search": "three_nn_kernel", "radius_candidates": "radius_group_kernel",
              "box_candidates": "box_crop_kernel", "gather_max": "gather_max_kernel"}
@@ -279,7 +279,9 @@ def main():
                                    ", %d-pt synthetic scenes, batch=%d per GPU, eval" % (args.points, args.batch),
                        "points": args.points, "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                        "parallelism": "scene-sharded x%d (no data-path collective)" % world,
-                       "scorenet_gflop_per_scene": SCORENET_GFLOP_PER_SCENE.get(args.points)},
+                       "scorenet_gflop_per_scene": SCORENET_GFLOP_PER_SCENE.get(args.points),
+                       "executed_gflop_per_scene": round(sum(f["units"] for f in fam.values() if f["bound"] == "mfma")
+                                                         / 1e9 / max(args.steps * args.batch, 1), 2)},
             "roofline": roofline,
             "mlp_tflops": round(SCORENET_GFLOP_PER_SCENE.get(args.points, 0.0) * total_scenes / world / dt / 1e3, 3),
             "kernels": kernels[:40],
