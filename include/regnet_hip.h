@@ -156,6 +156,16 @@ int regnet_mlp_layer_f32(const float* A, int64_t lda, int64_t Ka, const float* W
                          const float* scale, const float* shift, float* C, int64_t ldc, int64_t P,
                          int64_t N, int relu, int pool_group, void* stream);
 
+/* regnet_mlp_layer_splitk_f32: regnet_mlp_layer_f32 (no pooling) for SKINNY problems -- few rows, long K, e.g. the
+ * grasp-region heads on B*64 regions (pointnet2.py:165-197, :227-254), where a 128-row tile grid cannot fill the
+ * chip.  The K range is cut into `ksplit` slices multiplied by different workgroups; the slices' raw partial sums go
+ * to `workspace` (regnet_mlp_splitk_workspace_bytes(P, N, ksplit) bytes, 16-byte aligned) and a second kernel adds
+ * them IN INDEX ORDER and applies the affine + ReLU, so the result is deterministic.  1 <= ksplit <= Kpad / 16.   */
+int64_t regnet_mlp_splitk_workspace_bytes(int64_t P, int64_t N, int64_t ksplit);
+int regnet_mlp_layer_splitk_f32(const float* A, int64_t lda, int64_t Ka, const float* W, int64_t Kpad,
+                                const float* scale, const float* shift, float* C, int64_t ldc, int64_t P,
+                                int64_t N, int relu, int64_t ksplit, void* workspace, void* stream);
+
 /* regnet_sa_layer1_f32: first SharedMLP layer of a set-abstraction block with the grouping fused
  * into the operand load (no (B,C,M,K) tensor is materialised; reference: QueryGrouper.forward,
  * modules.py:39-56).  Row p = (b, m, k): A[p] = [feat[b, nbr[p], 0:Cf] | xyz[b,:,nbr[p]] -

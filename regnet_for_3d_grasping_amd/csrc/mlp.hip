@@ -87,15 +87,17 @@ struct MlpArgs {
   long long P;
   int N;
   int relu;
+  int ksplit;      // > 1: deterministic split-K for skinny problems -- workgroup (tile, s) multiplies k-slice s and writes its RAW
+                   // partial sums to C + s * P * ldc (C is then a workspace); splitk_finish_kernel adds the slices in order
   int wide_store;  // C rows 16-byte aligned (ldc % 4 == 0): interior tiles use the LDS-transposed dwordx4 epilogue
 };
 
-__device__ __forceinline__ void xcd_tile(int& tm, int& tn, int tiles_m, int tiles_n) {
+__device__ __forceinline__ void xcd_tile(unsigned vblock, int& tm, int& tn, int tiles_m, int tiles_n) {
   // Blocks are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8, a speed-only
   // observation).  Remap so that consecutive blocks ON ONE XCD walk the N-tiles of the same
   // M-tile: the A tile is then fetched into one L2 instead of eight.
   const long long total = (long long)tiles_m * tiles_n;
-  const long long L = blockIdx.x;
+  const long long L = vblock;
   const long long q = total / 8, r = total % 8;
   const long long xcd = L % 8, s = L / 8;
   const long long t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + s;
@@ -131,7 +133,8 @@ __global__ __launch_bounds__(MLP_THREADS, AMODE == 2 ? 3 : MLP_MIN_WAVES) void m
   const int tiles_n = (p.N + BN - 1) / BN;
   const int tiles_m = (int)((p.P + BM - 1) / BM);
   int tm, tn;
-  xcd_tile(tm, tn, tiles_m, tiles_n);
+  const int ks = p.ksplit > 1 ? (int)(blockIdx.x % (unsigned)p.ksplit) : 0;
+  xcd_tile(p.ksplit > 1 ? blockIdx.x / (unsigned)p.ksplit : blockIdx.x, tm, tn, tiles_m, tiles_n);
   const long long row0 = (long long)tm * BM;
   const int col0 = tn * BN;
 
@@ -280,13 +283,18 @@ __global__ __launch_bounds__(MLP_THREADS, AMODE == 2 ? 3 : MLP_MIN_WAVES) void m
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-  const int KT = p.Kpad / BK;
-  LOAD_TILE(0);
-  STORE_TILE(0, 0);
+  const int KT_all = p.Kpad / BK;
+  const int kt_per = p.ksplit > 1 ? (KT_all + p.ksplit - 1) / p.ksplit : KT_all;
+  const int kt0 = ks * kt_per;
+  const int KT = min(KT_all, kt0 + kt_per);   // this workgroup's k-tiles are [kt0, KT) (empty slices write zeros)
+  if (kt0 < KT) {
+    LOAD_TILE(kt0 * BK);
+    STORE_TILE(0, kt0 * BK);
+  }
   __syncthreads();
   const int fr = lane & 31, fh = lane >> 5;
-  for (int kt = 0; kt < KT; ++kt) {
-    const int buf = kt & 1;
+  for (int kt = kt0; kt < KT; ++kt) {
+    const int buf = (kt - kt0) & 1;
     if (kt + 1 < KT && !(MLP_ABLATE == 1 || MLP_ABLATE == 2 || MLP_ABLATE == 4)) LOAD_TILE((kt + 1) * BK);
 #pragma unroll
     for (int kk = 0; kk < BK / 8; ++kk) {
@@ -325,12 +333,15 @@ __global__ __launch_bounds__(MLP_THREADS, AMODE == 2 ? 3 : MLP_MIN_WAVES) void m
 
   // ---- epilogue: folded BN affine + ReLU (+ max over the 64 rows of a group) -------------
   // C/D layout of v_mfma_f32_32x32x2_f32: element r of lane l is row (r&3) + 8*(r>>2) + 4*(l>>5), col l&31.
+  const bool splitk = !POOL && p.ksplit > 1;
+  float* const Cout = splitk ? p.C + (long long)ks * p.P * p.ldc : p.C;
+  const int relu = splitk ? 0 : p.relu;
 #pragma unroll
   for (int ni = 0; ni < 2; ++ni) {
     const int col = col0 + wc * 64 + ni * 32 + fr;
     const bool col_ok = col < p.N;
-    const float s = col_ok ? p.scale[col] : 0.f;
-    const float t = col_ok ? p.shift[col] : 0.f;
+    const float s = splitk ? 1.f : (col_ok ? p.scale[col] : 0.f);
+    const float t = splitk ? 0.f : (col_ok ? p.shift[col] : 0.f);
     if (POOL) {
       float m = -__builtin_inff();
 #pragma unroll
@@ -338,7 +349,7 @@ __global__ __launch_bounds__(MLP_THREADS, AMODE == 2 ? 3 : MLP_MIN_WAVES) void m
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           float y = acc[mi][ni][r] * s + t;
-          if (p.relu) y = fmaxf(y, 0.f);
+          if (relu) y = fmaxf(y, 0.f);
           m = fmaxf(m, y);
         }
       m = fmaxf(m, __shfl_xor(m, 32, 64));
@@ -349,7 +360,7 @@ __global__ __launch_bounds__(MLP_THREADS, AMODE == 2 ? 3 : MLP_MIN_WAVES) void m
       // lane half).  Walk them with pointer increments (no 64-bit multiply per store); interior
       // tiles take the unguarded path so the 32 stores of an accumulator issue back to back.
       const long long first_row = row0 + wr * 64 + 4 * fh;
-      float* cp = p.C + first_row * p.ldc + col;
+      float* cp = Cout + first_row * p.ldc + col;
       const long long ld = p.ldc;
       const bool interior = (row0 + BM <= p.P) && (col0 + BN <= p.N);
       if (interior && p.wide_store) {
@@ -361,10 +372,10 @@ __global__ __launch_bounds__(MLP_THREADS, AMODE == 2 ? 3 : MLP_MIN_WAVES) void m
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             float y = acc[mi][ni][r] * s + t;
-            if (p.relu) y = fmaxf(y, 0.f);
+            if (relu) y = fmaxf(y, 0.f);
             stage[(mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh) * 36 + fr] = y;
           }
-        float* cbase = p.C + (row0 + wr * 64) * p.ldc + (col0 + wc * 64 + ni * 32);
+        float* cbase = Cout + (row0 + wr * 64) * p.ldc + (col0 + wc * 64 + ni * 32);
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
           const int row = it * 8 + (lane >> 3), q4 = lane & 7;
@@ -377,7 +388,7 @@ __global__ __launch_bounds__(MLP_THREADS, AMODE == 2 ? 3 : MLP_MIN_WAVES) void m
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             float y = acc[mi][ni][r] * s + t;
-            if (p.relu) y = fmaxf(y, 0.f);
+            if (relu) y = fmaxf(y, 0.f);
             *cp = y;
             cp += ((r & 3) == 3) ? 5 * ld : ld;   // after rows 3, 11, 19, 27 jump to the next block of four
           }
@@ -389,7 +400,7 @@ __global__ __launch_bounds__(MLP_THREADS, AMODE == 2 ? 3 : MLP_MIN_WAVES) void m
           for (int r = 0; r < 16; ++r) {
             const long long row = first_row + mi * 32 + (r & 3) + 8 * (r >> 2);
             float y = acc[mi][ni][r] * s + t;
-            if (p.relu) y = fmaxf(y, 0.f);
+            if (relu) y = fmaxf(y, 0.f);
             if (col_ok && row < p.P) *cp = y;
             cp += ((r & 3) == 3) ? 5 * ld : ld;
           }
@@ -405,7 +416,8 @@ static int launch_gemm(const MlpArgs& a_in, int amode, bool pool, hipStream_t st
   const long long tiles = ((a.P + BM - 1) / BM) * ((a.N + BN - 1) / BN);
   if (tiles <= 0) return REGNET_OK;
   if (tiles >= (1ll << 31)) return REGNET_ERR_UNSUPPORTED;
-  dim3 grid((unsigned)tiles), block(MLP_THREADS);
+  if (a.ksplit > 1 && (pool || tiles * a.ksplit >= (1ll << 31))) return REGNET_ERR_UNSUPPORTED;
+  dim3 grid((unsigned)(a.ksplit > 1 ? tiles * a.ksplit : tiles)), block(MLP_THREADS);
   if (amode == 3 && pool) hipLaunchKernelGGL((mlp_gemm_kernel<3, true>), grid, block, 0, st, a);
   else if (amode == 3) hipLaunchKernelGGL((mlp_gemm_kernel<3, false>), grid, block, 0, st, a);
   else if (amode == 2 && pool) hipLaunchKernelGGL((mlp_gemm_kernel<2, true>), grid, block, 0, st, a);
@@ -433,6 +445,56 @@ extern "C" int regnet_mlp_layer_f32(const float* A, int64_t lda, int64_t Ka, con
   a.W = W; a.Kpad = (int)Kpad; a.scale = scale; a.shift = shift;
   a.C = C; a.ldc = ldc; a.P = P; a.N = (int)N; a.relu = relu; a.group = 64; a.rows_per_scene = 1;
   return launch_gemm(a, 0, pool_group != 0, as_stream(stream));
+}
+
+// out[p][n] = relu(scale[n] * (sum_s part[s][p][n]) + shift[n]); slices added in index order (deterministic).
+__global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restrict__ part, int S, long long P, int N,
+                                                            long long ldp, const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, int relu,
+                                                            float* __restrict__ C, long long ldc) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;   // one output element per thread
+  if (i >= P * N) return;
+  const long long row = i / N;
+  const int col = (int)(i - row * N);
+  float acc = part[row * ldp + col];
+  for (int s = 1; s < S; ++s) acc += part[(long long)s * P * ldp + row * ldp + col];
+  float y = acc * scale[col] + shift[col];
+  if (relu) y = fmaxf(y, 0.f);
+  C[row * ldc + col] = y;
+}
+
+extern "C" int64_t regnet_mlp_splitk_workspace_bytes(int64_t P, int64_t N, int64_t ksplit) {
+  return ksplit > 1 ? ksplit * P * ((N + 3) / 4 * 4) * (int64_t)sizeof(float) : 0;
+}
+
+extern "C" int regnet_mlp_layer_splitk_f32(const float* A, int64_t lda, int64_t Ka, const float* W, int64_t Kpad,
+                                           const float* scale, const float* shift, float* C, int64_t ldc, int64_t P,
+                                           int64_t N, int relu, int64_t ksplit, void* workspace, void* stream) {
+  if (P < 0 || N <= 0 || Ka < 0 || Kpad <= 0 || Kpad % BK || Ka > Kpad || (Ka & 3) || (lda & 3) || ksplit < 1)
+    return REGNET_ERR_SHAPE;
+  if (ksplit > Kpad / BK || P * N >= (1ll << 40)) return REGNET_ERR_UNSUPPORTED;
+  if (P == 0) return REGNET_OK;
+  if (!A || !W || !scale || !shift || !C || (ksplit > 1 && !workspace)) return REGNET_ERR_NULL;
+  if (!aligned16(A) || !aligned16(W) || (ksplit > 1 && !aligned16(workspace))) return REGNET_ERR_SHAPE;
+  MlpArgs a = {};
+  a.A = A; a.lda = lda; a.Ka = (int)Ka;
+  a.W = W; a.Kpad = (int)Kpad; a.scale = scale; a.shift = shift;
+  a.P = P; a.N = (int)N; a.relu = relu; a.group = 64; a.rows_per_scene = 1;
+  if (ksplit == 1) {
+    a.C = C; a.ldc = ldc;
+    return launch_gemm(a, 0, false, as_stream(stream));
+  }
+  const long long ldp = (N + 3) / 4 * 4;
+  a.C = (float*)workspace; a.ldc = ldp; a.ksplit = (int)ksplit;
+  int rc = launch_gemm(a, 0, false, as_stream(stream));
+  if (rc) return rc;
+  const long long blocks = (P * N + 255) / 256;
+  if (blocks >= (1ll << 31)) return REGNET_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(splitk_finish_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream),
+                     (const float*)workspace, (int)ksplit, (long long)P, (int)N, ldp, scale, shift, relu, C,
+                     (long long)ldc);
+  REGNET_LAUNCH_CHECK();
+  return REGNET_OK;
 }
 
 extern "C" int regnet_sa_layer1_f32(const float* feat, int64_t fb, int64_t fn, int64_t fc, int64_t Cf,

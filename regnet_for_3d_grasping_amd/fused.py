@@ -18,6 +18,7 @@ from . import _lib, pn2_ext
 
 ENABLED = True
 CHAIN3 = True   # level-1 set-abstraction block as one register-chained kernel (see sa_features)
+SPLITK_MAX_ROWS = 1024   # at most this many rows: the GEMM is "skinny" and is split along K (see mlp_layer)
 PREMUL = True   # evaluate the first layer of wide set-abstraction blocks per source point (see sa_features)
 
 _check = _lib.check
@@ -96,6 +97,19 @@ def mlp_layer(A, Ka, layer, P, pool_group=0):
     """A: channels-last (P, lda) float32 buffer whose first Ka columns are valid."""
     rows = P // pool_group if pool_group else P
     out = torch.empty((rows, layer.N), dtype=torch.float32, device=A.device)
+    if not pool_group and P <= SPLITK_MAX_ROWS and layer.Kpad >= 128:
+        # skinny problem (the region heads: B*64 rows): a 128-row tile grid cannot fill the chip, so cut K into
+        # slices of >= 64 that run on different workgroups (deterministic: added in order by a second kernel)
+        tiles = ((P + 127) // 128) * ((layer.N + 127) // 128)
+        ksplit = max(1, min(layer.Kpad // 64, 256 // max(tiles, 1)))
+        if ksplit > 1:
+            ws = torch.empty((_L.regnet_mlp_splitk_workspace_bytes(P, layer.N, ksplit),), dtype=torch.uint8,
+                             device=A.device)
+            _check(_L.regnet_mlp_layer_splitk_f32(A.data_ptr(), A.stride(0), Ka, layer.W.data_ptr(), layer.Kpad,
+                                                  layer.scale.data_ptr(), layer.shift.data_ptr(), out.data_ptr(),
+                                                  out.stride(0), P, layer.N, layer.relu, ksplit, ws.data_ptr(),
+                                                  _stream(A)), "mlp_layer_splitk")
+            return out
     _check(_L.regnet_mlp_layer_f32(A.data_ptr(), A.stride(0), Ka, layer.W.data_ptr(), layer.Kpad,
                                    layer.scale.data_ptr(), layer.shift.data_ptr(), out.data_ptr(), out.stride(0), P,
                                    layer.N, layer.relu, pool_group, _stream(A)), "mlp_layer")

@@ -299,3 +299,22 @@ def test_sa_chain3_whole_block_in_registers(M, C3, Cf):
     h2 = fused.sa_layer12(feat, xyz, nbr, ctr, first, layer2, B, M, G)
     want2 = fused.mlp_layer(h2, layer3.K, layer3, B * M * G, pool_group=G)
     torch.testing.assert_close(got, want2, rtol=1e-5, atol=3e-5)
+
+
+@pytest.mark.parametrize("P,K,N", [(512, 1024, 256), (512, 256, 1024), (300, 128, 40), (64, 1536, 4), (1000, 516, 130)])
+def test_mlp_layer_split_k_is_exact_and_deterministic(P, K, N, monkeypatch):
+    """Skinny GEMMs take the split-K path: same values as the fp64 reference, bit-identical from run to run, and
+    within fp32 round-off of the un-split kernel."""
+    from regnet_for_3d_grasping_amd import fused
+    conv, bn, layer = _layer(N, K, seed=P + N)
+    A = torch.randn(P, (K + 3) // 4 * 4, device=DEV)
+    A[:, K:] = 0
+    Ka = A.size(1)
+    got = fused.mlp_layer(A, Ka, layer, P)
+    again = fused.mlp_layer(A, Ka, layer, P)
+    assert torch.equal(got, again)
+    want = _ref(A[:, :K], conv, bn, True)
+    torch.testing.assert_close(got.double(), want, rtol=1e-5, atol=2e-5)
+    monkeypatch.setattr(fused, "SPLITK_MAX_ROWS", 0)
+    plain = fused.mlp_layer(A, Ka, layer, P)
+    torch.testing.assert_close(got, plain, rtol=1e-5, atol=1e-5)
