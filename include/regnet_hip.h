@@ -196,11 +196,16 @@ int regnet_sa_layer12_f32(const float* feat, int64_t fb, int64_t fn, int64_t fc,
  * C3 % 32 == 0) -> max over the group's 64 neighbours -> out (B*M, ldo).  Layers 1 and 2 always apply their folded
  * BN affine + ReLU, layer 3 its affine and ReLU if relu3.  The products are formed transposed (channels x points)
  * so each layer's MFMA accumulator is the next layer's B operand: no activation is written to LDS or HBM.
+ * `count` (B*M int64, optional): the ball query's member counts -- slots >= count of a neighbourhood repeat slot 0
+ * (regnet_ball_query_f32), so a neighbourhood with <= 32 members needs only its first 32 slots and half the MFMAs.
+ * `order` (B*M int64, optional): a permutation of the neighbourhoods giving the order in which workgroups (8
+ * neighbourhoods each) take them; sorting small neighbourhoods together lets whole workgroups finish early.
  * Supported: group == 64, C1 == C2 == 128; anything else returns REGNET_ERR_UNSUPPORTED (use the layer-wise
  * entry points).  Same values as regnet_sa_layer12_f32 + regnet_mlp_layer_f32(pool) up to fp32 summation order. */
 int regnet_sa_chain3_f32(const float* feat, int64_t fb, int64_t fn, int64_t fc, int64_t Cf, const float* xyz,
                          int64_t xb, int64_t xc, int64_t xn, const int64_t* nbr, const int64_t* ctr,
-                         int64_t B, int64_t M, int64_t group, const float* W1, const float* scale1,
+                         const int64_t* count, const int64_t* order, int64_t B, int64_t M, int64_t group,
+                         const float* W1, const float* scale1,
                          const float* shift1, int64_t C1, const float* W2, int64_t K2pad,
                          const float* scale2, const float* shift2, int64_t C2, const float* W3,
                          int64_t K3pad, const float* scale3, const float* shift3, int64_t C3, int relu3,

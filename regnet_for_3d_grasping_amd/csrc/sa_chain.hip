@@ -38,6 +38,8 @@ struct ChainArgs {
   const float* xyz; long long xb, xc, xn;
   const long long* nbr;   // (groups, 64)
   const long long* ctr;   // (groups)
+  const long long* count; // (groups) members per neighbourhood (slots >= count repeat slot 0), or NULL
+  const long long* order; // (groups) the order in which the workgroups take the neighbourhoods, or NULL
   long long groups, groups_per_scene;
   const float* W1;        // [128][8]  columns [feat | rel xyz | 0]
   const float* scale1; const float* shift1;
@@ -48,6 +50,121 @@ struct ChainArgs {
   int C3, relu3;
   float* out; long long ldo;   // (groups, C3)
 };
+
+// Layers 2 and 3 + pooling of one neighbourhood per wave, for NPT = 1 or 2 tiles of 32 points.  A neighbourhood with
+// at most 32 members fills only the first tile: its slots 32..63 are copies of slot 0 (the ball query pads with the
+// first hit), which cannot change a maximum, so the second tile's MFMAs are skipped altogether.  Both instantiations
+// execute the same barriers (one per W3 tile), so waves of one workgroup may take different ones.
+template <int NPT>
+__device__ __forceinline__ void chain_group(const ChainArgs& p, const float* __restrict__ sW2, float (*sW3)[32 * CH_LD],
+                                            const float* __restrict__ sW1, const float* __restrict__ sS2,
+                                            const float* __restrict__ sT2, const float (&x)[2][8], long long gs, bool valid,
+                                            float4 w3a, float4 w3b, int tid, int lane, int fr, int fh, int t_row0,
+                                            int t_c4) {
+  // ---- layer 2 (layer 1 on the fly): acc2[dt][pt] = W2[32 dt .., :] . h1[:, 32 pt ..] ------------------------------
+  f32x16 acc2[4][NPT];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+    for (int pt = 0; pt < NPT; ++pt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc2[dt][pt][r] = 0.f;
+#pragma unroll 2
+  for (int s = 0; s < CH_C / 8; ++s) {
+    float4 a[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) a[dt] = *reinterpret_cast<const float4*>(&sW2[(dt * 32 + fr) * CH_LD + 8 * s + 4 * fh]);
+    float h[NPT][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float* w = &sW1[(8 * s + 4 * fh + j) * 12];   // one address per half-wave: broadcast reads
+      const float4 w0 = *reinterpret_cast<const float4*>(w), w1 = *reinterpret_cast<const float4*>(w + 4);
+      const float2 st = *reinterpret_cast<const float2*>(w + 8);
+#pragma unroll
+      for (int pt = 0; pt < NPT; ++pt) {
+        float v = w0.x * x[pt][0];
+        v += w0.y * x[pt][1]; v += w0.z * x[pt][2]; v += w0.w * x[pt][3];
+        v += w1.x * x[pt][4]; v += w1.y * x[pt][5]; v += w1.z * x[pt][6]; v += w1.w * x[pt][7];
+        h[pt][j] = fmaxf(v * st.x + st.y, 0.f);
+      }
+    }
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int pt = 0; pt < NPT; ++pt) {
+        acc2[dt][pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[dt].x, h[pt][0], acc2[dt][pt], 0, 0, 0);
+        acc2[dt][pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[dt].y, h[pt][1], acc2[dt][pt], 0, 0, 0);
+        acc2[dt][pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[dt].z, h[pt][2], acc2[dt][pt], 0, 0, 0);
+        acc2[dt][pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[dt].w, h[pt][3], acc2[dt][pt], 0, 0, 0);
+      }
+  }
+  // ---- BN + ReLU of layer 2, in place: register r of lane l is channel 32 dt + (r & 3) + 8 (r >> 2) + 4 fh ---------
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 sc = *reinterpret_cast<const float4*>(&sS2[dt * 32 + 8 * q + 4 * fh]);
+      const float4 sh = *reinterpret_cast<const float4*>(&sT2[dt * 32 + 8 * q + 4 * fh]);
+#pragma unroll
+      for (int pt = 0; pt < NPT; ++pt) {
+        acc2[dt][pt][4 * q + 0] = fmaxf(acc2[dt][pt][4 * q + 0] * sc.x + sh.x, 0.f);
+        acc2[dt][pt][4 * q + 1] = fmaxf(acc2[dt][pt][4 * q + 1] * sc.y + sh.y, 0.f);
+        acc2[dt][pt][4 * q + 2] = fmaxf(acc2[dt][pt][4 * q + 2] * sc.z + sh.z, 0.f);
+        acc2[dt][pt][4 * q + 3] = fmaxf(acc2[dt][pt][4 * q + 3] * sc.w + sh.w, 0.f);
+      }
+    }
+
+  // ---- layer 3, one 32-channel output tile at a time ------------------------------------------------------------------
+  const int tiles = p.C3 / 32;
+  float* orow = p.out + gs * p.ldo;
+  for (int et = 0; et < tiles; ++et) {
+    const int buf = et & 1;
+    if (et + 1 < tiles) {   // next W3 tile: registers now, LDS after this tile's MFMAs
+      w3a = reinterpret_cast<const float4*>(p.W3)[(et + 1) * 1024 + tid];
+      w3b = reinterpret_cast<const float4*>(p.W3)[(et + 1) * 1024 + tid + CH_THREADS];
+    }
+    f32x16 acc3[NPT];
+#pragma unroll
+    for (int pt = 0; pt < NPT; ++pt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc3[pt][r] = 0.f;
+    const float* wt = &sW3[buf][fr * CH_LD + 4 * fh];
+    // Layer 3 is formed the other way round, D3[point][channel] = h2 . W3^T: the layer-2 registers serve as the A
+    // operand just as well (lane -> point l & 31, k -> channel pair), and the max over the points then is a max over
+    // the accumulator's registers + one cross-half exchange instead of a 32-lane reduction per register (which cost
+    // 6 % of the kernel: VALU work is not free next to MFMAs, scripts/ablate/chain_ablate -DCH_ABLATE).
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 w = *reinterpret_cast<const float4*>(wt + dt * 32 + 8 * q);
+#pragma unroll
+        for (int pt = 0; pt < NPT; ++pt) {
+          acc3[pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(acc2[dt][pt][4 * q + 0], w.x, acc3[pt], 0, 0, 0);
+          acc3[pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(acc2[dt][pt][4 * q + 1], w.y, acc3[pt], 0, 0, 0);
+          acc3[pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(acc2[dt][pt][4 * q + 2], w.z, acc3[pt], 0, 0, 0);
+          acc3[pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(acc2[dt][pt][4 * q + 3], w.w, acc3[pt], 0, 0, 0);
+        }
+      }
+    // lane l holds channel et*32 + (l & 31) of 16 points per point tile (+ the other 16 in lane l ^ 32)
+    {
+      const float sc = p.scale3[et * 32 + fr], sh = p.shift3[et * 32 + fr];
+      float m = -__builtin_inff();
+#pragma unroll
+      for (int pt = 0; pt < NPT; ++pt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) m = fmaxf(m, acc3[pt][r] * sc + sh);
+      if (p.relu3) m = fmaxf(m, 0.f);
+      m = fmaxf(m, __shfl_xor(m, 32, 64));
+      if (fh == 0 && valid) orow[et * 32 + fr] = m;
+    }
+    if (et + 1 < tiles) {
+      *reinterpret_cast<float4*>(&sW3[buf ^ 1][t_row0 * CH_LD + t_c4 * 4]) = w3a;
+      *reinterpret_cast<float4*>(&sW3[buf ^ 1][(t_row0 + 16) * CH_LD + t_c4 * 4]) = w3b;
+    }
+    __syncthreads();
+  }
+}
 
 __global__ __launch_bounds__(CH_THREADS, 2) void sa_chain_kernel(const ChainArgs p) {
   __shared__ __attribute__((aligned(16))) float sW2[CH_C * CH_LD];
@@ -80,9 +197,10 @@ __global__ __launch_bounds__(CH_THREADS, 2) void sa_chain_kernel(const ChainArgs
   *reinterpret_cast<float4*>(&sW3[0][(t_row0 + 16) * CH_LD + t_c4 * 4]) = w3b;
 
   // ---- gather this wave's neighbourhood: lane -> point fr of point tile pt (both half-waves hold the same points)
-  const long long g = (long long)blockIdx.x * CH_WAVES + wave;
-  const bool valid = g < p.groups;
-  const long long gs = valid ? g : 0;
+  const long long slot = (long long)blockIdx.x * CH_WAVES + wave;
+  const bool valid = slot < p.groups;
+  const long long gs = valid ? (p.order ? p.order[slot] : slot) : 0;
+  const int npt = (p.count && p.count[gs] <= 32) ? 1 : 2;   // wave-uniform
   const long long b = gs / p.groups_per_scene;
   const float* xb = p.xyz + b * p.xb;
   const long long cj = p.ctr[gs];
@@ -104,116 +222,16 @@ __global__ __launch_bounds__(CH_THREADS, 2) void sa_chain_kernel(const ChainArgs
   }
   __syncthreads();
 
-  // ---- layer 2 (layer 1 on the fly): acc2[dt][pt] = W2[32 dt .., :] . h1[:, 32 pt ..] ------------------------------
-  f32x16 acc2[4][2];
-#pragma unroll
-  for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-    for (int pt = 0; pt < 2; ++pt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc2[dt][pt][r] = 0.f;
-#pragma unroll 2
-  for (int s = 0; s < CH_C / 8; ++s) {
-    float4 a[4];
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) a[dt] = *reinterpret_cast<const float4*>(&sW2[(dt * 32 + fr) * CH_LD + 8 * s + 4 * fh]);
-    float h[2][4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float* w = &sW1[(8 * s + 4 * fh + j) * 12];   // one address per half-wave: broadcast reads
-      const float4 w0 = *reinterpret_cast<const float4*>(w), w1 = *reinterpret_cast<const float4*>(w + 4);
-      const float2 st = *reinterpret_cast<const float2*>(w + 8);
-#pragma unroll
-      for (int pt = 0; pt < 2; ++pt) {
-        float v = w0.x * x[pt][0];
-        v += w0.y * x[pt][1]; v += w0.z * x[pt][2]; v += w0.w * x[pt][3];
-        v += w1.x * x[pt][4]; v += w1.y * x[pt][5]; v += w1.z * x[pt][6]; v += w1.w * x[pt][7];
-        h[pt][j] = fmaxf(v * st.x + st.y, 0.f);
-      }
-    }
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-      for (int pt = 0; pt < 2; ++pt) {
-        acc2[dt][pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[dt].x, h[pt][0], acc2[dt][pt], 0, 0, 0);
-        acc2[dt][pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[dt].y, h[pt][1], acc2[dt][pt], 0, 0, 0);
-        acc2[dt][pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[dt].z, h[pt][2], acc2[dt][pt], 0, 0, 0);
-        acc2[dt][pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[dt].w, h[pt][3], acc2[dt][pt], 0, 0, 0);
-      }
-  }
-  // ---- BN + ReLU of layer 2, in place: register r of lane l is channel 32 dt + (r & 3) + 8 (r >> 2) + 4 fh ---------
-#pragma unroll
-  for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float4 sc = *reinterpret_cast<const float4*>(&sS2[dt * 32 + 8 * q + 4 * fh]);
-      const float4 sh = *reinterpret_cast<const float4*>(&sT2[dt * 32 + 8 * q + 4 * fh]);
-#pragma unroll
-      for (int pt = 0; pt < 2; ++pt) {
-        acc2[dt][pt][4 * q + 0] = fmaxf(acc2[dt][pt][4 * q + 0] * sc.x + sh.x, 0.f);
-        acc2[dt][pt][4 * q + 1] = fmaxf(acc2[dt][pt][4 * q + 1] * sc.y + sh.y, 0.f);
-        acc2[dt][pt][4 * q + 2] = fmaxf(acc2[dt][pt][4 * q + 2] * sc.z + sh.z, 0.f);
-        acc2[dt][pt][4 * q + 3] = fmaxf(acc2[dt][pt][4 * q + 3] * sc.w + sh.w, 0.f);
-      }
-    }
-
-  // ---- layer 3, one 32-channel output tile at a time ------------------------------------------------------------------
-  const int tiles = p.C3 / 32;
-  float* orow = p.out + gs * p.ldo;
-  for (int et = 0; et < tiles; ++et) {
-    const int buf = et & 1;
-    if (et + 1 < tiles) {   // next W3 tile: registers now, LDS after this tile's MFMAs
-      w3a = reinterpret_cast<const float4*>(p.W3)[(et + 1) * 1024 + tid];
-      w3b = reinterpret_cast<const float4*>(p.W3)[(et + 1) * 1024 + tid + CH_THREADS];
-    }
-    f32x16 acc3[2];
-#pragma unroll
-    for (int pt = 0; pt < 2; ++pt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc3[pt][r] = 0.f;
-    const float* wt = &sW3[buf][fr * CH_LD + 4 * fh];
-    // Layer 3 is formed the other way round, D3[point][channel] = h2 . W3^T: the layer-2 registers serve as the A
-    // operand just as well (lane -> point l & 31, k -> channel pair), and the max over the points then is a max over
-    // the accumulator's registers + one cross-half exchange instead of a 32-lane reduction per register (which cost
-    // 6 % of the kernel: VALU work is not free next to MFMAs, scripts/ablate/chain_ablate -DCH_ABLATE).
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float4 w = *reinterpret_cast<const float4*>(wt + dt * 32 + 8 * q);
-#pragma unroll
-        for (int pt = 0; pt < 2; ++pt) {
-          acc3[pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(acc2[dt][pt][4 * q + 0], w.x, acc3[pt], 0, 0, 0);
-          acc3[pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(acc2[dt][pt][4 * q + 1], w.y, acc3[pt], 0, 0, 0);
-          acc3[pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(acc2[dt][pt][4 * q + 2], w.z, acc3[pt], 0, 0, 0);
-          acc3[pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(acc2[dt][pt][4 * q + 3], w.w, acc3[pt], 0, 0, 0);
-        }
-      }
-    // lane l holds channel et*32 + (l & 31) of 16 points per point tile (+ the other 16 in lane l ^ 32)
-    {
-      const float sc = p.scale3[et * 32 + fr], sh = p.shift3[et * 32 + fr];
-      float m = -__builtin_inff();
-#pragma unroll
-      for (int pt = 0; pt < 2; ++pt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) m = fmaxf(m, acc3[pt][r] * sc + sh);
-      if (p.relu3) m = fmaxf(m, 0.f);
-      m = fmaxf(m, __shfl_xor(m, 32, 64));
-      if (fh == 0 && valid) orow[et * 32 + fr] = m;
-    }
-    if (et + 1 < tiles) {
-      *reinterpret_cast<float4*>(&sW3[buf ^ 1][t_row0 * CH_LD + t_c4 * 4]) = w3a;
-      *reinterpret_cast<float4*>(&sW3[buf ^ 1][(t_row0 + 16) * CH_LD + t_c4 * 4]) = w3b;
-    }
-    __syncthreads();
-  }
+  if (npt == 2) chain_group<2>(p, sW2, sW3, sW1, sS2, sT2, x, gs, valid, w3a, w3b, tid, lane, fr, fh, t_row0, t_c4);
+  else chain_group<1>(p, sW2, sW3, sW1, sS2, sT2, x, gs, valid, w3a, w3b, tid, lane, fr, fh, t_row0, t_c4);
 }
 
 static bool aligned16c(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 extern "C" int regnet_sa_chain3_f32(const float* feat, int64_t fb, int64_t fn, int64_t fc, int64_t Cf, const float* xyz,
                                     int64_t xb, int64_t xc, int64_t xn, const int64_t* nbr, const int64_t* ctr,
-                                    int64_t B, int64_t M, int64_t group, const float* W1, const float* scale1,
+                                    const int64_t* count, const int64_t* order, int64_t B, int64_t M, int64_t group,
+                                    const float* W1, const float* scale1,
                                     const float* shift1, int64_t C1, const float* W2, int64_t K2pad,
                                     const float* scale2, const float* shift2, int64_t C2, const float* W3,
                                     int64_t K3pad, const float* scale3, const float* shift3, int64_t C3, int relu3,
@@ -233,6 +251,7 @@ extern "C" int regnet_sa_chain3_f32(const float* feat, int64_t fb, int64_t fn, i
   a.feat = Cf > 0 ? feat : nullptr; a.fb = fb; a.fn = fn; a.fc = fc; a.Cf = (int)Cf;
   a.xyz = xyz; a.xb = xb; a.xc = xc; a.xn = xn;
   a.nbr = (const long long*)nbr; a.ctr = (const long long*)ctr; a.groups = groups; a.groups_per_scene = M;
+  a.count = (const long long*)count; a.order = (const long long*)order;
   a.W1 = W1; a.scale1 = scale1; a.shift1 = shift1; a.W2 = W2; a.scale2 = scale2; a.shift2 = shift2;
   a.W3 = W3; a.scale3 = scale3; a.shift3 = shift3; a.C3 = (int)C3; a.relu3 = relu3;
   a.out = out; a.ldo = ldo;

@@ -174,15 +174,18 @@ def sa_premul_layer(U, V, nbr, layer, B, Nsrc, M, group, pool_group=0):
     return out
 
 
-def sa_chain3(feature, xyz, nbr, ctr, l1, l2, l3, B, M, group):
-    """Whole narrow-input SA block (gather, three layers, max over the neighbours) in one kernel; -> (B*M, C3)."""
+def sa_chain3(feature, xyz, nbr, ctr, l1, l2, l3, B, M, group, count=None, order=None):
+    """Whole narrow-input SA block (gather, three layers, max over the neighbours) in one kernel; -> (B*M, C3).
+    ``count`` (B,M) int64: members per neighbourhood (half the work for those with <= 32); ``order`` (B*M,) int64:
+    processing order of the neighbourhoods (small ones together)."""
     out = torch.empty((B * M, l3.N), dtype=torch.float32, device=xyz.device)
     if feature is None:
         fptr, fb, fn, fc, Cf = None, 0, 0, 0, 0
     else:
         fptr, (fb, fc, fn), Cf = feature.data_ptr(), feature.stride(), feature.size(1)
     _check(_L.regnet_sa_chain3_f32(fptr, fb, fn, fc, Cf, xyz.data_ptr(), *xyz.stride(), nbr.data_ptr(), ctr.data_ptr(),
-                                   B, M, group, l1.W8.data_ptr(), l1.scale.data_ptr(), l1.shift.data_ptr(), l1.N,
+                                   None if count is None else count.data_ptr(),
+                                   None if order is None else order.data_ptr(), B, M, group, l1.W8.data_ptr(), l1.scale.data_ptr(), l1.shift.data_ptr(), l1.N,
                                    l2.W.data_ptr(), l2.Kpad, l2.scale.data_ptr(), l2.shift.data_ptr(), l2.N,
                                    l3.W.data_ptr(), l3.Kpad, l3.scale.data_ptr(), l3.shift.data_ptr(), l3.N, l3.relu,
                                    out.data_ptr(), out.stride(0), _stream(xyz)), "sa_chain3")
@@ -281,7 +284,7 @@ TIMED_OPS = {
     "sa_layer1": lambda feature, xyz, nbr, ctr, layer, B, M, group: _flop_meta(B * M * group, layer.K, layer.N),
     "sa_premul_layer": lambda U, V, nbr, layer, B, Nsrc, M, group, pool_group=0:
         _flop_meta(B * M * group, layer.K, layer.N),
-    "sa_chain3": lambda feature, xyz, nbr, ctr, l1, l2, l3, B, M, group:
+    "sa_chain3": lambda feature, xyz, nbr, ctr, l1, l2, l3, B, M, group, count=None, order=None:
         "P%d K%d N%d flop%d" % (B * M * group, l3.K, l3.N,
                                 2 * B * M * group * (l1.K * l1.N + l2.K * l2.N + l3.K * l3.N)),
     "sa_layer12": lambda feature, xyz, nbr, ctr, first, layer, B, M, group, pool_group=0:
@@ -309,8 +312,14 @@ def sa_group(module, xyz, ctr):
     """Centroid gather + ball query given the sampled indices (modules.py:41, :238-239)."""
     B, M = ctr.shape
     new_xyz = torch.gather(xyz, 2, ctr[:, None, :].expand(B, 3, M))
-    nbr, _ = pn2_ext.ball_query(xyz, new_xyz, module.grouper.radius, module.grouper.num_neighbours)
-    return {"ctr": ctr, "new_xyz": new_xyz, "nbr": nbr}
+    nbr, count = pn2_ext.ball_query(xyz, new_xyz, module.grouper.radius, module.grouper.num_neighbours)
+    geo = {"ctr": ctr, "new_xyz": new_xyz, "nbr": nbr}
+    if CHAIN3 and module.grouper.num_neighbours == 64:
+        # for the register-chained block: neighbourhoods with <= 32 members first (they cost half), so that whole
+        # workgroups are of one kind; computed here, in the geometry stage, off the matrix cores' critical path
+        geo["count"] = count
+        geo["order"] = torch.argsort((count.view(-1) > 32).to(torch.uint8), stable=True)
+    return geo
 
 
 def sa_geometry(module, xyz, ctr=None):
@@ -338,7 +347,8 @@ def sa_features(module, xyz, feature, geo):
         if (CHAIN3 and len(layers) == 3 and layers[0].N == 128 and layers[1].N == 128 and layers[1].relu
                 and layers[2].N % 32 == 0):
             # the whole block in one kernel, activations in registers (csrc/sa_chain.hip)
-            pooled = sa_chain3(feature, xyz, geo["nbr"], geo["ctr"], layers[0], layers[1], layers[2], B, M, K)
+            pooled = sa_chain3(feature, xyz, geo["nbr"], geo["ctr"], layers[0], layers[1], layers[2], B, M, K,
+                               geo.get("count"), geo.get("order"))
             return geo["new_xyz"], pooled.view(B, M, -1).transpose(1, 2)
         if len(layers) == 2:
             pooled = sa_layer12(feature, xyz, geo["nbr"], geo["ctr"], layers[0], layers[1], B, M, K, pool_group=K)

@@ -30,7 +30,7 @@ int main() {
   hipMemcpy(dc, ctr.data(), ctr.size() * 8, hipMemcpyHostToDevice);
   // pc is (B,N,6): xyz = columns 0..2 (strides N*6, 1, 6), rgb = columns 3..5
   auto run = [&]() {
-    return regnet_sa_chain3_f32(pc + 3, N * 6, 6, 1, 3, pc, N * 6, 1, 6, (const int64_t*)dn, (const int64_t*)dc, B, M, G, W1, sc,
+    return regnet_sa_chain3_f32(pc + 3, N * 6, 6, 1, 3, pc, N * 6, 1, 6, (const int64_t*)dn, (const int64_t*)dc, nullptr, nullptr, B, M, G, W1, sc,
                                 sh, 128, W2, 128, sc + 128, sh + 128, 128, W3, 128, sc + 256, sh + 256, 256, 1, out, 256,
                                 nullptr);
   };

@@ -283,7 +283,15 @@ def test_sa_chain3_whole_block_in_registers(M, C3, Cf):
     conv3, bn3, layer3 = _layer(C3, 128, seed=43)
     order = torch.cat([torch.arange(3, 3 + Cf), torch.arange(3)]).to(DEV)
     first = fused._pack(conv1, bn1, True, order)
-    got = fused.sa_chain3(feat, xyz, nbr, ctr, first, layer2, layer3, B, M, G)
+    # ball-query style padding: a neighbourhood with `count` members repeats slot 0 behind them
+    count = torch.from_numpy(rng.integers(1, G + 1, (B, M))).to(DEV)
+    count[0, 0], count[-1, -1] = 32, 33
+    slot = torch.arange(G, device=DEV).view(1, 1, G)
+    nbr = torch.where(slot < count.unsqueeze(-1), nbr, nbr[:, :, :1].expand(B, M, G)).contiguous()
+    order = torch.argsort((count.view(-1) > 32).to(torch.uint8), stable=True)
+    got = fused.sa_chain3(feat, xyz, nbr, ctr, first, layer2, layer3, B, M, G, count, order)
+    plain = fused.sa_chain3(feat, xyz, nbr, ctr, first, layer2, layer3, B, M, G)
+    assert torch.equal(got, plain)     # skipping the all-padding point tile and reordering change nothing
     idx = nbr.view(B, 1, M * G)
     gx = torch.gather(xyz, 2, idx.expand(B, 3, -1)).view(B, 3, M, G)
     gx = gx - torch.gather(xyz, 2, ctr[:, None, :].expand(B, 3, M)).unsqueeze(-1)
