@@ -21,7 +21,8 @@ SOURCES = [
     ("region.hip", ["-ffp-contract=off"]),
     ("grid.hip", ["-ffp-contract=off"]),
     ("mlp.hip", []),
-    ("sa_chain.hip", ["-fno-slp-vectorize"]),  # SLP turns the layer-1 FMAs into v_pk_mul + separate adds
+    ("sa_chain.hip", ["-fno-slp-vectorize"]),
+    ("sa_chain2.hip", ["-fno-slp-vectorize"]),  # SLP turns the layer-1 FMAs into v_pk_mul + separate adds
     ("np_random.hip", []),
 ]
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
