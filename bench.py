@@ -36,8 +36,9 @@ SCORENET_GFLOP_PER_SCENE = {25600: 148.27, 51200: 180.20}
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200,
+                    help="timed steps (each timed run starts from an idle pipeline: its ~20 ms fill + drain is inside the timed region)")
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=8, help="scenes per GPU per step (configs[2]: 8)")
     ap.add_argument("--points", type=int, default=25600)
     ap.add_argument("--cpu-scenes", type=int, default=4, help="scenes timed for cpu_baseline (0 = skip)")

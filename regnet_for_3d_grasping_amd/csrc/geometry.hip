@@ -436,6 +436,120 @@ __global__ __launch_bounds__(T) void fps_streaming_kernel(const float* __restric
   }
 }
 
+// Scenes too large for one CU's register file (25 600 < N <= 102 400): G = 2..4 workgroups per scene, each keeping an
+// interleaved share of the points resident exactly like fps_resident_kernel (workgroup h holds j = (s G + h) T + tid, so a
+// thread's points still share one reference lane and its slot order is the reference's order), plus one exchange per round
+// through a few words of global memory: every workgroup publishes its local (maximum, tie-break key) as ONE 64-bit word
+//   [ distance bits : 32 | round tag : 15 | 0x1ffff - compact key : 17 ]
+// in slot [scene][round & 1][h] and polls the others' slots until their tag is this round's; the largest word wins
+// (largest distance, then smallest key).  Double buffering by round parity is enough: a workgroup can only run one
+// round ahead of the slowest.  The workgroups of a scene are co-resident by construction (a launch needs G B <= #CUs
+// whole CUs) and are mapped to one XCD when B % 8 == 0 so the words stay in one L2.  ~4 us per round instead of the
+// streaming kernel's 27 us.  A poll budget turns a (never observed) lost partner into garbage output instead of a hang.
+__device__ __forceinline__ unsigned fps_compact_key(unsigned key, int rb_log2) {   // order-preserving, < 2^17 for N < 2^17
+  const unsigned hi_mask = ~(0xffffffffu >> rb_log2);
+  return ((key & hi_mask) >> (32 - 17)) | (key & ~hi_mask);   // reversed lane -> bits [17-rb, 17), j / RB below
+}
+__device__ __forceinline__ unsigned fps_expand_key(unsigned ckey, int rb_log2) {
+  const unsigned lo_mask = (1u << (17 - rb_log2)) - 1u;
+  return ((ckey & ~lo_mask) << (32 - 17)) | (ckey & lo_mask);
+}
+
+template <int PPT>
+__global__ __launch_bounds__(1024) void fps_multi_kernel(const float* __restrict__ xyz, int64_t sb, int64_t sc, int64_t sn,
+                                                         int N, int M, int rb_log2, int G, int B, int Bpad,
+                                                         unsigned long long* __restrict__ slots,
+                                                         int64_t* __restrict__ index) {
+  constexpr int T = 1024, W = T / 64, WP = W;
+  __shared__ __attribute__((aligned(16))) float part[2][WP];
+  __shared__ unsigned win_key[2];
+  __shared__ unsigned long long xchg[4];
+  const int tid = threadIdx.x;
+  const int b = (int)(blockIdx.x % (unsigned)Bpad), h = (int)(blockIdx.x / (unsigned)Bpad);
+  if (b >= B) return;
+  const float* base = xyz + (int64_t)b * sb;
+  int64_t* out = index + (int64_t)b * M;
+  unsigned long long* my_slots = slots + (int64_t)b * 8;   // [parity][h], h < 4
+
+  float px[PPT], py[PPT], pz[PPT], dist[PPT];
+#pragma unroll
+  for (int s = 0; s < PPT; ++s) {
+    const int j = (s * G + h) * T + tid;
+    if (j < N) {
+      px[s] = base[(int64_t)j * sn];
+      py[s] = base[sc + (int64_t)j * sn];
+      pz[s] = base[2 * sc + (int64_t)j * sn];
+      dist[s] = __builtin_inff();
+    } else {
+      px[s] = py[s] = pz[s] = 0.f;
+      dist[s] = -1.f;
+    }
+  }
+  if (tid < 2 * WP) (&part[0][0])[tid] = 0.f;
+  if (tid < 2) win_key[tid] = 0xffffffffu;
+  if (tid == 0 && h == 0) out[0] = 0;
+  __syncthreads();
+  int cur = 0;
+  for (int i = 1; i < M; ++i) {
+    const int buf = i & 1;
+    const float cx = base[(int64_t)cur * sn];
+    const float cy = base[sc + (int64_t)cur * sn];
+    const float cz = base[2 * sc + (int64_t)cur * sn];
+    float tmax = 0.f;
+#pragma unroll
+    for (int s = 0; s < PPT; ++s) {
+      const float nd = vmin_f32(dist[s], sqdist3(px[s], py[s], pz[s], cx, cy, cz));
+      dist[s] = nd;
+      tmax = fmaxf(tmax, nd);
+    }
+    const float wmax = wave_max_f32(tmax);
+    if ((tid & 63) == 0) part[buf][tid >> 6] = wmax;
+    if (tid == 0) win_key[buf ^ 1] = 0xffffffffu;
+    __syncthreads();
+    float mx = 0.f;
+#pragma unroll
+    for (int w4 = 0; w4 < WP / 4; ++w4) {
+      const float4 q = *reinterpret_cast<const float4*>(&part[buf][w4 * 4]);
+      mx = fmaxf(fmaxf(mx, fmaxf(q.x, q.y)), fmaxf(q.z, q.w));
+    }
+    if (mx > 0.f && tmax == mx) {
+      int best_s = 0;
+#pragma unroll
+      for (int s = PPT - 1; s >= 0; --s)
+        if (dist[s] == mx) best_s = s;
+      atomicMin(&win_key[buf], fps_key((best_s * G + h) * T + tid, rb_log2));
+    }
+    __syncthreads();
+    // ---- exchange with the other workgroups of this scene -------------------------------------------------------------
+    const unsigned tag = (unsigned)i & 0x7fffu;
+    if (tid == 0) {
+      const unsigned key = win_key[buf];
+      const unsigned inv = key == 0xffffffffu ? 0u : 0x1ffffu - fps_compact_key(key, rb_log2);
+      const unsigned long long word = ((unsigned long long)__float_as_uint(mx) << 32) | ((unsigned long long)tag << 17) | inv;
+      xchg[h] = word;
+      __hip_atomic_store(&my_slots[buf * 4 + h], word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else if (tid >= 64 && tid < 64 + G && tid - 64 != h) {   // one lane of ANOTHER wave per partner: inside one wave
+      const int o = tid - 64;                                  // the poll branch could be scheduled ahead of the store
+      unsigned long long wv = 0;
+      int budget = 1 << 22;
+      do {
+        wv = __hip_atomic_load(&my_slots[buf * 4 + o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned)((wv >> 17) & 0x7fffu) == tag) break;
+        __builtin_amdgcn_s_sleep(1);
+      } while (--budget > 0);
+      xchg[o] = wv;
+    }
+    __syncthreads();
+    unsigned long long best = xchg[0];
+    for (int o = 1; o < G; ++o) best = xchg[o] > best ? xchg[o] : best;
+    const unsigned inv = (unsigned)(best & 0x1ffffull);
+    if ((best >> 32) != 0ull && inv != 0u)   // else: every distance is 0 -> repeat cur
+      cur = fps_unkey(fps_expand_key(0x1ffffu - inv, rb_log2), rb_log2);
+    cur = __builtin_amdgcn_readfirstlane(cur);
+    if (tid == 0 && h == 0) out[i] = cur;
+  }
+}
+
 static int ref_block_log2(int64_t n) {  // csrc/sampling_kernel.cu:32-40 + the >=16 switch (:148-165)
   int cnt = 0;
   int64_t x = n - 1;
@@ -447,9 +561,27 @@ static int ref_block_log2(int64_t n) {  // csrc/sampling_kernel.cu:32-40 + the >
 
 #define FPS_RESIDENT_MAX 25600
 
+#define FPS_MULTI_MAX (4 * FPS_RESIDENT_MAX)
+
+static int fps_num_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        v <= 0)
+      v = 256;
+    n = v;
+  }
+  return n;
+}
+
+// N > 25 600: 64 bytes of exchange slots per scene for the multi-workgroup kernel, or (scenes that do not fit it) a (B,N)
+// float array of running distances for the streaming kernel.  The callee initialises the workspace.
 extern "C" int64_t regnet_fps_workspace_bytes(int64_t B, int64_t N, int64_t M) {
   (void)M;
-  return N > FPS_RESIDENT_MAX ? B * N * (int64_t)sizeof(float) : 0;
+  if (N <= FPS_RESIDENT_MAX) return 0;
+  const int64_t stream_bytes = B * N * (int64_t)sizeof(float), slot_bytes = B * 64;
+  return stream_bytes > slot_bytes ? stream_bytes : slot_bytes;
 }
 
 #define FPS_CASE(T, PPT)                                                                                  \
@@ -489,7 +621,16 @@ extern "C" int regnet_fps_f32(const float* xyz, int64_t sb, int64_t sc, int64_t 
   else if (N <= 16384) FPS_SORTED_CASE(16);
   else if (N <= 20480) FPS_SORTED_CASE(20);
   else if (N <= FPS_RESIDENT_MAX) FPS_SORTED_CASE(25);
-  else {
+  else if (N <= FPS_MULTI_MAX && M < 32768 /* 15-bit round tag */ &&
+           ((N + FPS_RESIDENT_MAX - 1) / FPS_RESIDENT_MAX) * B <= fps_num_cus()) {
+    if (!workspace) return REGNET_ERR_NULL;
+    const int G = (int)((N + FPS_RESIDENT_MAX - 1) / FPS_RESIDENT_MAX);          // 2..4 workgroups (whole CUs) per scene
+    const int Bpad = (int)((B + 7) / 8 * 8);                                       // a scene's workgroups on one XCD
+    hipError_t e = hipMemsetAsync(workspace, 0, (size_t)B * 64, st);               // round tag 0 = "nothing published"
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL((fps_multi_kernel<25>), dim3((unsigned)(Bpad * G)), dim3(1024), 0, st, xyz, sb, sc, sn, (int)N,
+                       (int)M, rbl, G, (int)B, Bpad, (unsigned long long*)workspace, index);
+  } else {
     if (!workspace) return REGNET_ERR_NULL;
     hipLaunchKernelGGL((fps_streaming_kernel<1024>), dim3((unsigned)B), dim3(1024), 0, st, xyz, sb, sc, sn, (int)N,
                        (int)M, rbl, workspace, index);

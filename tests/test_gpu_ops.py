@@ -98,9 +98,27 @@ def test_fps_full_size_25600(ext, orc):
         assert len(set(got[b].tolist())) == 5120
 
 
-def test_fps_streaming_path_above_resident_limit(ext, orc):
-    x = cloud(7, 1, 30000)
-    assert torch.equal(ext.farthest_point_sample(x.to(DEV), 200).cpu(), orc.farthest_point_sample(x, 200))
+@pytest.mark.parametrize("B,N,M", [(1, 30000, 200), (3, 51200, 700), (2, 60000, 300), (1, 102400, 150)])
+def test_fps_multi_workgroup_path_above_resident_limit(ext, orc, B, N, M):
+    """25 600 < N <= 102 400: 2..4 workgroups per scene exchanging their maxima through global memory."""
+    x = cloud(7 + N, B, N)
+    assert torch.equal(ext.farthest_point_sample(x.to(DEV), M).cpu(), orc.farthest_point_sample(x, M))
+
+
+def test_fps_multi_workgroup_ties_and_duplicates(ext, orc):
+    """Lattice points (many exactly equal distances) and duplicated points across the workgroup boundary."""
+    g = torch.stack(torch.meshgrid(torch.arange(40.), torch.arange(40.), torch.arange(20.), indexing="ij"), -1).view(1, -1, 3)
+    x = (g[:, torch.randperm(g.shape[1], generator=torch.Generator().manual_seed(3))] * 0.05).permute(0, 2, 1).contiguous()
+    x = torch.cat([x, x[:, :, :4000]], dim=2)          # 36 000 points, 4 000 of them duplicates
+    assert torch.equal(ext.farthest_point_sample(x.to(DEV), 400).cpu(), orc.farthest_point_sample(x, 400))
+
+
+def test_fps_streaming_fallback(ext, orc):
+    """More than 32 767 samples of a large scene: the round tag of the multi-workgroup exchange would wrap, so the
+    streaming kernel (running distances in the workspace) takes over."""
+    x = cloud(11, 1, 33500)
+    got = ext.farthest_point_sample(x.to(DEV), 33000).cpu()
+    assert torch.equal(got, orc.farthest_point_sample(x, 33000))
 
 
 BQ_CASES = [  # (B, N1, N2, radius, K)
