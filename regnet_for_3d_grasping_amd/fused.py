@@ -32,6 +32,18 @@ def usable(module, xyz):
     return ENABLED and xyz.is_cuda and not module.training and not torch.is_grad_enabled()
 
 
+def supports_sa(module, feature):
+    """True when the fused set-abstraction chain covers this module's configuration; otherwise the caller takes the
+    operator-granular GPU path (pn2_ext group / torch conv), exactly like the reference."""
+    grouper = getattr(module, "grouper", None)
+    return (grouper is not None and grouper.num_neighbours == 64 and len(module.mlp) >= 2
+            and (feature is None or (module.use_xyz and feature.dtype == torch.float32)))
+
+
+def supports_fp(module, sparse_feature):
+    return sparse_feature.dtype == torch.float32 and getattr(module.interpolator, "num_neighbors", 0) == 3
+
+
 def _stream(t):
     return torch.cuda.current_stream(t.device).cuda_stream
 

@@ -185,7 +185,8 @@ class PointNetSAModule(_SetAbstraction):
 
     def forward(self, xyz, feature=None, geo=None):
         from .. import fused
-        if fused.usable(self, xyz) and self.num_centroids > 0 and self.grouper is not None:
+        if (fused.usable(self, xyz) and self.num_centroids > 0 and self.grouper is not None
+                and fused.supports_sa(self, feature)):
             return fused.sa_forward(self, xyz, feature, geo)
         return super().forward(xyz, feature)
 
@@ -295,7 +296,7 @@ class PointnetFPModule(nn.Module):
         if self.interpolator is None:
             return self.mlp(_broadcast_global(dense_xyz, sparse_xyz, dense_feature, sparse_feature))
         from .. import fused
-        if fused.usable(self, dense_xyz):
+        if fused.usable(self, dense_xyz) and fused.supports_fp(self, sparse_feature):
             return fused.fp_forward(self, dense_xyz, sparse_xyz, dense_feature, sparse_feature, geo)
         return self.mlp(self.interpolator(dense_xyz, sparse_xyz, dense_feature, sparse_feature))
 

@@ -349,3 +349,23 @@ def test_sa_chain_premul_equals_layerwise_kernels(C1, C2, C3, M):
     a1 = torch.relu(U[rows].double() - V.double().repeat_interleave(G, dim=0))
     want = _ref(_ref(a1, conv2, bn2, True).float(), conv3, bn3, True).view(B * M, G, C3).max(dim=1)[0]
     torch.testing.assert_close(got.double(), want, rtol=1e-5, atol=1e-4)
+
+
+def test_unsupported_configurations_take_the_operator_path(monkeypatch):
+    """A set-abstraction block the fused chain does not cover (32 neighbours, one MLP layer) must still run on the GPU
+    through the operator-granular kernels -- same result as with the fused path switched off, no exception."""
+    import regnet_for_3d_grasping_amd.fused as fused
+    from regnet_for_3d_grasping_amd import synthetic
+    from regnet_for_3d_grasping_amd.pn2_utils.modules import PointNetSAModule
+    torch.manual_seed(2)
+    pc = synthetic.make_batch(1030, 2, 2048, device=DEV)
+    xyz, rgb = pc.permute(0, 2, 1)[:, :3, :], pc.permute(0, 2, 1)[:, 3:6, :]
+    for sa in (PointNetSAModule(3, (32, 64), 128, 0.1, 32, True), PointNetSAModule(3, (48,), 128, 0.1, 64, True)):
+        sa = sa.to(DEV).eval()
+        assert not fused.supports_sa(sa, rgb)
+        with torch.no_grad():
+            monkeypatch.setattr(fused, "ENABLED", True)
+            nx1, nf1 = sa(xyz, rgb)
+            monkeypatch.setattr(fused, "ENABLED", False)
+            nx0, nf0 = sa(xyz, rgb)
+        assert torch.equal(nx0, nx1) and torch.equal(nf0, nf1)
