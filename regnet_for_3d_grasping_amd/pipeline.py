@@ -132,6 +132,10 @@ class ForwardPipeline:
                            final_mask=res[11])
             done = torch.cuda.Event()
             done.record(self.s_reg)
+        if not self.with_region:
+            # nothing here blocks the host, so without this the driver thread would enqueue every remaining batch at
+            # once; a bounded look-ahead (max_pending_regions batches) is what the full pipeline runs with
+            item["mlp_done"].synchronize()
         out["done"] = done
         return out
 
