@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--points", type=int, default=25600)
     ap.add_argument("--cpu-scenes", type=int, default=4, help="scenes timed for cpu_baseline (0 = skip)")
     ap.add_argument("--score-only", action="store_true", help="configs[1]: ScoreNet forward only")
+    ap.add_argument("--lookahead", type=int, default=3, help="batches whose region stage may be pending (pipeline depth)")
     return ap.parse_args()
 
 
@@ -215,7 +216,7 @@ def main():
 
     def run_steps(n):
         last = None
-        for last in pipe.run(pc for _ in range(n)):
+        for last in pipe.run((pc for _ in range(n)), max_pending_regions=args.lookahead):
             pass
         return last
 
