@@ -68,13 +68,16 @@ class ForwardPipeline:
     RNG call order: region stages execute in batch order on the host thread).
     """
 
-    def __init__(self, score_net, region_net, with_region=True):
+    def __init__(self, score_net, region_net, with_region=True, fps_streams=2):
+        """``fps_streams``: level-1 sampling launches in flight (each ~10 ms on one CU per scene, whatever the batch
+        size): 2 keep up with the matrix cores at 8 scenes per batch.  (Smaller batches are bound by the host's ~6 ms of
+        launch work per step, not by the sampling: more streams measured slower there.)"""
         self.score_net, self.region_net, self.with_region = score_net, region_net, with_region
         dev = next(score_net.parameters()).device
         self.device = dev
         # Priorities: FPS and the region stage are chains of small / single-CU kernels (the latter
         # separated by host syncs) -- they must not queue behind the big MLP launches.
-        self.s_fps = [torch.cuda.Stream(dev, priority=-1), torch.cuda.Stream(dev, priority=-1)]
+        self.s_fps = [torch.cuda.Stream(dev, priority=-1) for _ in range(max(1, int(fps_streams)))]
         self._n_sampled = 0
         self.s_geo = torch.cuda.Stream(dev, priority=-1)
         self.s_mlp = torch.cuda.Stream(dev, priority=0)
