@@ -1,5 +1,5 @@
 """Timeline analysis of a rocprofv3 --kernel-trace CSV of `python bench.py`: how much of the steady-state
-wall time has at least one mlp_gemm_kernel running, and what runs in the gaps.
+wall time has at least one MFMA kernel (mlp_gemm_kernel / sa_chain_kernel) running, and what runs in the gaps.
 
     rocprofv3 --kernel-trace --output-format csv -d gpurun_out/kt -o kt -- python bench.py --cpu-scenes 0 --steps 20
     python scripts/gemm_gaps.py gpurun_out/kt
@@ -11,11 +11,11 @@ for f in glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0][:60]))
 rows.sort()
-g_all = [r for r in rows if "mlp_gemm" in r[2]]
+g_all = [r for r in rows if "mlp_gemm" in r[2] or "sa_chain" in r[2]]
 # steady state: from 40 % to 90 % of the GEMM launches (skips model set-up and warm-up)
 a, b = g_all[int(len(g_all) * 0.4)][0], g_all[int(len(g_all) * 0.9)][1]
 sel = [r for r in rows if r[0] >= a and r[1] <= b]
-gemm = [r for r in sel if "mlp_gemm" in r[2]]
+gemm = [r for r in sel if "mlp_gemm" in r[2] or "sa_chain" in r[2]]
 iv = sorted((s, e) for s, e, _ in gemm)
 merged = []
 for s, e in iv:
