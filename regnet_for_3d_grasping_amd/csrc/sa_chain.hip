@@ -132,7 +132,7 @@ __device__ __forceinline__ void chain_group(const ChainArgs& p, const float* __r
     // Layer 3 is formed the other way round, D3[point][channel] = h2 . W3^T: the layer-2 registers serve as the A
     // operand just as well (lane -> point l & 31, k -> channel pair), and the max over the points then is a max over
     // the accumulator's registers + one cross-half exchange instead of a 32-lane reduction per register (which cost
-    // 6 % of the kernel: VALU work is not free next to MFMAs, scripts/ablate/chain_ablate -DCH_ABLATE).
+    // 6 % of the kernel: VALU work is not free next to MFMAs; measured with scripts/ablate/chain_ablate.cpp).
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
