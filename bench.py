@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--points", type=int, default=25600)
     ap.add_argument("--cpu-scenes", type=int, default=4, help="scenes timed for cpu_baseline (0 = skip)")
     ap.add_argument("--score-only", action="store_true", help="configs[1]: ScoreNet forward only")
+    ap.add_argument("--time-every", type=int, default=8,
+                    help="bracket every n-th call of each native op (per shape) with HIP events; bracketing all calls costs ~2 %")
     ap.add_argument("--lookahead", type=int, default=3, help="batches whose region stage may be pending (pipeline depth)")
     return ap.parse_args()
 
@@ -51,9 +53,11 @@ class OpTimer:
     """Brackets every native-op call of the product package with HIP events on the stream the
     kernel is launched on (torch's current stream), without synchronising."""
 
-    def __init__(self):
+    def __init__(self, every=1):
         self.records = []  # (name, meta, start_event, end_event)
         self.enabled = False
+        self.every = max(1, int(every))   # bracket every n-th call of an op (event records are not free, see --time-every)
+        self.calls = {}
 
     def wrap(self, module, name, meta_fn):
         orig = getattr(module, name)
@@ -61,22 +65,29 @@ class OpTimer:
         def timed(*a, **k):
             if not self.enabled:
                 return orig(*a, **k)
+            key = (name, meta_fn(*a, **k))
+            n = self.calls.get(key, 0)
+            self.calls[key] = n + 1
+            if n % self.every:
+                return orig(*a, **k)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()  # records on torch's CURRENT stream == the stream the kernel is launched on
             out = orig(*a, **k)
             e.record()
-            self.records.append((name, meta_fn(*a, **k), s, e))
+            self.records.append((key[0], key[1], s, e))
             return out
         setattr(module, name, timed)
 
     def summary(self):
+        """(name, shape) -> (total ms, calls) over ALL calls of the timed region: the mean of the bracketed calls (every
+        ``self.every``-th one of each shape) times the number of calls."""
         agg = {}
         for name, meta, s, e in self.records:
             key = (name, meta)
             ms = s.elapsed_time(e)
             tot, cnt = agg.get(key, (0.0, 0))
             agg[key] = (tot + ms, cnt + 1)
-        return agg
+        return {key: (tot / cnt * self.calls[key], self.calls[key]) for key, (tot, cnt) in agg.items()}
 
 
 def install_timers(timer):
@@ -198,7 +209,7 @@ def main():
         sharding.init("nccl", dev)   # RCCL; used only for the barrier + max-over-ranks of the contract
 
     from regnet_for_3d_grasping_amd import pipeline, synthetic
-    timer = OpTimer()
+    timer = OpTimer(args.time_every)
     install_timers(timer)
 
     score_net, region_net = pipeline.build_models(dev)
