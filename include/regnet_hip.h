@@ -211,6 +211,13 @@ int regnet_sa_chain3_f32(const float* feat, int64_t fb, int64_t fn, int64_t fc, 
                          int64_t K3pad, const float* scale3, const float* shift3, int64_t C3, int relu3,
                          float* out, int64_t ldo, void* stream);
 
+/* regnet_pack_rows_f32: channels-last rows [feature(Cf) | xyz(3) | 0...] (width W >= Cf + 3) of all B*N source points,
+ * the operand of the per-source-point first layer (U, V of regnet_sa_premul_layer_f32); feat (B,Cf,N) and xyz (B,3,N)
+ * with element strides (b, c, n).  Replaces a zero fill and two strided copies.                                    */
+int regnet_pack_rows_f32(const float* feat, int64_t fb, int64_t fc, int64_t fn, int64_t Cf, const float* xyz,
+                         int64_t xb, int64_t xc, int64_t xn, int64_t B, int64_t N, int64_t W, float* out,
+                         void* stream);
+
 /* regnet_sa_chain_premul_f32: layers 2 and 3 + the max over the 64 neighbours of a WIDE set-abstraction block
  * (levels 2 and 3 of PointNet2Seg, pointnet2.py:40-42) in one kernel, on pre-multiplied layer-1 rows as
  * regnet_sa_premul_layer_f32: A1[p][k] = max(U[b*Nsrc + nbr[p]][k] - V[p / 64][k], 0), k < C1 (C1 % 16 == 0);

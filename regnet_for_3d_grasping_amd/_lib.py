@@ -48,6 +48,7 @@ SIGNATURES = {
     "regnet_sa_chain3_f32": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp,
                                     _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _int, _vp, _i64,
                                     _vp]),
+    "regnet_pack_rows_f32": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp]),
     "regnet_sa_chain_premul_f32": (_int, [_vp, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _vp, _vp, _i64,
                                           _vp, _i64, _vp, _vp, _i64, _int, _vp, _i64, _vp]),
     "regnet_sa_premul_layer_f32": (_int, [_vp, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _vp, _vp,

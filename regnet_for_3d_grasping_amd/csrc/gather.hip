@@ -170,3 +170,38 @@ extern "C" int regnet_gather_knn_bwd_f32(const float* grad_out, int64_t sb, int6
                                          int64_t K, float* grad_in, void* stream) {
   return regnet_group_points_bwd_f32(grad_out, sb, sc, sn2, sk, index, B, C, N, NI, K, grad_in, stream);
 }
+
+// ---------------------------------------------------------------------------------------
+// Row packer for the per-source-point evaluation of a set-abstraction block's first layer (fused.sa_features):
+//   out[b*N + n][0:Cf] = feat[b, 0:Cf, n]   out[..][Cf:Cf+3] = xyz[b, 0:3, n]   out[..][Cf+3:W] = 0
+// one launch instead of a zero fill and two strided copies.  feat element (b,c,n) at feat[b*fb + c*fc + n*fn].
+__global__ __launch_bounds__(256) void pack_rows_kernel(const float* __restrict__ feat, long long fb, long long fc,
+                                                        long long fn, int Cf, const float* __restrict__ xyz, long long xb,
+                                                        long long xc, long long xn, long long N, int W,
+                                                        float* __restrict__ out, long long total) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;   // one output element per thread, channel fastest
+  if (i >= total) return;
+  const long long row = i / W;
+  const int c = (int)(i - row * W);
+  const long long b = row / N, n = row - b * N;
+  float v = 0.f;
+  if (c < Cf) v = feat[b * fb + (long long)c * fc + n * fn];
+  else if (c < Cf + 3) v = xyz[b * xb + (long long)(c - Cf) * xc + n * xn];
+  out[i] = v;
+}
+
+extern "C" int regnet_pack_rows_f32(const float* feat, int64_t fb, int64_t fc, int64_t fn, int64_t Cf, const float* xyz,
+                                    int64_t xb, int64_t xc, int64_t xn, int64_t B, int64_t N, int64_t W, float* out,
+                                    void* stream) {
+  if (B < 0 || N < 0 || Cf < 0 || W < Cf + 3) return REGNET_ERR_SHAPE;
+  const long long total = B * N * W;
+  if (total == 0) return REGNET_OK;
+  if (!xyz || !out || (Cf > 0 && !feat)) return REGNET_ERR_NULL;
+  const long long blocks = (total + 255) / 256;
+  if (blocks >= (1ll << 31)) return REGNET_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), feat, (long long)fb,
+                     (long long)fc, (long long)fn, (int)Cf, xyz, (long long)xb, (long long)xc, (long long)xn,
+                     (long long)N, (int)W, out, total);
+  REGNET_LAUNCH_CHECK();
+  return REGNET_OK;
+}

@@ -177,6 +177,19 @@ def _premul_layers(first, Cf):
     return first.premul
 
 
+def pack_rows(feature, xyz, width):
+    """Channels-last rows [feature | xyz | 0] of every point: feature (B,Cf,N) or None, xyz (B,3,N) -> (B*N, width)."""
+    B, _, N = xyz.shape
+    out = torch.empty((B * N, width), dtype=torch.float32, device=xyz.device)
+    if feature is None:
+        fptr, fb, fc, fn, Cf = None, 0, 0, 0, 0
+    else:
+        fptr, (fb, fc, fn), Cf = feature.data_ptr(), feature.stride(), feature.size(1)
+    _check(_L.regnet_pack_rows_f32(fptr, fb, fc, fn, Cf, xyz.data_ptr(), *xyz.stride(), B, N, width, out.data_ptr(),
+                                   _stream(xyz)), "pack_rows")
+    return out
+
+
 def sa_premul_layer(U, V, nbr, layer, B, Nsrc, M, group, pool_group=0):
     """Layer 2 of a set-abstraction block over pre-multiplied layer-1 rows: relu(U[nbr] - V[centre]) . W."""
     P = B * M * group
@@ -390,13 +403,8 @@ def sa_features(module, xyz, feature, geo):
         first, N1 = layers[0], xyz.shape[2]
         u_layer, v_layer = _premul_layers(first, Cf)
         width = _round_up(Cf + 3, 4)
-        src = torch.zeros((B, N1, width), dtype=torch.float32, device=xyz.device)
-        src[:, :, :Cf] = feature.transpose(1, 2)
-        src[:, :, Cf:Cf + 3] = xyz.transpose(1, 2)
-        U = mlp_layer(src.view(B * N1, width), width, u_layer, B * N1)
-        cxyz = torch.zeros((B, M, 4), dtype=torch.float32, device=xyz.device)
-        cxyz[:, :, :3] = geo["new_xyz"].transpose(1, 2)
-        V = mlp_layer(cxyz.view(B * M, 4), 4, v_layer, B * M)
+        U = mlp_layer(pack_rows(feature, xyz, width), width, u_layer, B * N1)
+        V = mlp_layer(pack_rows(None, geo["new_xyz"], 4), 4, v_layer, B * M)
         if (CHAIN3 and len(layers) == 3 and layers[1].N in CHAIN_PREMUL_WIDTHS and layers[1].relu and first.N % 16 == 0
                 and layers[2].N % 16 == 0 and layers[2].K == layers[1].N):
             # layers 2 and 3 + the pooling in one kernel, layer-2 activation in registers (csrc/sa_chain2.hip)
