@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--score-only", action="store_true", help="configs[1]: ScoreNet forward only")
     ap.add_argument("--time-every", type=int, default=8,
                     help="bracket every n-th call of each native op (per shape) with HIP events; bracketing all calls costs ~2 %")
+    ap.add_argument("--train", action="store_true",
+                    help="configs[3]: the reference's training iteration (forward with labels, losses, backward, two Adam "
+                         "steps, one flat gradient all-reduce per network over RCCL) instead of the forward pipeline")
     ap.add_argument("--lookahead", type=int, default=3, help="batches whose region stage may be pending (pipeline depth)")
     return ap.parse_args()
 
@@ -197,6 +200,55 @@ def _cpu_model():
     return "unknown x%d" % (os.cpu_count() or 0)
 
 
+def run_train(args, rank, world, dev):
+    """configs[3-4]: K training iterations of ``train_step.RefineTrainer`` on this rank's scenes (synthetic labels)."""
+    from regnet_for_3d_grasping_amd import pipeline, sharding, synthetic
+    from regnet_for_3d_grasping_amd.gripper_region_network import GripperRegionNetwork
+    from regnet_for_3d_grasping_amd.score_network import ScoreNetwork
+    from regnet_for_3d_grasping_amd.train_step import RefineTrainer
+    B, N = args.batch, args.points
+    pc_cpu = synthetic.make_batch(1000 + rank * B, B, N)
+    records = [synthetic.make_grasp_labels(pc_cpu[b].numpy(), 50 + rank * B + b) for b in range(B)]
+    target = torch.from_numpy(np.random.default_rng(2 + rank).uniform(0, 1, (B, N)).astype(np.float32)).to(dev)
+    score_net = ScoreNetwork(training=True)
+    score_net.load_state_dict(synthetic.seeded_state_dict(score_net, 7))
+    region_net = GripperRegionNetwork(training=True, group_num=pipeline.GROUP_NUM, gripper_num=pipeline.GRIPPER_NUM,
+                                      grasp_score_threshold=pipeline.GRASP_SCORE_THRESHOLD, radius=pipeline.DEPTH,
+                                      reg_channel=pipeline.REG_CHANNEL)
+    region_net.load_state_dict(synthetic.seeded_state_dict(region_net, 11))
+    trainer = RefineTrainer(score_net.to(dev), region_net.to(dev), pipeline.PARAMS, pipeline.GRIPPER_PARAMS)
+    pc = pc_cpu.to(dev)
+    np.random.seed(rank)
+
+    def fence():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        trainer.step(pc, target, records)
+    fence()
+    t0 = time.perf_counter()
+    region_steps = 0
+    for _ in range(args.steps):
+        loss, parts = trainer.step(pc, target, records)
+        region_steps += "region_error" not in parts
+    fence()
+    dt = sharding.max_over_ranks(time.perf_counter() - t0, dev)
+    if rank == 0:
+        grads = sum(p.numel() for net in (score_net, region_net) for p in net.parameters())
+        print(json.dumps({
+            "metric": "train scenes/sec (25 600-pt ScoreNet+GRN+Refine training iteration)", "value": round(B * args.steps * world / dt, 3),
+            "unit": "scenes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[3]: training iteration (forward with labels, stage-2 + refine losses, backward, "
+                                   "two Adam steps), %d-pt synthetic scenes, batch=%d per GPU" % (N, B),
+                       "points": N, "batch_per_gpu": B, "global_batch": B * world,
+                       "parallelism": "dp%d: one flat fp32 gradient all-reduce per network (%d elements) over RCCL" % (world, grads),
+                       "steps_with_region_losses": region_steps, "last_loss": float(loss)}}))
+
+
 def main():
     args = parse()
     from regnet_for_3d_grasping_amd import sharding
@@ -207,6 +259,11 @@ def main():
     dev = torch.device("cuda", local_rank)
     if world > 1:
         sharding.init("nccl", dev)   # RCCL; used only for the barrier + max-over-ranks of the contract
+    if args.train:
+        run_train(args, rank, world, dev)
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
 
     from regnet_for_3d_grasping_amd import pipeline, synthetic
     timer = OpTimer(args.time_every)
