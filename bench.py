@@ -163,30 +163,57 @@ def pmc_traffic(kernel):
         return None
 
 
-def cpu_baseline(args, n_scenes):
+def cpu_baseline(args, n_scenes, gpu_models=None):
     """The same forward on the host CPU: the host-side mirror driven by the C oracle (OpenMP) and
-    torch-CPU 1x1 convs.  Bounded sample: ``n_scenes`` scenes of the bench workload, batch 1."""
+    torch-CPU 1x1 convs.  Bounded sample: ``n_scenes`` scenes of the bench workload, batch 1.
+    With ``gpu_models`` (the bench's networks) the CPU side runs THEIR weights and the first scene is also pushed
+    through the GPU path: the returned ``parity`` is the metric's "fp max-abs-err vs ref" on identical inputs."""
     from oracle.install import oracle_backend
     from regnet_for_3d_grasping_amd import pipeline, synthetic
     threads = torch.get_num_threads()
     score_net, region_net = pipeline.build_models("cpu")
     pc0 = synthetic.make_batch(1000, 1, args.points)
+    first_out = None
     with oracle_backend():
-        synthetic.calibrate_score_head(score_net, pc0)
+        if gpu_models is not None:
+            score_net.load_state_dict({k: v.cpu() for k, v in gpu_models[0].state_dict().items()})
+            region_net.load_state_dict({k: v.cpu() for k, v in gpu_models[1].state_dict().items()})
+        else:
+            synthetic.calibrate_score_head(score_net, pc0)
         np.random.seed(0)
         t0 = time.perf_counter()
         for i in range(n_scenes):
             pc = pc0 if i == 0 else synthetic.make_batch(1000 + i, 1, args.points)
             t1 = time.perf_counter()
-            pipeline.forward_scenes(score_net, region_net, pc, with_region=not args.score_only)
+            out = pipeline.forward_scenes(score_net, region_net, pc, with_region=not args.score_only)
             if i == 0:
                 first = time.perf_counter() - t1
+                first_out = out
         dt = time.perf_counter() - t0
+    parity = None
+    if gpu_models is not None:
+        dev = next(gpu_models[0].parameters()).device
+        np.random.seed(0)   # the region stage draws from numpy's global stream: same seed as the CPU side's first scene
+        got = pipeline.forward_scenes(gpu_models[0], gpu_models[1], pc0.to(dev), with_region=not args.score_only)
+        torch.cuda.synchronize()
+        ref_f, got_f = first_out["all_feature"], got["all_feature"].cpu()
+        parity = {"score_max_abs_err": float((got["score"].cpu() - first_out["score"]).abs().max()),
+                  "feature_max_rel_err": float(((got_f - ref_f).abs() / (1.0 + ref_f.abs())).max()),
+                  "tolerance": 1e-4, "scene": "seed 1000, %d pts, batch 1, same weights on both sides" % args.points}
+        if "center_pc_index" in got:
+            same = (torch.equal(got["center_pc_index"].cpu(), first_out["center_pc_index"])
+                    and torch.equal(got["pc_group_index"].cpu(), first_out["pc_group_index"])
+                    and got["next_grasp"].shape == first_out["next_grasp"].shape)
+            # centre selection thresholds the scores at 0.5: a score within fp32 noise of it may flip a centre
+            parity["region_indices_equal"] = bool(same)
+            parity["grasp_max_abs_err"] = (float((got["next_grasp"].cpu() - first_out["next_grasp"]).abs().max())
+                                           if same else None)
     return {"value": n_scenes / dt, "unit": "scenes/s", "cores": threads, "kind": "port",
             "sample": "%d scene(s) x %d pts, batch 1, eval forward (%s), oracle C kernels (OpenMP) + torch-CPU convs, "
                       "%.1f s total; host %s" % (n_scenes, args.points,
                                                  "ScoreNet" if args.score_only else "ScoreNet+grouping+GRN+refine", dt,
-                                                 _cpu_model())}
+                                                 _cpu_model()),
+            "parity": parity}
 
 
 def _cpu_model():
@@ -358,7 +385,8 @@ def main():
             "grasps_last_step": int(out["next_grasp"].shape[0]) if "next_grasp" in out else None,
         }
         if world == 1 and args.cpu_scenes > 0:
-            res["cpu_baseline"] = cpu_baseline(args, args.cpu_scenes)
+            res["cpu_baseline"] = cpu_baseline(args, args.cpu_scenes, (score_net, region_net))
+            res["parity"] = res["cpu_baseline"].pop("parity")
             res["speedup_vs_cpu_baseline"] = round(res["value"] / res["cpu_baseline"]["value"], 1)
         print(json.dumps(res))
     if world > 1:
