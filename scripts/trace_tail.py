@@ -6,7 +6,8 @@ for f in glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
 rows.sort()
 frac = float(sys.argv[2]) if len(sys.argv) > 2 else 0.3
-t0 = rows[-1][1] - (rows[-1][1] - rows[0][0]) * frac
+# frac < 1: that fraction of the trace's span; frac >= 1: that many milliseconds before the last kernel ends
+t0 = rows[-1][1] - ((rows[-1][1] - rows[0][0]) * frac if frac < 1 else frac * 1e6)
 sel = [r for r in rows if r[0] >= t0]
 tot = collections.Counter(); cnt = collections.Counter()
 for s, e, n in sel:
