@@ -252,13 +252,20 @@ def run_train(args, rank, world, dev):
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    # steady state of a training loop: the geometry (FPS / ball query / 3-NN: xyz only) of the NEXT batch is enqueued
+    # on a side stream before each iteration, as a data loader with one batch of look-ahead would
+    ahead = trainer.prefetch(pc)
     for _ in range(args.warmup):
-        trainer.step(pc, target, records)
+        nxt = trainer.prefetch(pc)
+        trainer.step(pc, target, records, plan=ahead)
+        ahead = nxt
     fence()
     t0 = time.perf_counter()
     region_steps = 0
     for _ in range(args.steps):
-        loss, parts = trainer.step(pc, target, records)
+        nxt = trainer.prefetch(pc)
+        loss, parts = trainer.step(pc, target, records, plan=ahead)
+        ahead = nxt
         region_steps += "region_error" not in parts
     fence()
     dt = sharding.max_over_ranks(time.perf_counter() - t0, dev)

@@ -31,11 +31,13 @@ class FarthestPointSampler(nn.Module):
         return "num_centroids={:d}".format(self.num_centroids)
 
 
-def _ball_group(radius, k, new_xyz, xyz):
+def _ball_group(radius, k, new_xyz, xyz, index=None):
     """Ball query + xyz grouping shared by the groupers: returns (index, centred group_xyz).
-    group_xyz is (B,3,M,K) with the centroid subtracted in place (modules.py:41-46)."""
-    with torch.no_grad():
-        index, _ = _F.ball_query(xyz, new_xyz, radius, k)
+    group_xyz is (B,3,M,K) with the centroid subtracted in place (modules.py:41-46).
+    ``index``: the ball-query result when it was computed ahead of time (a geometry plan)."""
+    if index is None:
+        with torch.no_grad():
+            index, _ = _F.ball_query(xyz, new_xyz, radius, k)
     group_xyz = _F.group_points(xyz, index)
     group_xyz -= new_xyz.unsqueeze(-1)
     return index, group_xyz
@@ -50,8 +52,8 @@ class QueryGrouper(nn.Module):
         assert radius > 0.0 and num_neighbours > 0
         self.radius, self.num_neighbours = radius, num_neighbours
 
-    def forward(self, new_xyz, xyz, feature, use_xyz):
-        index, group_xyz = _ball_group(self.radius, self.num_neighbours, new_xyz, xyz)
+    def forward(self, new_xyz, xyz, feature, use_xyz, index=None):
+        index, group_xyz = _ball_group(self.radius, self.num_neighbours, new_xyz, xyz, index)
         if feature is None:
             return group_xyz, group_xyz
         group_feature = _F.group_points(feature, index)
@@ -77,10 +79,14 @@ class EdgeQueryGrouper(QueryGrouper):
         return torch.cat(parts, dim=1), group_xyz
 
 
-def _three_nn_weights(dense_xyz, sparse_xyz, k, eps):
-    """3-NN indices + inverse-SQUARED-distance weights, normalised (modules.py:115-122)."""
+def _three_nn_weights(dense_xyz, sparse_xyz, k, eps, geo=None):
+    """3-NN indices + inverse-SQUARED-distance weights, normalised (modules.py:115-122).
+    ``geo``: dict(idx, dist2) when the search was done ahead of time (a geometry plan)."""
     with torch.no_grad():
-        index, dist2 = _F.search_nn_distance(dense_xyz, sparse_xyz, k)
+        if geo is not None:
+            index, dist2 = geo["idx"], geo["dist2"]
+        else:
+            index, dist2 = _F.search_nn_distance(dense_xyz, sparse_xyz, k)
         inv = 1.0 / torch.clamp(dist2, min=eps)
         weight = inv / torch.sum(inv, dim=2, keepdim=True)
     return index, weight
@@ -94,8 +100,8 @@ class FeatureInterpolator(nn.Module):
         super().__init__()
         self.num_neighbors, self._eps = num_neighbors, eps
 
-    def forward(self, dense_xyz, sparse_xyz, dense_feature, sparse_feature):
-        index, weight = _three_nn_weights(dense_xyz, sparse_xyz, self.num_neighbors, self._eps)
+    def forward(self, dense_xyz, sparse_xyz, dense_feature, sparse_feature, geo=None):
+        index, weight = _three_nn_weights(dense_xyz, sparse_xyz, self.num_neighbors, self._eps, geo)
         out = _F.feature_interpolate(sparse_feature, index, weight)
         if dense_feature is not None:
             out = torch.cat([out, dense_feature], dim=1)
@@ -156,9 +162,13 @@ class _SetAbstraction(nn.Module):
     def _reduce(self, x):
         return torch.max(x, 3)[0]
 
-    def forward(self, xyz, feature=None):
+    def forward(self, xyz, feature=None, geo=None):
+        """``geo``: dict(new_xyz, nbr) of ``fused.sa_geometry`` when sampling and ball query ran ahead of time."""
         if self.num_centroids == 0:
             new_xyz, group_feature = self._global_group(xyz, feature)
+        elif geo is not None and type(self.grouper) is QueryGrouper:
+            new_xyz = geo["new_xyz"]
+            group_feature, _ = self.grouper(new_xyz, xyz, feature, use_xyz=self.use_xyz, index=geo["nbr"])
         else:
             _, new_xyz = self._sample(xyz)
             group_feature, _ = self.grouper(new_xyz, xyz, feature, use_xyz=self.use_xyz)
@@ -188,7 +198,7 @@ class PointNetSAModule(_SetAbstraction):
         if (fused.usable(self, xyz) and self.num_centroids > 0 and self.grouper is not None
                 and fused.supports_sa(self, feature)):
             return fused.sa_forward(self, xyz, feature, geo)
-        return super().forward(xyz, feature)
+        return super().forward(xyz, feature, geo)
 
 
 class PointNetSAAvgModule(_SetAbstraction):
@@ -298,6 +308,8 @@ class PointnetFPModule(nn.Module):
         from .. import fused
         if fused.usable(self, dense_xyz) and fused.supports_fp(self, sparse_feature):
             return fused.fp_forward(self, dense_xyz, sparse_xyz, dense_feature, sparse_feature, geo)
+        if geo is not None and type(self.interpolator) is FeatureInterpolator:
+            return self.mlp(self.interpolator(dense_xyz, sparse_xyz, dense_feature, sparse_feature, geo))
         return self.mlp(self.interpolator(dense_xyz, sparse_xyz, dense_feature, sparse_feature))
 
     def init_weights(self, init_fn=None):

@@ -57,18 +57,25 @@ class PointNet2Seg(nn.Module):
         forward, separable so a pipeline can run it two batches ahead.  Pass the result to ``plan``."""
         from . import fused
         xyz = points[:, :3, :]
-        if not fused.usable(self, xyz):
-            raise RuntimeError("PointNet2Seg.sample_level1 needs eval mode, torch.no_grad() and GPU tensors")
-        return fused.sa_sample(self.sa_modules[0], xyz)
+        if not (fused.ENABLED and xyz.is_cuda):
+            raise RuntimeError("PointNet2Seg.sample_level1 needs GPU tensors")
+        with torch.no_grad():
+            return fused.sa_sample(self.sa_modules[0], xyz)
 
     def plan(self, points, level1_ctr=None):
         """Geometry of a forward pass -- FPS / ball-query / 3-NN indices of every level.  Depends on
         xyz only, so it can be computed ahead of (and concurrently with) the feature pass; hand the
-        result to ``forward(points, plan=...)``.  Fused MI355X path only."""
+        result to ``forward(points, plan=...)`` -- the fused inference path or the operator-granular training path.
+        GPU only; always computed without autograd (the reference's geometry ops return no gradients)."""
         from . import fused
         xyz = points[:, :3, :]
-        if not fused.usable(self, xyz):
-            raise RuntimeError("PointNet2Seg.plan needs eval mode, torch.no_grad() and GPU tensors")
+        if not (fused.ENABLED and xyz.is_cuda):
+            raise RuntimeError("PointNet2Seg.plan needs GPU tensors")
+        with torch.no_grad():
+            return self._plan(xyz, level1_ctr)
+
+    def _plan(self, xyz, level1_ctr):
+        from . import fused
         levels, sa_geo = [xyz], []
         for i, sa in enumerate(self.sa_modules):
             geo = fused.sa_geometry(sa, levels[-1], level1_ctr if i == 0 else None)

@@ -45,12 +45,17 @@ class ScoreTrainer:
         self.reduce = reduce
         self.optimizer = torch.optim.Adam([{"params": score_net.parameters(), "initial_lr": lr}], lr=lr)
         self.scheduler = torch.optim.lr_scheduler.StepLR(self.optimizer, step_size=5, gamma=0.5)
+        self.geometry = GeometryPrefetcher(score_net)
 
-    def step(self, pc, pc_score, pc_label=None):
+    def prefetch(self, pc):
+        """Start the geometry of a FUTURE batch on a side stream; pass the result to ``step(..., plan=...)``."""
+        return self.geometry.prefetch(pc)
+
+    def step(self, pc, pc_score, pc_label=None, plan=None):
         self.net.train()
         self.optimizer.zero_grad()
         with torch.enable_grad():
-            _, _, loss = self.net(pc, pc_score, pc_label)
+            _, _, loss = self.net(pc, pc_score, pc_label, plan=GeometryPrefetcher.acquire(plan, pc.device))
             loss_total = loss.sum()
             loss_total.backward()
         allreduce_gradients(list(self.net.parameters()), self.reduce)
@@ -59,6 +64,41 @@ class ScoreTrainer:
 
     def end_epoch(self):
         self.scheduler.step()
+
+
+class GeometryPrefetcher:
+    """Computes the geometry plan of a batch (every FPS / ball-query / 3-NN index of ScoreNet: functions of xyz only,
+    no gradients) on a side HIP stream, so that the NEXT batch's ~9 ms level-1 sampling chain -- one CU per scene --
+    runs underneath the current iteration's forward/backward instead of at the head of its own."""
+
+    def __init__(self, score_net):
+        self.score_net = score_net
+        self.stream = None
+
+    def prefetch(self, pc):
+        """pc (B,N,6) on the GPU -> handle for ``step(..., plan=handle)``.  Enqueue-only, does not block the host."""
+        from . import fused
+        if self.stream is None:
+            self.stream = torch.cuda.Stream(pc.device, priority=-1)
+        cur = torch.cuda.current_stream(pc.device)
+        self.stream.wait_stream(cur)          # pc may still be in flight on the caller's stream
+        with torch.cuda.stream(self.stream):
+            plan = self.score_net.plan(pc)
+            ready = torch.cuda.Event()
+            ready.record(self.stream)
+        pc.record_stream(self.stream)
+        return {"plan": plan, "ready": ready, "tensors": fused.plan_tensors(plan)}
+
+    @staticmethod
+    def acquire(handle, device):
+        """Make the current stream wait for a prefetched plan; returns the plan (None passes through)."""
+        if handle is None:
+            return None
+        cur = torch.cuda.current_stream(device)
+        cur.wait_event(handle["ready"])
+        for t in handle["tensors"]:
+            t.record_stream(cur)
+        return handle["plan"]
 
 
 class RefineTrainer:
@@ -75,14 +115,20 @@ class RefineTrainer:
         self.opt_region = torch.optim.Adam([{"params": region_net.parameters(), "initial_lr": lr}], lr=lr)
         self.sched_score = torch.optim.lr_scheduler.StepLR(self.opt_score, step_size=5, gamma=0.5)
         self.sched_region = torch.optim.lr_scheduler.StepLR(self.opt_region, step_size=5, gamma=0.5)
+        self.geometry = GeometryPrefetcher(score_net)
 
-    def forward_losses(self, pc, pc_score, grasp_records):
+    def prefetch(self, pc):
+        """Start the geometry of a FUTURE batch on a side stream; pass the result to ``step(..., plan=...)``."""
+        return self.geometry.prefetch(pc)
+
+    def forward_losses(self, pc, pc_score, grasp_records, plan=None):
         """-> (loss_total, parts) with parts = dict(score=..., stage2=... or None, refine=... or None)."""
         import contextlib
         import io
 
         from .get_regiondataset import get_grasp_allobj
-        all_feature, output_score, loss = self.score_net(pc, pc_score, None)
+        all_feature, output_score, loss = self.score_net(pc, pc_score, None,
+                                                         plan=GeometryPrefetcher.acquire(plan, pc.device))
         parts = {"score": loss, "stage2": None, "refine": None}
         total = loss.sum()
         try:
@@ -100,13 +146,13 @@ class RefineTrainer:
             parts["region_error"] = repr(exc)
         return total, parts
 
-    def step(self, pc, pc_score, grasp_records):
+    def step(self, pc, pc_score, grasp_records, plan=None):
         self.score_net.train()
         self.region_net.train()
         self.opt_score.zero_grad()
         self.opt_region.zero_grad()
         with torch.enable_grad():
-            total, parts = self.forward_losses(pc, pc_score, grasp_records)
+            total, parts = self.forward_losses(pc, pc_score, grasp_records, plan)
             total.backward()
         allreduce_gradients(list(self.score_net.parameters()), self.reduce)
         allreduce_gradients(list(self.region_net.parameters()), self.reduce)

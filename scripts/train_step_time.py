@@ -20,9 +20,15 @@ t = RefineTrainer(s.to(dev), r.to(dev), pipeline.PARAMS, pipeline.GRIPPER_PARAMS
 t.score_net.train(); t.region_net.train()
 pc = pc.to(dev)
 np.random.seed(1)
-for _ in range(2): t.step(pc, target, records)
+PRE = bool(int(os.environ.get("PREFETCH", "1")))   # geometry of the next batch on a side stream
+ahead = t.prefetch(pc) if PRE else None
+def one(ahead):
+    nxt = t.prefetch(pc) if PRE else None
+    out = t.step(pc, target, records, plan=ahead)
+    return out, nxt
+for _ in range(2): _, ahead = one(ahead)
 torch.cuda.synchronize(); t0 = time.perf_counter()
-n = 5
-for _ in range(n): loss, parts = t.step(pc, target, records)
+n = 8
+for _ in range(n): (loss, parts), ahead = one(ahead)
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
-print("train step B=%d N=%d: %.1f ms/step, %.1f scenes/s, loss %.4f, peak mem %.1f GB" % (B, N, dt * 1e3, B / dt, float(loss), torch.cuda.max_memory_allocated() / 2**30))
+print("prefetch=%d" % PRE, "train step B=%d N=%d: %.1f ms/step, %.1f scenes/s, loss %.4f, peak mem %.1f GB" % (B, N, dt * 1e3, B / dt, float(loss), torch.cuda.max_memory_allocated() / 2**30))

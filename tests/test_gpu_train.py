@@ -93,3 +93,34 @@ def test_full_training_step_on_gpu_matches_cpu_losses():
     l1, _ = gpu.step(pc.to(DEV), target.to(DEV), records)
     l2, _ = gpu.step(pc.to(DEV), target.to(DEV), records)
     assert torch.isfinite(l1) and torch.isfinite(l2)
+
+
+def test_prefetched_geometry_plan_gives_the_same_training_forward():
+    """train_step.GeometryPrefetcher: the FPS / ball-query / 3-NN indices computed ahead of time on a side stream feed
+    the operator-granular training forward; score, loss and feature must equal the in-line forward bit for bit
+    (same kernels, same indices) and gradients must flow."""
+    from regnet_for_3d_grasping_amd import synthetic
+    from regnet_for_3d_grasping_amd.score_network import ScoreNetwork
+    from regnet_for_3d_grasping_amd.train_step import GeometryPrefetcher, ScoreTrainer
+    B, N = 2, 6144
+    pc = synthetic.make_batch(8200, B, N).to(DEV)
+    target = torch.from_numpy(np.random.default_rng(1).uniform(0, 1, (B, N)).astype(np.float32)).to(DEV)
+    net = ScoreNetwork(training=True)
+    net.load_state_dict(synthetic.seeded_state_dict(net, 3))
+    net = net.to(DEV).train()
+    net.extrat_featurePN2.mlp.dropout_prob = 0.0
+    feat0, score0, loss0 = net(pc, target)
+    stats = {k: v.clone() for k, v in net.state_dict().items() if "running" in k}
+    pre = GeometryPrefetcher(net)
+    handle = pre.prefetch(pc)
+    plan = GeometryPrefetcher.acquire(handle, pc.device)
+    assert all(not t.requires_grad for t in handle["tensors"])
+    net.load_state_dict(stats, strict=False)
+    feat1, score1, loss1 = net(pc, target, plan=plan)
+    assert torch.equal(score0, score1) and torch.equal(feat0, feat1) and torch.equal(loss0, loss1)
+    loss1.backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all()
+               for k, p in net.named_parameters() if "sa_modules" in k or "fp_modules" in k)
+    trainer = ScoreTrainer(net)
+    out = trainer.step(pc, target, plan=trainer.prefetch(pc))
+    assert torch.isfinite(out)
