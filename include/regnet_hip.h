@@ -218,6 +218,26 @@ int regnet_pack_rows_f32(const float* feat, int64_t fb, int64_t fc, int64_t fn, 
                          int64_t xb, int64_t xc, int64_t xn, int64_t B, int64_t N, int64_t W, float* out,
                          void* stream);
 
+/* regnet_bn_relu_train_fwd_f32 / _bwd_f32: TRAINING-mode BatchNorm (+ ReLU, + max over the K neighbours) of a shared-MLP
+ * block -- nn/modules/conv.py:30-36, :70-76 (bn then relu after the bias-free 1x1 convolution) and the set-abstraction
+ * reduction torch.max(new_feature, 3) of modules.py:245 -- as two HBM passes each way instead of torch's 13-18.
+ * x (B, C, L) contiguous, 16-byte aligned; statistics per channel over (B, L), biased variance for the normalisation,
+ * running_mean / running_var (may be NULL) updated with `momentum` and the unbiased variance, save_mean / save_invstd
+ * (C) written for the backward.  pool_group == 0: y (B, C, L) = [relu](bn(x)).  pool_group = K (a power of two in
+ * 4..256 dividing L, the K neighbours innermost): y (B, C, L/K) = max over each run of K, pool_index (B, C, L/K) int32 =
+ * position of the selected element (smallest on ties).  workspace: regnet_bn_workspace_bytes(C) bytes.
+ * Backward: dy shaped like y; dx (B, C, L), dgamma / dbeta (C) are overwritten; the ReLU mask is recomputed from x
+ * (pooled: taken from y, which must then be the forward's output).                                                   */
+int64_t regnet_bn_workspace_bytes(int64_t C);
+int regnet_bn_relu_train_fwd_f32(const float* x, int64_t B, int64_t C, int64_t L, const float* gamma, const float* beta,
+                                 float eps, float momentum, float* running_mean, float* running_var, int relu,
+                                 int64_t pool_group, float* y, int32_t* pool_index, float* save_mean, float* save_invstd,
+                                 void* workspace, void* stream);
+int regnet_bn_relu_train_bwd_f32(const float* x, const float* y, const float* dy, const int32_t* pool_index, int64_t B,
+                                 int64_t C, int64_t L, const float* gamma, const float* beta, const float* save_mean,
+                                 const float* save_invstd, int relu, int64_t pool_group, float* dx, float* dgamma,
+                                 float* dbeta, void* workspace, void* stream);
+
 /* regnet_sa_chain_premul_f32: layers 2 and 3 + the max over the 64 neighbours of a WIDE set-abstraction block
  * (levels 2 and 3 of PointNet2Seg, pointnet2.py:40-42) in one kernel, on pre-multiplied layer-1 rows as
  * regnet_sa_premul_layer_f32: A1[p][k] = max(U[b*Nsrc + nbr[p]][k] - V[p / 64][k], 0), k < C1 (C1 % 16 == 0);

@@ -23,6 +23,7 @@ SOURCES = [
     ("mlp.hip", []),
     ("sa_chain.hip", ["-fno-slp-vectorize"]),
     ("sa_chain2.hip", ["-fno-slp-vectorize"]),  # SLP turns the layer-1 FMAs into v_pk_mul + separate adds
+    ("bn_train.hip", []),
     ("np_random.hip", []),
 ]
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",

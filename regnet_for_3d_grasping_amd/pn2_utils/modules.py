@@ -162,6 +162,12 @@ class _SetAbstraction(nn.Module):
     def _reduce(self, x):
         return torch.max(x, 3)[0]
 
+    def _mlp_reduce(self, group_feature):
+        """SharedMLP then the reduction over the K neighbours (modules.py:244-245)."""
+        if type(self)._reduce is _SetAbstraction._reduce:
+            return self.mlp(group_feature, pool_max=True)   # max: fusable into the last BatchNorm + ReLU pass
+        return self._reduce(self.mlp(group_feature))
+
     def forward(self, xyz, feature=None, geo=None):
         """``geo``: dict(new_xyz, nbr) of ``fused.sa_geometry`` when sampling and ball query ran ahead of time."""
         if self.num_centroids == 0:
@@ -172,7 +178,7 @@ class _SetAbstraction(nn.Module):
         else:
             _, new_xyz = self._sample(xyz)
             group_feature, _ = self.grouper(new_xyz, xyz, feature, use_xyz=self.use_xyz)
-        return new_xyz, self._reduce(self.mlp(group_feature))
+        return new_xyz, self._mlp_reduce(group_feature)
 
     def init_weights(self, init_fn=None):
         self.mlp.init_weights(init_fn)

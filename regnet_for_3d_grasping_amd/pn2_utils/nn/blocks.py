@@ -6,6 +6,7 @@ hence identical ``state_dict`` keys (``mlp.<i>.conv.weight``, ``mlp.<i>.bn.runni
 The affine layer is bias-free whenever BN follows (conv.py:24,64); BN uses eps 1e-5 and the
 given momentum; conv weights keep torch's default init unless ``init_weights(fn)`` is called.
 """
+import torch
 import torch.nn.functional as F
 from torch import nn
 
@@ -22,13 +23,23 @@ class _AffineBNReLU(nn.Module):
         self.bn = bn
         self.relu = nn.ReLU(inplace=True) if relu else None
 
-    def forward(self, x):
+    def forward(self, x, pool_max=False):
+        """``pool_max``: also take the max over the last axis (the set-abstraction reduction, modules.py:245)."""
         x = getattr(self, self._affine_name)(x)
+        if self.bn is not None and self.training and x.is_cuda:
+            # training on the GPU: BatchNorm + ReLU (+ the max over the neighbours) as fused HIP passes
+            from ... import bn_train
+            group = x.shape[-1] if pool_max and x.dim() == 4 else 0
+            if group and bn_train.supported(self.bn, x, group):
+                return bn_train.bn_relu(self.bn, x, self.relu is not None, group)
+            if bn_train.supported(self.bn, x):
+                x = bn_train.bn_relu(self.bn, x, self.relu is not None)
+                return torch.max(x, x.dim() - 1)[0] if pool_max else x
         if self.bn is not None:
             x = self.bn(x)
         if self.relu is not None:
             x = self.relu(x)
-        return x
+        return torch.max(x, x.dim() - 1)[0] if pool_max else x
 
     def init_weights(self, init_fn=None):
         if init_fn is not None:
@@ -73,11 +84,18 @@ class _Stack(nn.ModuleList):
     def _dropout(self, x):
         return F.dropout(x, p=self.dropout_prob, training=True)
 
-    def forward(self, x):
-        for block in self:
-            x = block(x)
-            if self.training and self.dropout_prob > 0.0:
+    def forward(self, x, pool_max=False):
+        """``pool_max``: return the max over the last axis of the stack's output (fused into the last block's
+        BatchNorm + ReLU pass when training on the GPU)."""
+        last = len(self) - 1
+        dropout = self.training and self.dropout_prob > 0.0
+        for i, block in enumerate(self):
+            fuse = pool_max and i == last and not dropout
+            x = block(x, pool_max=True) if fuse else block(x)
+            if dropout:
                 x = self._dropout(x)
+        if pool_max and (dropout or last < 0):
+            x = torch.max(x, x.dim() - 1)[0]
         return x
 
     def init_weights(self, init_fn=None):
