@@ -1,0 +1,70 @@
+"""Per-point (1x1) convolution of the shared-MLP blocks for TRAINING on the GPU, as plain GEMMs in the tensors' own
+channel-first layout (nn/modules/conv.py:20-36, :60-76: ``nn.Conv1d/2d(kernel_size=1, bias=False)``).
+
+Why not ``F.conv2d``: MIOpen computes the weight gradient of these layers with an NHWC implicit-GEMM kernel and therefore
+transposes the (B,C,L) activation and gradient tensors (up to 1.3 GB each) to channels-last and back on every call --
+measured 3.6 ms of ``batched_transpose`` + 5.4 ms of ``igemm_wrw`` per iteration at 4 scenes.  Both operands of
+dW[o,i] = sum_{b,l} dY[b,o,l] X[b,i,l] are already K-major in memory, so it is a batched GEMM over chunks of the point
+axis (split-K: the output is only C_out x C_in) followed by a small sum; forward and input gradient are one batched GEMM
+each.  Same values up to fp32 summation order.
+"""
+import os
+
+import torch
+
+ENABLED = os.environ.get("REGNET_CONV1X1_TRAIN", "1") != "0"
+
+
+def supported(conv, x):
+    if not (ENABLED and x.is_cuda and x.dtype == torch.float32 and x.dim() in (3, 4) and conv.bias is None):
+        return False
+    one = (1,) * (x.dim() - 2)
+    zero = (0,) * (x.dim() - 2)
+    return (tuple(conv.kernel_size) == one and tuple(conv.stride) == one and tuple(conv.dilation) == one
+            and tuple(conv.padding) == zero and conv.groups == 1 and x.numel() > 0)
+
+
+def _chunks(L, tiles, B):
+    """Number of point-axis chunks for the weight gradient: a power of two dividing L, enough (chunk x tile) GEMMs for
+    ~1000 workgroups, chunks of at least 1024 points."""
+    s = 1
+    while L % (2 * s) == 0 and L // (2 * s) >= 1024 and s * tiles * B < 1024:
+        s *= 2
+    return s
+
+
+class _Conv1x1(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w):
+        """x (B, Ci, L) contiguous, w (Co, Ci) -> (B, Co, L)."""
+        ctx.save_for_backward(x, w)
+        # bmm on the expanded weight, NOT torch.matmul: for (2-D, 3-D) operands matmul folds the batch by transposing the
+        # activation -- a full copy each way
+        return torch.bmm(w.unsqueeze(0).expand(x.shape[0], -1, -1), x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        B, Ci, L = x.shape
+        Co = w.shape[0]
+        dx = torch.bmm(w.t().unsqueeze(0).expand(B, -1, -1), dy) if ctx.needs_input_grad[0] else None
+        dw = None
+        if ctx.needs_input_grad[1]:
+            S = _chunks(L, ((Co + 127) // 128) * ((Ci + 127) // 128), B)
+            Ls = L // S
+            part = torch.empty((B, S, Co, Ci), dtype=torch.float32, device=x.device)
+            for b in range(B):
+                xs = x[b].view(Ci, S, Ls).permute(1, 2, 0)       # (S, Ls, Ci): a strided view, no copy
+                ds = dy[b].view(Co, S, Ls).transpose(0, 1)       # (S, Co, Ls)
+                torch.bmm(ds, xs, out=part[b])
+            dw = part.sum((0, 1)) if B * S > 1 else part.view(Co, Ci)
+        return dx, dw
+
+
+def conv1x1(conv, x):
+    """``conv(x)`` for a bias-free kernel-size-1 Conv1d / Conv2d; check ``supported`` first."""
+    B, Ci = x.shape[0], x.shape[1]
+    Co = conv.weight.shape[0]
+    y = _Conv1x1.apply(x.contiguous().view(B, Ci, -1), conv.weight.view(Co, Ci))
+    return y.view(B, Co, *x.shape[2:])

@@ -25,7 +25,12 @@ class _AffineBNReLU(nn.Module):
 
     def forward(self, x, pool_max=False):
         """``pool_max``: also take the max over the last axis (the set-abstraction reduction, modules.py:245)."""
-        x = getattr(self, self._affine_name)(x)
+        affine = getattr(self, self._affine_name)
+        if self.training and x.is_cuda and self._affine_name == "conv":
+            from ... import conv1x1_train
+            x = conv1x1_train.conv1x1(affine, x) if conv1x1_train.supported(affine, x) else affine(x)
+        else:
+            x = affine(x)
         if self.bn is not None and self.training and x.is_cuda:
             # training on the GPU: BatchNorm + ReLU (+ the max over the neighbours) as fused HIP passes
             from ... import bn_train

@@ -124,3 +124,28 @@ def test_prefetched_geometry_plan_gives_the_same_training_forward():
     trainer = ScoreTrainer(net)
     out = trainer.step(pc, target, plan=trainer.prefetch(pc))
     assert torch.isfinite(out)
+
+
+@pytest.mark.parametrize("shape,co", [((2, 6, 40, 64), 32), ((3, 259, 4096), 64), ((1, 128, 2048, 64), 128), ((2, 5, 77), 3)])
+def test_gemm_conv1x1_matches_torch_convolution(shape, co):
+    """conv1x1_train: the kernel-size-1 convolutions of the shared-MLP blocks as batched GEMMs (split over the point axis
+    for the weight gradient) == F.conv1d / F.conv2d, forward and both gradients."""
+    import torch.nn as nn
+    from regnet_for_3d_grasping_amd import conv1x1_train
+    torch.manual_seed(len(shape) + co)
+    conv = (nn.Conv2d if len(shape) == 4 else nn.Conv1d)(shape[1], co, 1, bias=False).to(DEV)
+    xa = torch.randn(shape, device=DEV, requires_grad=True)
+    xb = xa.detach().clone().requires_grad_(True)
+    assert conv1x1_train.supported(conv, xa)
+    assert not conv1x1_train.supported(nn.Conv1d(4, 4, 1).to(DEV), torch.zeros(1, 4, 8, device=DEV))   # biased: torch
+    ya = conv1x1_train.conv1x1(conv, xa)
+    up = torch.randn_like(ya)
+    ya.backward(up)
+    ga, conv.weight.grad = conv.weight.grad.clone(), None
+    yb = conv(xb)
+    yb.backward(up)
+    assert ya.is_contiguous() and ya.shape == yb.shape
+
+    def close(a, b):
+        assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max()))
+    close(ya, yb), close(xa.grad, xb.grad), close(ga, conv.weight.grad)
