@@ -227,6 +227,11 @@ def _cpu_model():
     return "unknown x%d" % (os.cpu_count() or 0)
 
 
+def _pts(n):
+    """25600 -> '25 600' (BASELINE.json writes the metric's point count that way)."""
+    return "{:,}".format(int(n)).replace(",", " ")
+
+
 def run_train(args, rank, world, dev):
     """configs[3-4]: K training iterations of ``train_step.RefineTrainer`` on this rank's scenes (synthetic labels)."""
     from regnet_for_3d_grasping_amd import pipeline, sharding, synthetic
@@ -272,7 +277,7 @@ def run_train(args, rank, world, dev):
     if rank == 0:
         grads = sum(p.numel() for net in (score_net, region_net) for p in net.parameters())
         print(json.dumps({
-            "metric": "train scenes/sec (25 600-pt ScoreNet+GRN+Refine training iteration)", "value": round(B * args.steps * world / dt, 3),
+            "metric": "train scenes/sec (%s-pt ScoreNet+GRN+Refine training iteration)" % _pts(N), "value": round(B * args.steps * world / dt, 3),
             "unit": "scenes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
@@ -374,7 +379,7 @@ def main():
                         "families_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in
                                                  sorted(fam.items(), key=lambda kv: -kv[1]["ms"])[:6]}}
         res = {
-            "metric": "scenes/sec (25 600-pt ScoreNet+GRN fwd)", "value": round(total_scenes / dt, 3),
+            "metric": "scenes/sec (%s-pt ScoreNet+GRN fwd)" % _pts(args.points), "value": round(total_scenes / dt, 3),
             "unit": "scenes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
