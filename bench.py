@@ -48,6 +48,11 @@ def parse():
     ap.add_argument("--train", action="store_true",
                     help="configs[3]: the reference's training iteration (forward with labels, losses, backward, two Adam "
                          "steps, one flat gradient all-reduce per network over RCCL) instead of the forward pipeline")
+    ap.add_argument("--exclusive-steps", type=int, default=48,
+                    help="with --mlp-streams > 1: extra steps (outside the timed region) with one feature-stage stream for "
+                         "per-kernel accounting (roofline_exclusive); 0 = skip")
+    ap.add_argument("--mlp-streams", type=int, default=2, help="feature-stage streams (batches whose MFMA kernels may overlap)")
+    ap.add_argument("--fps-streams", type=int, default=2, help="level-1 sampling launches in flight")
     ap.add_argument("--lookahead", type=int, default=3, help="batches whose region stage may be pending (pipeline depth)")
     return ap.parse_args()
 
@@ -288,6 +293,41 @@ def run_train(args, rank, world, dev):
                        "steps_with_region_losses": region_steps, "last_loss": float(loss)}}))
 
 
+def roofline_of(agg, steps, batch):
+    """OpTimer summary -> (kernel families, roofline object of the dominant one)."""
+    # kernel families: every mlp_layer / sa_layer1 launch is the same device kernel (mlp_gemm_kernel)
+    fam = {}
+    for (name, meta), (tot, cnt) in agg.items():
+        bound, units = algorithmic_work(name, meta)
+        key = KERNEL_OF.get(name, name)
+        f = fam.setdefault(key, {"ms": 0.0, "launches": 0, "units": 0, "bound": bound})
+        f["ms"] += tot
+        f["launches"] += cnt
+        f["units"] += units * cnt
+    if not fam:
+        return fam, None
+
+    # dominant = most GPU resource-time: a furthest-point-sampling launch keeps ONE CU per
+    # scene busy (a latency chain running beside the MLPs), every other kernel fills the chip
+    def cu_ms(k):
+        return fam[k]["ms"] * (min(1.0, batch / 256.0) if k == "fps_kernel" else 1.0)
+    dom = max(fam, key=cu_ms)
+    f = fam[dom]
+    avg_s = f["ms"] / f["launches"] / 1e3
+    per_launch = f["units"] / f["launches"]
+    if f["bound"] == "hbm":
+        achieved, peak, unit = per_launch / avg_s / 1e9, HBM_PEAK_GBS, "GB/s"
+    else:
+        achieved, peak, unit = per_launch / avg_s / 1e12, MFMA_F32_PEAK_TFLOPS, "TFLOP/s"
+    roofline = {"bound": f["bound"], "achieved": round(achieved, 4), "peak": peak, "unit": unit,
+                "frac": round(achieved / peak, 6), "traffic": pmc_traffic(dom), "kernel": dom,
+                "avg_launch_ms": round(f["ms"] / f["launches"], 4), "launches": f["launches"],
+                "algorithmic_units_per_launch": round(per_launch),
+                "families_ms_per_step": {k: round(v["ms"] / steps, 3) for k, v in
+                                         sorted(fam.items(), key=lambda kv: -kv[1]["ms"])[:6]}}
+    return fam, roofline
+
+
 def main():
     args = parse()
     from regnet_for_3d_grasping_amd import sharding
@@ -319,7 +359,8 @@ def main():
     # ForwardPipeline, which overlaps the geometry of the next batch, the MLPs of the current one
     # and the region stage of the previous one on three HIP streams (all work of the K timed
     # steps happens inside the timed region; the pipeline drains before the closing fence).
-    pipe = pipeline.ForwardPipeline(score_net, region_net, with_region=not args.score_only)
+    pipe = pipeline.ForwardPipeline(score_net, region_net, with_region=not args.score_only, fps_streams=args.fps_streams,
+                                    mlp_streams=args.mlp_streams)
 
     def run_steps(n):
         last = None
@@ -341,43 +382,39 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     timer.enabled = False
+    main_summary = timer.summary() if rank == 0 else None
     dt = sharding.max_over_ranks(dt, dev)
+
+    exclusive = None
+    if args.mlp_streams > 1 and world == 1 and args.exclusive_steps > 0:
+        # per-kernel accounting without feature stages overlapping each other: a short extra pass (outside the timed
+        # region) through a pipeline with ONE feature-stage stream, same scenes, same event bracketing
+        timer.records, timer.calls = [], {}
+        pipe1 = pipeline.ForwardPipeline(score_net, region_net, with_region=not args.score_only,
+                                         fps_streams=args.fps_streams, mlp_streams=1)
+        for _ in pipe1.run((pc for _ in range(4)), max_pending_regions=args.lookahead):
+            pass
+        torch.cuda.synchronize()
+        timer.enabled = True
+        t1 = time.perf_counter()
+        for _ in pipe1.run((pc for _ in range(args.exclusive_steps)), max_pending_regions=args.lookahead):
+            pass
+        torch.cuda.synchronize()
+        dt1 = time.perf_counter() - t1
+        timer.enabled = False
+        exclusive = (timer.summary(), dt1)
 
     if rank == 0:
         total_scenes = args.batch * args.steps * world
-        agg = timer.summary()
+        agg = main_summary
         by_time = sorted(agg.items(), key=lambda kv: -kv[1][0])
         kernels = [{"op": k[0], "shape": k[1], "calls": c, "avg_ms": round(tot / c, 4), "total_ms": round(tot, 3)}
                    for k, (tot, c) in by_time]
-        # kernel families: every mlp_layer / sa_layer1 launch is the same device kernel (mlp_gemm_kernel)
-        fam = {}
-        for (name, meta), (tot, cnt) in agg.items():
-            bound, units = algorithmic_work(name, meta)
-            key = KERNEL_OF.get(name, name)
-            f = fam.setdefault(key, {"ms": 0.0, "launches": 0, "units": 0, "bound": bound})
-            f["ms"] += tot
-            f["launches"] += cnt
-            f["units"] += units * cnt
-        roofline = None
-        if fam:
-            # dominant = most GPU resource-time: a furthest-point-sampling launch keeps ONE CU per
-            # scene busy (a latency chain running beside the MLPs), every other kernel fills the chip
-            def cu_ms(k):
-                return fam[k]["ms"] * (min(1.0, args.batch / 256.0) if k == "fps_kernel" else 1.0)
-            dom = max(fam, key=cu_ms)
-            f = fam[dom]
-            avg_s = f["ms"] / f["launches"] / 1e3
-            per_launch = f["units"] / f["launches"]
-            if f["bound"] == "hbm":
-                achieved, peak, unit = per_launch / avg_s / 1e9, HBM_PEAK_GBS, "GB/s"
-            else:
-                achieved, peak, unit = per_launch / avg_s / 1e12, MFMA_F32_PEAK_TFLOPS, "TFLOP/s"
-            roofline = {"bound": f["bound"], "achieved": round(achieved, 4), "peak": peak, "unit": unit,
-                        "frac": round(achieved / peak, 6), "traffic": pmc_traffic(dom), "kernel": dom,
-                        "avg_launch_ms": round(f["ms"] / f["launches"], 4), "launches": f["launches"],
-                        "algorithmic_units_per_launch": round(per_launch),
-                        "families_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in
-                                                 sorted(fam.items(), key=lambda kv: -kv[1]["ms"])[:6]}}
+        fam, roofline = roofline_of(agg, args.steps, args.batch)
+        if roofline and args.mlp_streams > 1:
+            roofline["concurrency"] = ("%d feature-stage streams: launches of this family overlap each other, so the launch "
+                                       "duration above (what rocprofv3 shows too) includes time-sharing; roofline_exclusive "
+                                       "is the same measurement with one feature-stage stream" % args.mlp_streams)
         res = {
             "metric": "scenes/sec (%s-pt ScoreNet+GRN fwd)" % _pts(args.points), "value": round(total_scenes / dt, 3),
             "unit": "scenes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -392,10 +429,19 @@ def main():
                        "executed_gflop_per_scene": round(sum(f["units"] for f in fam.values() if f["bound"] == "mfma")
                                                          / 1e9 / max(args.steps * args.batch, 1), 2)},
             "roofline": roofline,
+            "roofline_exclusive": None,
             "mlp_tflops": round(SCORENET_GFLOP_PER_SCENE.get(args.points, 0.0) * total_scenes / world / dt / 1e3, 3),
             "kernels": kernels[:40],
             "grasps_last_step": int(out["next_grasp"].shape[0]) if "next_grasp" in out else None,
         }
+        if exclusive is not None:
+            _, r1 = roofline_of(exclusive[0], args.exclusive_steps, args.batch)
+            if r1:
+                r1["steps"] = args.exclusive_steps
+                r1["scenes_per_s_in_this_mode"] = round(args.batch * args.exclusive_steps / exclusive[1], 1)
+            res["roofline_exclusive"] = r1
+        else:
+            res.pop("roofline_exclusive")
         if world == 1 and args.cpu_scenes > 0:
             res["cpu_baseline"] = cpu_baseline(args, args.cpu_scenes, (score_net, region_net))
             res["parity"] = res["cpu_baseline"].pop("parity")

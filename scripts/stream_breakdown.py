@@ -28,3 +28,14 @@ print("queue %s: %d steps, %.3f ms/step span; MFMA kernels %.3f, other kernels %
       (q, steps, span / 1e6 / steps, mf / 1e6 / steps, sum(other.values()) / 1e6 / steps, gaps / 1e6 / steps, len(qs) // steps))
 for n, v in other.most_common(12):
     print("   %7.3f ms/step  %s" % (v / 1e6 / steps, n))
+# where the idle gaps of that queue sit: by position in the step (index of the kernel that follows the gap)
+per_pos = collections.defaultdict(list)
+pos = 0
+for i in range(len(qs) - 1):
+    if "sa_chain_kernel" in qs[i][2]:
+        pos = 0
+    pos += 1
+    per_pos[(pos, qs[i][2].split("(")[0][:28], qs[i + 1][2].split("(")[0][:28])].append(max(0, qs[i + 1][0] - qs[i][1]))
+print("largest average gaps (us) by position after the level-1 block: (position, kernel before, kernel after)")
+for k, v in sorted(per_pos.items(), key=lambda kv: -sum(kv[1]) / max(1, steps))[:12]:
+    print("   %6.1f us avg  max %7.1f  n=%d  %s" % (sum(v) / len(v) / 1e3, max(v) / 1e3, len(v), k))
