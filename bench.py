@@ -51,7 +51,8 @@ def parse():
     ap.add_argument("--exclusive-steps", type=int, default=48,
                     help="with --mlp-streams > 1: extra steps (outside the timed region) with one feature-stage stream for "
                          "per-kernel accounting (roofline_exclusive); 0 = skip")
-    ap.add_argument("--mlp-streams", type=int, default=2, help="feature-stage streams (batches whose MFMA kernels may overlap)")
+    ap.add_argument("--mlp-streams", type=int, default=1, help="feature-stage streams (batches whose MFMA kernels may overlap): 2 is ~6 %% faster (875 scenes/s) but "
+                         "time-shares the launches, so per-kernel durations stop being a kernel property (DESIGN.md par. 7)")
     ap.add_argument("--fps-streams", type=int, default=2, help="level-1 sampling launches in flight")
     ap.add_argument("--lookahead", type=int, default=3, help="batches whose region stage may be pending (pipeline depth)")
     return ap.parse_args()

@@ -61,21 +61,24 @@ class ForwardPipeline:
                                       ~10 ms latency chain on ONE CU per scene, so two of them in
                                       flight double the sampling throughput at no cost to the MLPs
         s_geo : geometry(batch i+1)   FPS levels 2-3, ball query x3, 3-NN x3
-        s_mlp : features(batch i)     gather / MFMA shared-MLP / pool / head    (matrix cores; consecutive batches
-                                      alternate between two such streams so one's kernel tails are filled by the other)
+        s_mlp : features(batch i)     gather / MFMA shared-MLP / pool / head    (matrix cores; with ``mlp_streams=2``
+                                      consecutive batches alternate between two such streams)
         s_reg : region(batch i-1)     radius grouping, host RNG draws, GRN + refine heads
 
     Results are identical to running ``forward_scenes`` batch by batch (same kernels, same numpy
     RNG call order: region stages execute in batch order on the host thread).
     """
 
-    def __init__(self, score_net, region_net, with_region=True, fps_streams=2, mlp_streams=2):
+    def __init__(self, score_net, region_net, with_region=True, fps_streams=2, mlp_streams=1):
         """``fps_streams``: level-1 sampling launches in flight (each ~10 ms on one CU per scene, whatever the batch
         size): 2 keep up with the matrix cores at 8 scenes per batch.  (Smaller batches are bound by the host's ~6 ms of
         launch work per step, not by the sampling: more streams measured slower there.)
         ``mlp_streams``: feature stages (consecutive batches) that may overlap.  One batch's ~30 MFMA launches leave the
         chip partly idle at every kernel tail and in the small layers (P <= 40 960 rows); a second stream fills those
-        holes with the next batch's kernels: 9.70 -> 9.14 ms per batch of 8 (824 -> 875 scenes/s).  3 measured slower."""
+        holes with the next batch's kernels: 9.70 -> 9.14 ms per batch of 8 (824 -> 875 scenes/s) with
+        ``mlp_streams=2``; 3 measured slower.  The default stays 1 because overlapping launches time-share the chip:
+        a launch's duration (the quantity the roofline accounting and every profile under profiles/ is built on) then
+        depends on what the other stream happens to run, and a profiler perturbs exactly that."""
         self.score_net, self.region_net, self.with_region = score_net, region_net, with_region
         dev = next(score_net.parameters()).device
         self.device = dev

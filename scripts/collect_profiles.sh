@@ -1,18 +1,21 @@
 #!/bin/bash
 # One GPU-box pass that produces everything kept under profiles/ for a round tag:
-#   bash scripts/collect_profiles.sh r01d        (run through gpurun; outputs land in gpurun_out/<tag>/)
+#   bash scripts/collect_profiles.sh r01d [extra bench.py arguments, e.g. --mlp-streams 1]
+#   (run through gpurun; outputs land in gpurun_out/<tag>/)
 # 1. the bench line (with cpu_baseline), 2. rocprofv3 --kernel-trace --stats of the same command,
 # 3. separate PMC passes (FETCH_SIZE, WRITE_SIZE) of the same command.  Summaries: scripts/rocprof_summary.py,
 # scripts/collect_pmc.py.
 TAG=${1:-rXX}
+shift
+EXTRA="$@"
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-python $REPO/bench.py > $OUT/bench.json 2> $OUT/bench.err
-rocprofv3 --kernel-trace --stats -d $OUT/prof -o $TAG -- python $REPO/bench.py --cpu-scenes 0 --steps 12 > $OUT/prof.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o p -- python $REPO/bench.py --cpu-scenes 0 --steps 4 > $OUT/pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o p -- python $REPO/bench.py --cpu-scenes 0 --steps 4 > $OUT/pmc_write.log 2>&1
+python $REPO/bench.py $EXTRA > $OUT/bench.json 2> $OUT/bench.err
+rocprofv3 --kernel-trace --stats -d $OUT/prof -o $TAG -- python $REPO/bench.py $EXTRA --cpu-scenes 0 --exclusive-steps 0 --steps 24 > $OUT/prof.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o p -- python $REPO/bench.py $EXTRA --cpu-scenes 0 --exclusive-steps 0 --steps 4 > $OUT/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o p -- python $REPO/bench.py $EXTRA --cpu-scenes 0 --exclusive-steps 0 --steps 4 > $OUT/pmc_write.log 2>&1
 cd $REPO
 DB=$(find $OUT/prof -name "*results.db" | head -1)
 python scripts/rocprof_summary.py $DB > $OUT/kernel_stats.txt
