@@ -1,4 +1,4 @@
-"""ForwardPipeline (3 HIP streams, batches in flight) must return exactly what the sequential
+"""ForwardPipeline (six or seven HIP streams, four batches in flight; one or two feature-stage streams) must return exactly what the sequential
 forward returns for the same batches and numpy seed."""
 import numpy as np
 import pytest
@@ -8,7 +8,8 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def test_pipeline_equals_sequential():
+@pytest.mark.parametrize("mlp_streams", [1, 2])
+def test_pipeline_equals_sequential(mlp_streams):
     from regnet_for_3d_grasping_amd import pipeline, synthetic
     score_net, region_net = pipeline.build_models(DEV)
     batches = [synthetic.make_batch(3000 + 10 * i, 2, 6144, device=DEV) for i in range(4)]
@@ -17,7 +18,7 @@ def test_pipeline_equals_sequential():
     want = [pipeline.forward_scenes(score_net, region_net, pc) for pc in batches]
     torch.cuda.synchronize()
     np.random.seed(77)
-    pipe = pipeline.ForwardPipeline(score_net, region_net)
+    pipe = pipeline.ForwardPipeline(score_net, region_net, mlp_streams=mlp_streams)
     got = list(pipe.run(iter(batches)))
     torch.cuda.synchronize()
     assert len(got) == len(want)
