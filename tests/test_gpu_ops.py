@@ -247,6 +247,29 @@ def test_interpolate_forward_backward(ext, orc):
     torch.testing.assert_close(gb, orc.interpolate_backward(g, idx, w, M), rtol=0, atol=2e-5)
 
 
+@pytest.mark.parametrize("B,C,N1,N2,K", [(2, 9, 5120, 1024, 64), (1, 130, 36864, 300, 8), (2, 5, 40000, 700, 16),
+                                         (3, 1, 7, 5, 3)])
+def test_group_points_backward_row_lengths(ext, orc, B, C, N1, N2, K):
+    """K4 (grouping_kernel.cu:54-93) through both implementations: output rows that fit the LDS accumulators
+    (N1 <= 36 864) and the global-atomic fallback beyond; gradient given as a non-contiguous view."""
+    rng = np.random.default_rng(N1 + K)
+    idx = torch.from_numpy(rng.integers(0, N1, (B, N2, K)))
+    g = torch.from_numpy(rng.normal(size=(B, N2, K, C)).astype(np.float32)).permute(0, 3, 1, 2)   # (B,C,N2,K) view
+    gb = ext.group_points_backward(g.to(DEV), idx.to(DEV), N1).cpu()
+    torch.testing.assert_close(gb, orc.group_points_backward(g.contiguous(), idx, N1), rtol=0, atol=5e-5)
+
+
+@pytest.mark.parametrize("B,C,M,N", [(2, 64, 5120, 25600), (1, 33, 36864, 5000), (2, 6, 40000, 9000), (2, 3, 3, 11)])
+def test_interpolate_backward_row_lengths(ext, orc, B, C, M, N):
+    """K7 (interpolate_kernel.cu:239-282): LDS-accumulator path (M <= 36 864) and the global-atomic fallback."""
+    rng = np.random.default_rng(M + N)
+    idx = torch.from_numpy(rng.integers(0, M, (B, N, 3)))
+    w = torch.from_numpy(rng.dirichlet(np.ones(3), (B, N)).astype(np.float32))
+    g = torch.from_numpy(rng.normal(size=(B, N, C)).astype(np.float32)).transpose(1, 2)           # (B,C,N) view
+    gb = ext.interpolate_backward(g.to(DEV), idx.to(DEV), w.to(DEV), M).cpu()
+    torch.testing.assert_close(gb, orc.interpolate_backward(g.contiguous(), idx, w, M), rtol=0, atol=5e-5)
+
+
 def test_empty_and_error_cases(ext):
     x = torch.zeros(2, 3, 10, device=DEV)
     with pytest.raises(RuntimeError):
