@@ -62,6 +62,11 @@ class _Conv1x1(torch.autograd.Function):
         return dx, dw
 
 
+def gemm_conv(x, w):
+    """x (B, Ci, L) contiguous, w (Co, Ci) -> (B, Co, L): the autograd GEMM convolution itself."""
+    return _Conv1x1.apply(x, w)
+
+
 def conv1x1(conv, x):
     """``conv(x)`` for a bias-free kernel-size-1 Conv1d / Conv2d; check ``supported`` first."""
     B, Ci = x.shape[0], x.shape[1]

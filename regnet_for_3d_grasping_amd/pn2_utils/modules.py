@@ -16,6 +16,11 @@ from .functions.gather_knn import gather_knn
 from .nn import SharedMLP
 
 
+# Training on the GPU: evaluate a block's first (linear) layer before the gather / interpolation it commutes with
+# (_SetAbstraction._premul_first_layer, PointnetFPModule._premul_first_layer).  Tests switch it off for A/B comparisons.
+TRAIN_PREMUL = True
+
+
 class FarthestPointSampler(nn.Module):
     """xyz (B,3,N) -> (B,num_centroids) int64, under no_grad (modules.py:11-29)."""
 
@@ -162,6 +167,29 @@ class _SetAbstraction(nn.Module):
     def _reduce(self, x):
         return torch.max(x, 3)[0]
 
+    def _premul_first_layer(self, xyz, feature, new_xyz, index):
+        """Training on the GPU, wide inputs: the first shared-MLP layer is linear in [x_j - c | f_j], so
+        W [x_j - c ; f_j] = (W [x_j ; f_j]) - (W_xyz c): evaluate it once per SOURCE point (U) and once per centroid (V)
+        and group the products, instead of grouping the (3 + C)-wide input and multiplying every (centroid, neighbour)
+        pair -- the (B, 3 + C, M, K) tensor, its concatenation copy and its gradient are never formed, and the GEMM
+        (forward, input gradient, weight gradient) runs on N rows instead of M * K.  Same values up to fp32
+        reassociation; returns the first convolution's output (B, C1, M, K) or None when this does not apply."""
+        if not (TRAIN_PREMUL and self.training and xyz.is_cuda and feature is not None and self.use_xyz
+                and type(self.grouper) is QueryGrouper and feature.shape[1] >= 32 and len(self.mlp) > 0):
+            return None
+        from .. import conv1x1_train
+        block = self.mlp[0]
+        conv = getattr(block, "conv", None)
+        if conv is None or not conv1x1_train.supported(conv, feature.unsqueeze(-1)) or conv.weight.shape[1] != 3 + feature.shape[1]:
+            return None
+        W = conv.weight.view(conv.weight.shape[0], -1)                     # columns: [xyz | feature] (modules.py:52)
+        src = torch.cat([xyz, feature], dim=1).contiguous()                # (B, 3 + C, N): source points, not groups
+        U = conv1x1_train.gemm_conv(src, W)                                # (B, C1, N)
+        V = conv1x1_train.gemm_conv(new_xyz.contiguous(), W[:, :3].contiguous())   # (B, C1, M)
+        Y = _F.group_points(U, index)
+        Y -= V.unsqueeze(-1)
+        return Y
+
     def _mlp_reduce(self, group_feature):
         """SharedMLP then the reduction over the K neighbours (modules.py:244-245)."""
         if type(self)._reduce is _SetAbstraction._reduce:
@@ -172,12 +200,23 @@ class _SetAbstraction(nn.Module):
         """``geo``: dict(new_xyz, nbr) of ``fused.sa_geometry`` when sampling and ball query ran ahead of time."""
         if self.num_centroids == 0:
             new_xyz, group_feature = self._global_group(xyz, feature)
-        elif geo is not None and type(self.grouper) is QueryGrouper:
-            new_xyz = geo["new_xyz"]
-            group_feature, _ = self.grouper(new_xyz, xyz, feature, use_xyz=self.use_xyz, index=geo["nbr"])
         else:
-            _, new_xyz = self._sample(xyz)
-            group_feature, _ = self.grouper(new_xyz, xyz, feature, use_xyz=self.use_xyz)
+            index = None
+            if geo is not None and type(self.grouper) is QueryGrouper:
+                new_xyz, index = geo["new_xyz"], geo["nbr"]
+            else:
+                _, new_xyz = self._sample(xyz)
+            if type(self.grouper) is QueryGrouper and type(self)._reduce is _SetAbstraction._reduce:
+                if index is None and self.training and xyz.is_cuda:
+                    with torch.no_grad():
+                        index, _ = _F.ball_query(xyz, new_xyz, self.grouper.radius, self.grouper.num_neighbours)
+                first = self._premul_first_layer(xyz, feature, new_xyz, index) if index is not None else None
+                if first is not None:
+                    return new_xyz, self.mlp(first, pool_max=True, first_affine_done=True)
+            if index is not None:
+                group_feature, _ = self.grouper(new_xyz, xyz, feature, use_xyz=self.use_xyz, index=index)
+            else:
+                group_feature, _ = self.grouper(new_xyz, xyz, feature, use_xyz=self.use_xyz)
         return new_xyz, self._mlp_reduce(group_feature)
 
     def init_weights(self, init_fn=None):
@@ -314,9 +353,35 @@ class PointnetFPModule(nn.Module):
         from .. import fused
         if fused.usable(self, dense_xyz) and fused.supports_fp(self, sparse_feature):
             return fused.fp_forward(self, dense_xyz, sparse_xyz, dense_feature, sparse_feature, geo)
+        first = self._premul_first_layer(dense_xyz, sparse_xyz, dense_feature, sparse_feature, geo)
+        if first is not None:
+            return self.mlp(first, first_affine_done=True)
         if geo is not None and type(self.interpolator) is FeatureInterpolator:
             return self.mlp(self.interpolator(dense_xyz, sparse_xyz, dense_feature, sparse_feature, geo))
         return self.mlp(self.interpolator(dense_xyz, sparse_xyz, dense_feature, sparse_feature))
+
+    def _premul_first_layer(self, dense_xyz, sparse_xyz, dense_feature, sparse_feature, geo):
+        """Training on the GPU: the first layer is linear in [interpolated | skip] and the 3-NN interpolation is linear
+        in the features, so multiply the SPARSE points (and the skip features by their own weight columns) and
+        interpolate the products: the GEMM runs on N_sparse rows and the interpolated tensor is C1 wide instead of
+        C_sparse.  Same values up to fp32 reassociation; None when it does not apply or would not pay."""
+        if not (TRAIN_PREMUL and self.training and dense_xyz.is_cuda and type(self.interpolator) is FeatureInterpolator
+                and len(self.mlp) > 0):
+            return None
+        from .. import conv1x1_train
+        conv = getattr(self.mlp[0], "conv", None)
+        Cs = sparse_feature.shape[1]
+        Cd = 0 if dense_feature is None else dense_feature.shape[1]
+        if (conv is None or not conv1x1_train.supported(conv, sparse_feature) or conv.weight.shape[1] != Cs + Cd
+                or sparse_feature.shape[2] >= dense_xyz.shape[2] or conv.weight.shape[0] > Cs):
+            return None
+        W = conv.weight.view(conv.weight.shape[0], -1)                     # columns: [interpolated | skip] (modules.py:127)
+        index, weight = _three_nn_weights(dense_xyz, sparse_xyz, self.interpolator.num_neighbors, self.interpolator._eps, geo)
+        Ys = conv1x1_train.gemm_conv(sparse_feature.contiguous(), W[:, :Cs].contiguous())
+        Y = _F.feature_interpolate(Ys, index, weight)
+        if Cd:
+            Y = Y + conv1x1_train.gemm_conv(dense_feature.contiguous(), W[:, Cs:].contiguous())
+        return Y
 
     def init_weights(self, init_fn=None):
         self.mlp.init_weights(init_fn)

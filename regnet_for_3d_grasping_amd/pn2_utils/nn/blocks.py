@@ -31,6 +31,11 @@ class _AffineBNReLU(nn.Module):
             x = conv1x1_train.conv1x1(affine, x) if conv1x1_train.supported(affine, x) else affine(x)
         else:
             x = affine(x)
+        return self.after_affine(x, pool_max)
+
+    def after_affine(self, x, pool_max=False):
+        """BatchNorm -> ReLU (-> max over the last axis) of the block, given the affine layer's output.  Callers that
+        evaluate the (linear) affine layer before a gather / interpolation enter here."""
         if self.bn is not None and self.training and x.is_cuda:
             # training on the GPU: BatchNorm + ReLU (+ the max over the neighbours) as fused HIP passes
             from ... import bn_train
@@ -89,14 +94,18 @@ class _Stack(nn.ModuleList):
     def _dropout(self, x):
         return F.dropout(x, p=self.dropout_prob, training=True)
 
-    def forward(self, x, pool_max=False):
+    def forward(self, x, pool_max=False, first_affine_done=False):
         """``pool_max``: return the max over the last axis of the stack's output (fused into the last block's
-        BatchNorm + ReLU pass when training on the GPU)."""
+        BatchNorm + ReLU pass when training on the GPU).  ``first_affine_done``: ``x`` already is the output of the
+        first block's convolution (evaluated by the caller before a gather / interpolation, which it commutes with)."""
         last = len(self) - 1
         dropout = self.training and self.dropout_prob > 0.0
         for i, block in enumerate(self):
             fuse = pool_max and i == last and not dropout
-            x = block(x, pool_max=True) if fuse else block(x)
+            if i == 0 and first_affine_done:
+                x = block.after_affine(x, pool_max=fuse)
+            else:
+                x = block(x, pool_max=True) if fuse else block(x)
             if dropout:
                 x = self._dropout(x)
         if pool_max and (dropout or last < 0):

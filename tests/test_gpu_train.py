@@ -149,3 +149,41 @@ def test_gemm_conv1x1_matches_torch_convolution(shape, co):
     def close(a, b):
         assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max()))
     close(ya, yb), close(xa.grad, xb.grad), close(ga, conv.weight.grad)
+
+
+def test_training_first_layer_before_gather_matches_plain_path():
+    """modules.TRAIN_PREMUL: SA / FP blocks evaluate their first layer per source / sparse point and gather /
+    interpolate the products; outputs, running statistics and every gradient must equal the plain operator path
+    (group -> concat -> conv) up to fp32 reassociation."""
+    import copy
+    from regnet_for_3d_grasping_amd.pn2_utils import modules
+    torch.manual_seed(3)
+    B, N = 2, 2048
+    xyz = torch.rand(B, 3, N, device=DEV)
+    feat = torch.randn(B, 64, N, device=DEV)
+
+    def close(a, b, tol=3e-5):
+        a, b = a.detach(), b.detach()
+        assert float((a - b).abs().max()) <= tol * max(1.0, float(b.abs().max())), float((a - b).abs().max())
+
+    sa = modules.PointNetSAModule(64, (64, 64, 128), 256, 0.2, 64, True).to(DEV).train()
+    fp = modules.PointnetFPModule(128 + 64, (96, 64), 3).to(DEV).train()
+    sa0, fp0 = copy.deepcopy(sa), copy.deepcopy(fp)
+    outs = []
+    for flag, (s_, f_) in ((True, (sa, fp)), (False, (sa0, fp0))):
+        modules.TRAIN_PREMUL = flag
+        try:
+            fa = feat.clone().requires_grad_(True)
+            new_xyz, pooled = s_(xyz, fa)
+            dense = f_(xyz, new_xyz, fa, pooled)
+            (dense.square().mean() + pooled.mean()).backward()
+            outs.append((pooled, dense, fa.grad))
+        finally:
+            modules.TRAIN_PREMUL = True
+    for a, b in zip(*outs):
+        close(a, b)
+    for m, m0 in ((sa, sa0), (fp, fp0)):
+        for (k, p), (_, q) in zip(m.named_parameters(), m0.named_parameters()):
+            close(p.grad, q.grad, 1e-4)
+        for (k, p), (_, q) in zip(m.named_buffers(), m0.named_buffers()):
+            close(p.float(), q.float())
