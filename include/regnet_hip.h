@@ -218,6 +218,18 @@ int regnet_pack_rows_f32(const float* feat, int64_t fb, int64_t fc, int64_t fn, 
                          int64_t xb, int64_t xc, int64_t xn, int64_t B, int64_t N, int64_t W, float* out,
                          void* stream);
 
+/* regnet_grasp_collision_counts_f32: the per-grasp point scan of the view-cloud collision filter that test.py:147 applies to
+ * the predicted grasps (utils.py:391-401 -> dataset_utils/eval_score/eval.py:4-12 -> eval_utils/
+ * evaluation_data_generator.py:198-229, EvalDataTest.finger_hand_view; constants: eval_score/configs/config.py).
+ * points: N rows, element strides (pn, pc) for (point, coordinate); T (B,4,4) row-major global->local matrices
+ * (:91-93).  For grasp b and local coordinates (x,y,z) = T[b] (p,1), counts[b] = { #(x_lo < x < x_hi),
+ *   #(... and |y| < half_width and x < back_x and |z| < half_thickness),
+ *   #(... and |z| < half_thickness and half_space < |y| < half_width) } (all comparisons strict).
+ * The caller applies the reference's thresholds (:203, :218, :229).  fp32, individually rounded, no contraction.   */
+int regnet_grasp_collision_counts_f32(const float* points, int64_t pn, int64_t pc, int64_t N, const float* T, int64_t B,
+                                      float x_lo, float x_hi, float half_thickness, float half_width, float half_space,
+                                      float back_x, int32_t* counts, void* stream);
+
 /* regnet_bn_relu_train_fwd_f32 / _bwd_f32: TRAINING-mode BatchNorm (+ ReLU, + max over the K neighbours) of a shared-MLP
  * block -- nn/modules/conv.py:30-36, :70-76 (bn then relu after the bias-free 1x1 convolution) and the set-abstraction
  * reduction torch.max(new_feature, 3) of modules.py:245 -- as two HBM passes each way instead of torch's 13-18.

@@ -216,6 +216,75 @@ extern "C" int regnet_box_crop_f32(const float* group_points, int64_t gb, int64_
   return REGNET_OK;
 }
 
+// Collision scan of predicted grasps against the view cloud (test.py:147 -> utils.py:391-401 -> eval_score/eval.py:4-12
+// -> evaluation_data_generator.py:188-236, EvalDataTest.finger_hand_view).  The reference loops over the grasps in
+// Python and, for each, multiplies the whole cloud by the grasp's 4x4 global->local matrix and builds five boolean
+// masks with torch ops (~25 launches and a host sync per grasp; 4000 grasps per scene in test.py).  Here: one workgroup
+// per grasp walks the cloud once and counts the points (0) in the closing slab -bottom < x < depth, (1) behind the hand,
+// (2) inside either finger -- the three numbers the reference's thresholds are applied to.  Arithmetic: individually
+// rounded fp32 in source order, x = ((t00*px + t01*py) + t02*pz) + t03 (this file is built with -ffp-contract=off), the
+// same as oracle/collision_oracle.py.
+#define GC_T 256
+__global__ __launch_bounds__(GC_T) void grasp_collision_kernel(const float* __restrict__ points, int64_t pn, int64_t pc,
+                                                               int N, const float* __restrict__ T, float x_lo,
+                                                               float x_hi, float half_thickness, float half_width,
+                                                               float half_space, float back_x,
+                                                               int32_t* __restrict__ counts) {
+  const float* t = T + (int64_t)blockIdx.x * 16;
+  const float t00 = t[0], t01 = t[1], t02 = t[2], t03 = t[3];
+  const float t10 = t[4], t11 = t[5], t12 = t[6], t13 = t[7];
+  const float t20 = t[8], t21 = t[9], t22 = t[10], t23 = t[11];
+  int c_close = 0, c_back = 0, c_finger = 0;
+  for (int j = threadIdx.x; j < N; j += GC_T) {
+    const float* p = points + (int64_t)j * pn;
+    const float px = p[0], py = p[pc], pz = p[2 * pc];
+    const float x = ((t00 * px + t01 * py) + t02 * pz) + t03;
+    const bool close = x > x_lo && x < x_hi;
+    if (!close) continue;
+    const float y = ((t10 * px + t11 * py) + t12 * pz) + t13;
+    const float z = ((t20 * px + t21 * py) + t22 * pz) + t23;
+    const bool zc = z < half_thickness && z > -half_thickness;
+    const bool back = y < half_width && y > -half_width && x < back_x && zc;
+    const bool finger = zc && ((y < half_width && y > half_space) || (y > -half_width && y < -half_space));
+    c_close += 1;
+    c_back += back;
+    c_finger += finger;
+  }
+  __shared__ int red[3][GC_T / 64];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    c_close += __shfl_xor(c_close, o);
+    c_back += __shfl_xor(c_back, o);
+    c_finger += __shfl_xor(c_finger, o);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = c_close;
+    red[1][threadIdx.x >> 6] = c_back;
+    red[2][threadIdx.x >> 6] = c_finger;
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    int v = 0;
+#pragma unroll
+    for (int w = 0; w < GC_T / 64; ++w) v += red[threadIdx.x][w];
+    counts[(int64_t)blockIdx.x * 3 + threadIdx.x] = v;
+  }
+}
+
+extern "C" int regnet_grasp_collision_counts_f32(const float* points, int64_t pn, int64_t pc, int64_t N, const float* T,
+                                                 int64_t B, float x_lo, float x_hi, float half_thickness,
+                                                 float half_width, float half_space, float back_x, int32_t* counts,
+                                                 void* stream) {
+  if (N < 0 || B < 0) return REGNET_ERR_SHAPE;
+  if (N >= (int64_t)1 << 31 || B >= (int64_t)1 << 31) return REGNET_ERR_UNSUPPORTED;
+  if (B == 0) return REGNET_OK;
+  if (!T || !counts || (N > 0 && !points)) return REGNET_ERR_NULL;
+  hipLaunchKernelGGL(grasp_collision_kernel, dim3((unsigned)B), dim3(GC_T), 0, as_stream(stream), points, pn, pc, (int)N, T,
+                     x_lo, x_hi, half_thickness, half_width, half_space, back_x, counts);
+  REGNET_LAUNCH_CHECK();
+  return REGNET_OK;
+}
+
 // out[r, ch] = max_g feat[rows[r, g], ch]: the grouped-feature gather fused with MaxPool1d(G).
 // feat is (num_rows, F) row-major (= all_feature.view(B*N, F)); one workgroup per output row,
 // threads across channels so every gathered row is one coalesced F*4-byte read.

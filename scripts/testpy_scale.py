@@ -3,7 +3,7 @@ python testpy_scale.py [N]"""
 import contextlib, io, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from regnet_for_3d_grasping_amd import pipeline, synthetic
+from regnet_for_3d_grasping_amd import eval_collision, pipeline, synthetic
 from regnet_for_3d_grasping_amd.get_regiondataset import get_grasp_allobj
 dev = "cuda:0"
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 25600
@@ -23,8 +23,10 @@ def run():
         torch.cuda.synchronize(); t["centres + grouping"] = time.perf_counter() - t0; t0 = time.perf_counter()
         with contextlib.redirect_stdout(io.StringIO()):
             res = region_net(g[3], g[5], g[2], g[4], g[0], g[1], pc, all_feature, pipeline.GRIPPER_PARAMS, None, [])
-        torch.cuda.synchronize(); t["region_net + refine"] = time.perf_counter() - t0
-    return t, int((score > 0.5).sum()), res
+        torch.cuda.synchronize(); t["region_net + refine"] = time.perf_counter() - t0; t0 = time.perf_counter()
+        kept = eval_collision.eval_test(pc[0, :, :3], res[0][:, :8], None, 0.75, pipeline.DEPTH, pipeline.WIDTH, 0)
+        torch.cuda.synchronize(); t["collision filter (test.py:147)"] = time.perf_counter() - t0
+    return t, int((score > 0.5).sum()), (res[0], kept)
 for _ in range(2): run()
 # per-call detail of the grouping stage (each wrapped call is followed by a device sync)
 from regnet_for_3d_grasping_amd import get_regiondataset as G, np_random, region_ops
@@ -48,6 +50,7 @@ acc = {}
 for _ in range(5):
     t, npos, res = run()
     for k, v in t.items(): acc[k] = acc.get(k, 0) + v / 5
-print("N=%d, %d points score > 0.5, %d centres, %d grasps after refine" % (N, npos, params[0], res[0].shape[0]))
+print("N=%d, %d points score > 0.5, %d centres, %d grasps after refine, %d without collision" %
+      (N, npos, params[0], res[0].shape[0], res[1].shape[0]))
 for k, v in acc.items(): print("%-24s %8.2f ms" % (k, v * 1e3))
 print("%-24s %8.2f ms" % ("total", sum(acc.values()) * 1e3))
