@@ -66,12 +66,14 @@ def test_reference_import_paths_resolve_here():
     for name in ("pn2_ext", "dgcnn_ext", "multi_model.utils.pn2_utils.function",
                  "multi_model.utils.pn2_utils.modules", "multi_model.utils.pn2_utils.nn",
                  "multi_model.utils.pointnet2", "multi_model.score_network", "multi_model.gripper_region_network",
-                 "dataset_utils.get_regiondataset"):
+                 "dataset_utils.get_regiondataset", "dataset_utils.scoredataset", "dataset_utils.eval_score.eval"):
         mod = importlib.import_module(name)
         assert os.path.abspath(mod.__file__).startswith(REPO), name
     from multi_model.score_network import ScoreNetwork
     from multi_model.utils.pn2_utils import function as _F
     assert ScoreNetwork.__name__ == "ScoreNetwork" and callable(_F.farthest_point_sample)
+    from dataset_utils.eval_score.eval import eval_test, eval_validate   # test.py:17
+    assert callable(eval_test) and callable(eval_validate)
     for op in ("gather_points", "farthest_point_sample", "ball_query", "group_points", "search_nn_distance",
                "feature_interpolate"):
         assert hasattr(_F, op)
