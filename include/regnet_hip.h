@@ -218,17 +218,27 @@ int regnet_pack_rows_f32(const float* feat, int64_t fb, int64_t fc, int64_t fn, 
                          int64_t xb, int64_t xc, int64_t xn, int64_t B, int64_t N, int64_t W, float* out,
                          void* stream);
 
-/* regnet_grasp_collision_counts_f32: the per-grasp point scan of the view-cloud collision filter that test.py:147 applies to
- * the predicted grasps (utils.py:391-401 -> dataset_utils/eval_score/eval.py:4-12 -> eval_utils/
- * evaluation_data_generator.py:198-229, EvalDataTest.finger_hand_view; constants: eval_score/configs/config.py).
- * points: N rows, element strides (pn, pc) for (point, coordinate); T (B,4,4) row-major global->local matrices
- * (:91-93).  For grasp b and local coordinates (x,y,z) = T[b] (p,1), counts[b] = { #(x_lo < x < x_hi),
- *   #(... and |y| < half_width and x < back_x and |z| < half_thickness),
- *   #(... and |z| < half_thickness and half_space < |y| < half_width) } (all comparisons strict).
- * The caller applies the reference's thresholds (:203, :218, :229).  fp32, individually rounded, no contraction.   */
+/* regnet_grasp_collision_counts_f32 / regnet_grasp_antipodal_stats_f32: the per-grasp point scans of the reference's grasp
+ * evaluation, dataset_utils/eval_score/eval.py:4-24 -> eval_utils/evaluation_data_generator.py (EvalDataTest /
+ * EvalDataValidate .finger_hand_view :188-236 / :420-483, .finger_hand_scene :485-537, ._antipodal_score :392-418;
+ * constants: eval_score/configs/config.py), which loop over the grasps in Python.  test.py:147 applies the view-cloud
+ * filter to every predicted grasp (utils.py:391-401); utils.py:270-295 scores validation grasps against the scene cloud.
+ * points (and normals): N rows, element strides (pn, pc) / (nn, nc) for (point, coordinate); T (B,4,4) row-major
+ * global->local matrices (:91-93).  With (x,y,z) = T[b] (p,1) and all comparisons strict, counts[b] (4 x int32) =
+ *   { #(x_lo < x < x_hi), # behind the hand (.. and |y| < half_width, x < back_x, |z| < half_thickness),
+ *     # inside a finger (.. |z| < half_thickness, half_space < |y| < half_width), # closing region (.. |y| < half_space) };
+ * x_hi_per_grasp (B) overrides x_hi when not NULL (per-grasp depths, :428-430).  The caller applies the reference's
+ * thresholds.  Antipodal statistics over the closing-region points: stats[b] = { y_max, y_min, sum |n_y| over
+ * y > y_max - d, sum |n_y| over y < y_min + d } with d = min((y_max - y_min) / 3, neighbour_depth) and n_y the normal's
+ * y component in the grasp frame; side_counts[b] = the two point counts (the reference's score is the product of the
+ * two means).  fp32, individually rounded, no contraction; the sums are accumulated in fp64.                            */
 int regnet_grasp_collision_counts_f32(const float* points, int64_t pn, int64_t pc, int64_t N, const float* T, int64_t B,
-                                      float x_lo, float x_hi, float half_thickness, float half_width, float half_space,
-                                      float back_x, int32_t* counts, void* stream);
+                                      float x_lo, float x_hi, const float* x_hi_per_grasp, float half_thickness,
+                                      float half_width, float half_space, float back_x, int32_t* counts, void* stream);
+int regnet_grasp_antipodal_stats_f32(const float* points, int64_t pn, int64_t pc, const float* normals, int64_t nn,
+                                     int64_t nc, int64_t N, const float* T, int64_t B, float x_lo, float x_hi,
+                                     const float* x_hi_per_grasp, float half_thickness, float half_width, float half_space,
+                                     float back_x, float neighbour_depth, float* stats, int32_t* side_counts, void* stream);
 
 /* regnet_bn_relu_train_fwd_f32 / _bwd_f32: TRAINING-mode BatchNorm (+ ReLU, + max over the K neighbours) of a shared-MLP
  * block -- nn/modules/conv.py:30-36, :70-76 (bn then relu after the bias-free 1x1 convolution) and the set-abstraction

@@ -1,18 +1,25 @@
-"""CPU ORACLE for the view-cloud collision filter of test.py (test infrastructure, NOT product code).
+"""CPU ORACLE for the reference's grasp evaluation (test infrastructure, NOT product code).
 
-Restates dataset_utils/eval_score/eval.py:4-12 -> eval_utils/evaluation_data_generator.py (class EvalDataTest):
-``inv_transform_predicted_grasp`` (:109-170), the global->local matrices (:91-93) and ``finger_hand_view`` (:188-236),
-which test.py applies to every predicted grasp through utils.eval_notruth (utils.py:391-401).  Constants:
-eval_score/configs/config.py.  Citations are relative to /root/reference.
+Restates dataset_utils/eval_score/eval.py:4-24 -> eval_utils/evaluation_data_generator.py:
+  * class EvalDataTest -- ``inv_transform_predicted_grasp`` (:109-170), the global->local matrices (:91-93) and
+    ``finger_hand_view`` (:188-236), which test.py applies to every predicted grasp through utils.eval_notruth
+    (utils.py:391-401);
+  * class EvalDataValidate -- ``finger_hand_view`` (:420-483, table margin with the opposite sign and one more
+    threshold), ``finger_hand_scene`` (:485-537), ``_antipodal_score`` (:392-418) and ``run_collision`` (:352-366), used
+    on validation grasps through utils.eval_grasp_with_gt (utils.py:270-295).
+Constants: eval_score/configs/config.py.  Citations are relative to /root/reference.
 
-The estimated normals of that class (open3d, :77-80) and its table-corner test (:172-186, result unused at :197) do
-not influence the returned grasps and are not restated.
+The VIEW cloud's estimated normals (open3d, :77-80 / :261-262), the kd-trees (:260, torch_scene_point_cloud.py:24) and
+the table-corner tests (:172-186 / :374-386, results unused) do not influence anything these functions return and are
+not restated; the SCENE cloud's normals are taken from the record (``scene_normal``, torch_scene_point_cloud.py:13-16).
 
 Canonical arithmetic of the point transform, shared with csrc/region.hip:grasp_collision_kernel: individually rounded
 binary32 operations in source order, ``x = ((t00*px + t01*py) + t02*pz) + t03`` (the reference's 4xN torch.matmul goes
 through a BLAS whose summation order / FMA use is unspecified; a point within one ulp of a box face may therefore fall
 on the other side there).
 """
+import warnings
+
 import numpy as np
 import torch
 
@@ -24,7 +31,9 @@ FINGER_COLLISION_THRESHOLD = 0
 FINGER_WIDTH = 0.01
 HALF_HAND_THICKNESS = 0.005
 BOTTOM_LENGTH = 0.06
-TABLE_MARGIN = 0.005           # evaluation_data_generator.py:195
+CLOSE_REGION_MIN_POINTS = 16
+NEIGHBOR_DEPTH = 0.005
+TABLE_MARGIN = 0.005           # evaluation_data_generator.py:195 (+) and :428 (-)
 
 
 def grasp_frames(grasp):
@@ -69,31 +78,66 @@ def global_to_local(frame, center):
     return T
 
 
-def collision_counts(points, T, depth, width, chunk=64):
-    """points (N,3) float32, T (B,4,4) float32 -> int32 (B,3): points in the closing slab, behind the hand, inside a
-    finger.  evaluation_data_generator.py:200-229 with the canonical arithmetic of the module docstring; Python scalars
-    are compared as float32, as torch does for a float32 tensor against a Python number."""
+def _local(points, t):
     p = np.ascontiguousarray(points, dtype=np.float32)
-    T = np.ascontiguousarray(T, dtype=np.float32)
+    px, py, pz = p[None, :, 0], p[None, :, 1], p[None, :, 2]
+
+    def coord(r):
+        return ((t[:, r, 0, None] * px + t[:, r, 1, None] * py) + t[:, r, 2, None] * pz) + t[:, r, 3, None]
+    return coord(0), coord(1), coord(2)
+
+
+def _regions(x, y, z, depth, width):
     f = np.float32
-    x_lo, x_hi = f(-BOTTOM_LENGTH), f(depth)
+    x_lo = f(-BOTTOM_LENGTH)
+    x_hi = np.asarray(depth, dtype=np.float32).reshape(-1, 1) if np.ndim(depth) else f(depth)
     hw, hs = f(width / 2 + FINGER_WIDTH), f(width / 2)
     th, bm = f(HALF_HAND_THICKNESS), f(-BACK_COLLISION_MARGIN)
-    px, py, pz = p[None, :, 0], p[None, :, 1], p[None, :, 2]
-    out = np.zeros((T.shape[0], 3), dtype=np.int32)
-    for s in range(0, T.shape[0], chunk):
-        t = T[s:s + chunk]
+    close = (x > x_lo) & (x < x_hi)
+    zc = close & (z < th) & (z > -th)
+    back = zc & (y < hw) & (y > -hw) & (x < bm)
+    finger = zc & (((y < hw) & (y > hs)) | ((y > -hw) & (y < -hs)))
+    region = zc & (y < hs) & (y > -hs)
+    return close, back, finger, region
 
-        def coord(r):
-            return ((t[:, r, 0, None] * px + t[:, r, 1, None] * py) + t[:, r, 2, None] * pz) + t[:, r, 3, None]
-        x, y, z = coord(0), coord(1), coord(2)
-        close = (x > x_lo) & (x < x_hi)
-        zc = (z < th) & (z > -th)
-        back = close & (y < hw) & (y > -hw) & (x < bm) & zc
-        finger = close & zc & (((y < hw) & (y > hs)) | ((y > -hw) & (y < -hs)))
-        out[s:s + chunk, 0] = close.sum(1)
-        out[s:s + chunk, 1] = back.sum(1)
-        out[s:s + chunk, 2] = finger.sum(1)
+
+def collision_counts(points, T, depth, width, chunk=64):
+    """points (N,3) float32, T (B,4,4) float32 -> int32 (B,4): points in the closing slab, behind the hand, inside a
+    finger, between the fingers.  evaluation_data_generator.py:200-229 / :438-476 with the canonical arithmetic of the
+    module docstring; Python scalars are compared as float32, as torch does for a float32 tensor against a Python
+    number.  ``depth``: a float or one value per grasp (:428-430)."""
+    T = np.ascontiguousarray(T, dtype=np.float32)
+    out = np.zeros((T.shape[0], 4), dtype=np.int32)
+    for s in range(0, T.shape[0], chunk):
+        x, y, z = _local(points, T[s:s + chunk])
+        d = np.asarray(depth, dtype=np.float32)[s:s + chunk] if np.ndim(depth) else depth
+        for k, m in enumerate(_regions(x, y, z, d, width)):
+            out[s:s + chunk, k] = m.sum(1)
+    return out
+
+
+def antipodal_scores(points, normals, T, depth, width):
+    """float32 (B,): evaluation_data_generator.py:392-418 applied to the closing-region points of every grasp (:531-537):
+    mean |n_y| over the points within d of the largest y times the same near the smallest y, d = min((y_max - y_min) / 3,
+    NEIGHBOR_DEPTH), n_y the y component of the normal in the grasp frame.  NaN where the region is empty."""
+    T = np.ascontiguousarray(T, dtype=np.float32)
+    nrm = np.ascontiguousarray(normals, dtype=np.float32)
+    out = np.full((T.shape[0],), np.nan, dtype=np.float32)
+    for b in range(T.shape[0]):
+        t = T[b:b + 1]
+        x, y, z = _local(points, t)
+        d = np.asarray(depth, dtype=np.float32)[b:b + 1] if np.ndim(depth) else depth
+        region = _regions(x, y, z, d, width)[3][0]
+        if not region.any():
+            continue
+        yy = y[0][region]
+        ny = np.abs((t[0, 1, 0] * nrm[region, 0] + t[0, 1, 1] * nrm[region, 1]) + t[0, 1, 2] * nrm[region, 2])
+        ly, ry = yy.max(), yy.min()
+        dep = min(np.float32((ly - ry) / np.float32(3)), np.float32(NEIGHBOR_DEPTH))
+        left, right = yy > ly - dep, yy < ry + dep
+        with np.errstate(all="ignore"), warnings.catch_warnings():    # a one-point region has d = 0 and empty sides: NaN, like torch.mean of nothing
+            warnings.simplefilter("ignore")
+            out[b] = np.float32(ny[left].mean(dtype=np.float32)) * np.float32(ny[right].mean(dtype=np.float32))
     return out
 
 
@@ -117,3 +161,35 @@ def eval_test(points, predicted_grasp, view_num, table_height, depth, width, gpu
     counts = collision_counts(np.asarray(torch.as_tensor(points).float()), T.numpy(), depth, width)
     keep = accept(counts, frame.numpy(), center.numpy(), table_height, depth)
     return grasp[torch.from_numpy(np.nonzero(keep)[0])]
+
+
+def _passes(counts, with_region):
+    ok = (counts[:, 0] >= NUM_POINTS_THRESHOLD) & ~(counts[:, 1] > BACK_COLLISION_THRESHOLD) & ~(counts[:, 2] > FINGER_COLLISION_THRESHOLD)
+    return ok & (counts[:, 3] >= CLOSE_REGION_MIN_POINTS) if with_region else ok
+
+
+def eval_validate(data, predicted_grasp, view_num, table_height, depth, width, gpu=-1):
+    """eval.py:14-24 / EvalDataValidate.run_collision: -> (vgr, score, n_view, grasps without view collision, grasps
+    without scene collision).  ``data``: dict with view_cloud (N1,3), scene_cloud (N2,3), scene_normal (N2,3)."""
+    grasp = torch.as_tensor(predicted_grasp).float()
+    if grasp.dim() == 3:                                                    # (B,4,4) frames (:273-275)
+        frame, center = grasp[:, :3, :3].contiguous(), grasp[:, :3, 3].contiguous()
+    else:
+        frame, center = grasp_frames(grasp.view(-1, 8))
+    T = global_to_local(frame, center).numpy()
+    f = np.float32
+    dep = np.asarray(depth, dtype=np.float32) if np.ndim(depth) else f(depth)
+    view = collision_counts(np.asarray(data["view_cloud"], dtype=np.float32), T, depth, width)
+    above = ~((center.numpy()[:, 2] + frame.numpy()[:, 2, 0] * dep) < f(table_height - TABLE_MARGIN))      # :427-432
+    keep_view = np.nonzero(above & _passes(view, True))[0]
+    Tv = T[keep_view]
+    dv = np.asarray(depth, dtype=np.float32)[keep_view] if np.ndim(depth) else depth
+    scene_pts = np.asarray(data["scene_cloud"], dtype=np.float32)
+    scene = collision_counts(scene_pts, Tv, dv, width)
+    ok = _passes(scene, True)
+    score = np.zeros((len(keep_view),), dtype=np.float32)
+    if ok.any():
+        dvo = np.asarray(dv, dtype=np.float32)[ok] if np.ndim(dv) else dv
+        score[ok] = antipodal_scores(scene_pts, np.asarray(data["scene_normal"], dtype=np.float32), Tv[ok], dvo, width)
+    grasp_view = grasp[torch.from_numpy(keep_view)]
+    return int(ok.sum()), float(torch.from_numpy(score).sum().item()), len(keep_view), grasp_view, grasp_view[torch.from_numpy(np.nonzero(ok)[0])]

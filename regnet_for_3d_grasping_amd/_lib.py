@@ -48,8 +48,10 @@ SIGNATURES = {
     "regnet_sa_chain3_f32": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp,
                                     _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _int, _vp, _i64,
                                     _vp]),
-    "regnet_grasp_collision_counts_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _vp,
-                                                 _vp]),
+    "regnet_grasp_collision_counts_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _f32, _f32, _vp, _f32, _f32, _f32, _f32,
+                                                 _vp, _vp]),
+    "regnet_grasp_antipodal_stats_f32": (_int, [_vp, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _i64, _f32, _f32, _vp, _f32,
+                                                _f32, _f32, _f32, _f32, _vp, _vp, _vp]),
     "regnet_bn_workspace_bytes": (_i64, [_i64]),
     "regnet_bn_relu_train_fwd_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _f32, _f32, _vp, _vp, _int, _i64, _vp, _vp, _vp,
                                             _vp, _vp, _vp]),

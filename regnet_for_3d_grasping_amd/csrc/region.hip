@@ -225,62 +225,156 @@ extern "C" int regnet_box_crop_f32(const float* group_points, int64_t gb, int64_
 // rounded fp32 in source order, x = ((t00*px + t01*py) + t02*pz) + t03 (this file is built with -ffp-contract=off), the
 // same as oracle/collision_oracle.py.
 #define GC_T 256
+
+struct GraspBox {   // the reference's box constants as float32 (what torch compares a float32 tensor against)
+  float x_lo, x_hi, half_thickness, half_width, half_space, back_x;
+};
+
+// local coordinates of point j for the matrix rows held in registers; returns false when outside the closing slab
+#define GC_LOCAL(j)                                                          \
+  const float* p = points + (int64_t)(j) * pn;                               \
+  const float px = p[0], py = p[pc], pz = p[2 * pc];                         \
+  const float x = ((t00 * px + t01 * py) + t02 * pz) + t03;                  \
+  const bool close = x > box.x_lo && x < x_hi;                               \
+  const float y = ((t10 * px + t11 * py) + t12 * pz) + t13;                  \
+  const float z = ((t20 * px + t21 * py) + t22 * pz) + t23;                  \
+  const bool zc = close && z < box.half_thickness && z > -box.half_thickness;
+
+__device__ __forceinline__ int block_sum_int(int v, int* red) {   // red: GC_T / 64 ints of LDS; all threads get the sum
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  int s = 0;
+#pragma unroll
+  for (int w = 0; w < GC_T / 64; ++w) s += red[w];
+  return s;
+}
+
+// counts[b] = { closing slab, behind the hand, inside a finger, between the fingers (closing region) }
 __global__ __launch_bounds__(GC_T) void grasp_collision_kernel(const float* __restrict__ points, int64_t pn, int64_t pc,
-                                                               int N, const float* __restrict__ T, float x_lo,
-                                                               float x_hi, float half_thickness, float half_width,
-                                                               float half_space, float back_x,
+                                                               int N, const float* __restrict__ T, GraspBox box,
+                                                               const float* __restrict__ x_hi_per_grasp,
                                                                int32_t* __restrict__ counts) {
+  __shared__ int red[GC_T / 64];
   const float* t = T + (int64_t)blockIdx.x * 16;
   const float t00 = t[0], t01 = t[1], t02 = t[2], t03 = t[3];
   const float t10 = t[4], t11 = t[5], t12 = t[6], t13 = t[7];
   const float t20 = t[8], t21 = t[9], t22 = t[10], t23 = t[11];
-  int c_close = 0, c_back = 0, c_finger = 0;
+  const float x_hi = x_hi_per_grasp ? x_hi_per_grasp[blockIdx.x] : box.x_hi;
+  int c_close = 0, c_back = 0, c_finger = 0, c_region = 0;
   for (int j = threadIdx.x; j < N; j += GC_T) {
-    const float* p = points + (int64_t)j * pn;
-    const float px = p[0], py = p[pc], pz = p[2 * pc];
-    const float x = ((t00 * px + t01 * py) + t02 * pz) + t03;
-    const bool close = x > x_lo && x < x_hi;
-    if (!close) continue;
-    const float y = ((t10 * px + t11 * py) + t12 * pz) + t13;
-    const float z = ((t20 * px + t21 * py) + t22 * pz) + t23;
-    const bool zc = z < half_thickness && z > -half_thickness;
-    const bool back = y < half_width && y > -half_width && x < back_x && zc;
-    const bool finger = zc && ((y < half_width && y > half_space) || (y > -half_width && y < -half_space));
-    c_close += 1;
+    GC_LOCAL(j)
+    const bool back = zc && y < box.half_width && y > -box.half_width && x < box.back_x;
+    const bool finger = zc && ((y < box.half_width && y > box.half_space) || (y > -box.half_width && y < -box.half_space));
+    const bool region = zc && y < box.half_space && y > -box.half_space;
+    c_close += close;
     c_back += back;
     c_finger += finger;
+    c_region += region;
   }
-  __shared__ int red[3][GC_T / 64];
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    c_close += __shfl_xor(c_close, o);
-    c_back += __shfl_xor(c_back, o);
-    c_finger += __shfl_xor(c_finger, o);
-  }
-  if ((threadIdx.x & 63) == 0) {
-    red[0][threadIdx.x >> 6] = c_close;
-    red[1][threadIdx.x >> 6] = c_back;
-    red[2][threadIdx.x >> 6] = c_finger;
-  }
-  __syncthreads();
-  if (threadIdx.x < 3) {
-    int v = 0;
-#pragma unroll
-    for (int w = 0; w < GC_T / 64; ++w) v += red[threadIdx.x][w];
-    counts[(int64_t)blockIdx.x * 3 + threadIdx.x] = v;
+  c_close = block_sum_int(c_close, red);
+  c_back = block_sum_int(c_back, red);
+  c_finger = block_sum_int(c_finger, red);
+  c_region = block_sum_int(c_region, red);
+  if (threadIdx.x == 0) {
+    int32_t* o = counts + (int64_t)blockIdx.x * 4;
+    o[0] = c_close; o[1] = c_back; o[2] = c_finger; o[3] = c_region;
   }
 }
 
-extern "C" int regnet_grasp_collision_counts_f32(const float* points, int64_t pn, int64_t pc, int64_t N, const float* T,
-                                                 int64_t B, float x_lo, float x_hi, float half_thickness,
-                                                 float half_width, float half_space, float back_x, int32_t* counts,
-                                                 void* stream) {
+// Antipodal statistics of the closing region against a cloud with normals (evaluation_data_generator.py:392-418 on the
+// region selected at :521-534): y extent of the region, then |n_y| (normal in the grasp frame) summed over the points
+// within `depth = min((y_max - y_min) / 3, neighbour_depth)` of either extreme.
+// stats[b] = { y_max, y_min, sum_left, sum_right }, side_counts[b] = { n_left, n_right }.
+__global__ __launch_bounds__(GC_T) void grasp_antipodal_kernel(const float* __restrict__ points, int64_t pn, int64_t pc,
+                                                               const float* __restrict__ normals, int64_t nn, int64_t nc,
+                                                               int N, const float* __restrict__ T, GraspBox box,
+                                                               const float* __restrict__ x_hi_per_grasp,
+                                                               float neighbour_depth, float* __restrict__ stats,
+                                                               int32_t* __restrict__ side_counts) {
+  __shared__ float redf[2][GC_T / 64];
+  __shared__ double redd[2][GC_T / 64];
+  __shared__ int red[GC_T / 64];
+  const float* t = T + (int64_t)blockIdx.x * 16;
+  const float t00 = t[0], t01 = t[1], t02 = t[2], t03 = t[3];
+  const float t10 = t[4], t11 = t[5], t12 = t[6], t13 = t[7];
+  const float t20 = t[8], t21 = t[9], t22 = t[10], t23 = t[11];
+  const float x_hi = x_hi_per_grasp ? x_hi_per_grasp[blockIdx.x] : box.x_hi;
+  float ymax = -__builtin_inff(), ymin = __builtin_inff();
+  for (int j = threadIdx.x; j < N; j += GC_T) {
+    GC_LOCAL(j)
+    if (zc && y < box.half_space && y > -box.half_space) { ymax = fmaxf(ymax, y); ymin = fminf(ymin, y); }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { ymax = fmaxf(ymax, __shfl_xor(ymax, o)); ymin = fminf(ymin, __shfl_xor(ymin, o)); }
+  if ((threadIdx.x & 63) == 0) { redf[0][threadIdx.x >> 6] = ymax; redf[1][threadIdx.x >> 6] = ymin; }
+  __syncthreads();
+#pragma unroll
+  for (int w = 0; w < GC_T / 64; ++w) { ymax = fmaxf(ymax, redf[0][w]); ymin = fminf(ymin, redf[1][w]); }
+  const float third = (ymax - ymin) / 3.0f;
+  const float depth = third < neighbour_depth ? third : neighbour_depth;   // torch.min(a, b)
+  const float left_edge = ymax - depth, right_edge = ymin + depth;
+  double s_left = 0.0, s_right = 0.0;
+  int n_left = 0, n_right = 0;
+  for (int j = threadIdx.x; j < N; j += GC_T) {
+    GC_LOCAL(j)
+    if (!(zc && y < box.half_space && y > -box.half_space)) continue;
+    const float* q = normals + (int64_t)j * nn;
+    const float ny = fabsf((t10 * q[0] + t11 * q[nc]) + t12 * q[2 * nc]);
+    if (y > left_edge) { s_left += (double)ny; n_left += 1; }
+    if (y < right_edge) { s_right += (double)ny; n_right += 1; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { s_left += __shfl_xor(s_left, o); s_right += __shfl_xor(s_right, o); }
+  if ((threadIdx.x & 63) == 0) { redd[0][threadIdx.x >> 6] = s_left; redd[1][threadIdx.x >> 6] = s_right; }
+  n_left = block_sum_int(n_left, red);     // (its barriers also publish redd)
+  n_right = block_sum_int(n_right, red);
+  if (threadIdx.x == 0) {
+    double a = 0.0, b = 0.0;
+#pragma unroll
+    for (int w = 0; w < GC_T / 64; ++w) { a += redd[0][w]; b += redd[1][w]; }
+    float* o = stats + (int64_t)blockIdx.x * 4;
+    o[0] = ymax; o[1] = ymin; o[2] = (float)a; o[3] = (float)b;
+    side_counts[(int64_t)blockIdx.x * 2] = n_left;
+    side_counts[(int64_t)blockIdx.x * 2 + 1] = n_right;
+  }
+}
+
+static inline int grasp_args_ok(int64_t N, int64_t B) {
   if (N < 0 || B < 0) return REGNET_ERR_SHAPE;
   if (N >= (int64_t)1 << 31 || B >= (int64_t)1 << 31) return REGNET_ERR_UNSUPPORTED;
+  return REGNET_OK;
+}
+
+extern "C" int regnet_grasp_collision_counts_f32(const float* points, int64_t pn, int64_t pc, int64_t N, const float* T,
+                                                 int64_t B, float x_lo, float x_hi, const float* x_hi_per_grasp,
+                                                 float half_thickness, float half_width, float half_space, float back_x,
+                                                 int32_t* counts, void* stream) {
+  const int rc = grasp_args_ok(N, B);
+  if (rc != REGNET_OK) return rc;
   if (B == 0) return REGNET_OK;
   if (!T || !counts || (N > 0 && !points)) return REGNET_ERR_NULL;
+  const GraspBox box{x_lo, x_hi, half_thickness, half_width, half_space, back_x};
   hipLaunchKernelGGL(grasp_collision_kernel, dim3((unsigned)B), dim3(GC_T), 0, as_stream(stream), points, pn, pc, (int)N, T,
-                     x_lo, x_hi, half_thickness, half_width, half_space, back_x, counts);
+                     box, x_hi_per_grasp, counts);
+  REGNET_LAUNCH_CHECK();
+  return REGNET_OK;
+}
+
+extern "C" int regnet_grasp_antipodal_stats_f32(const float* points, int64_t pn, int64_t pc, const float* normals, int64_t nn,
+                                                int64_t nc, int64_t N, const float* T, int64_t B, float x_lo, float x_hi,
+                                                const float* x_hi_per_grasp, float half_thickness, float half_width,
+                                                float half_space, float back_x, float neighbour_depth, float* stats,
+                                                int32_t* side_counts, void* stream) {
+  const int rc = grasp_args_ok(N, B);
+  if (rc != REGNET_OK) return rc;
+  if (B == 0) return REGNET_OK;
+  if (!T || !stats || !side_counts || (N > 0 && (!points || !normals))) return REGNET_ERR_NULL;
+  const GraspBox box{x_lo, x_hi, half_thickness, half_width, half_space, back_x};
+  hipLaunchKernelGGL(grasp_antipodal_kernel, dim3((unsigned)B), dim3(GC_T), 0, as_stream(stream), points, pn, pc, normals,
+                     nn, nc, (int)N, T, box, x_hi_per_grasp, neighbour_depth, stats, side_counts);
   REGNET_LAUNCH_CHECK();
   return REGNET_OK;
 }

@@ -1,15 +1,18 @@
-"""View-cloud collision filter of the predicted grasps (mirror of dataset_utils/eval_score/eval.py:4-12 ->
-eval_utils/evaluation_data_generator.py, class EvalDataTest; applied by test.py:147 through utils.eval_notruth,
-utils.py:391-401).
+"""Grasp evaluation against point clouds (mirror of dataset_utils/eval_score/eval.py:4-24 ->
+eval_utils/evaluation_data_generator.py, classes EvalDataTest / EvalDataValidate).
 
-``eval_test(points, predicted_grasp, view_num, table_height, depth, width, gpu)`` keeps the reference's signature and
-returns the rows of ``predicted_grasp[:, :8]`` whose gripper does not collide with the cloud, in input order.  The
-reference loops over the grasps in Python (a 4xN matmul, five masks and a host sync per grasp); here the grasp frames
-are computed batched with the reference's torch expressions and ONE kernel launch scans the cloud for all grasps
-(csrc/region.hip:grasp_collision_kernel), followed by the reference's thresholds as tensor ops -- one sync in total.
-GPU only (the reference's ``gpu=-1`` CPU mode is not offered: there is no CPU fallback in this package).
+``eval_test(points, predicted_grasp, view_num, table_height, depth, width, gpu)`` -- test.py:147 through
+utils.eval_notruth (utils.py:391-401) -- returns the rows of ``predicted_grasp[:, :8]`` whose gripper does not collide
+with the view cloud, in input order.  ``eval_validate(formal_dict, predicted_grasp, view_num, table_height, depth, width,
+gpu)`` -- utils.eval_grasp_with_gt (utils.py:270-295) -- additionally filters against the ground-truth scene cloud and
+sums the antipodal scores: ``(vgr, score, n_view, grasps_view, grasps_scene)``.  Same signatures and return values.
 
-Not mirrored: ``eval_validate`` (antipodal scoring against the ground-truth scene cloud; needs open3d normal estimation).
+The reference loops over the grasps in Python (a 4xN matmul, five or six masks and several host syncs per grasp, twice
+for validation); here the grasp frames are computed batched with the reference's torch expressions and each pass is ONE
+kernel launch over all grasps (csrc/region.hip: grasp_collision_kernel, grasp_antipodal_kernel) followed by the
+reference's thresholds as tensor ops.  GPU only (the reference's ``gpu=-1`` CPU mode is not offered: there is no CPU
+fallback in this package).  Scene normals are taken from the record (``scene_normal``); estimating them (open3d in the
+reference, torch_scene_point_cloud.py:17-19) is outside this package.
 """
 import torch
 
@@ -26,7 +29,9 @@ FINGER_COLLISION_THRESHOLD = 0
 FINGER_WIDTH = 0.01
 HALF_HAND_THICKNESS = 0.005
 BOTTOM_LENGTH = 0.06
-TABLE_MARGIN = 0.005   # evaluation_data_generator.py:195
+CLOSE_REGION_MIN_POINTS = 16
+NEIGHBOR_DEPTH = 0.005
+TABLE_MARGIN = 0.005   # evaluation_data_generator.py:195 (+, test flavour) and :428 (-, validation flavour)
 
 
 def _unit_or(v, fallback):
@@ -64,24 +69,68 @@ def global_to_local(frame, center):
     return T
 
 
-def collision_counts(points, T, depth, width):
-    """points (N,3) float32 on the GPU (any strides), T (B,4,4) -> int32 (B,3): points in the closing slab / behind the
-    hand / inside a finger for every grasp (evaluation_data_generator.py:200-229)."""
+def _points_ok(points, name="points"):
     if not points.is_cuda:
-        raise RuntimeError("points must be a CUDA tensor (no CPU path)")
+        raise RuntimeError("%s must be a CUDA tensor (no CPU path)" % name)
     if points.dtype != torch.float32 or points.dim() != 2 or points.shape[1] != 3:
-        raise RuntimeError("points must be float32 (N, 3)")
+        raise RuntimeError("%s must be float32 (N, 3)" % name)
+
+
+def _depth_args(depth, B, device):
+    """-> (scalar x_hi, per-grasp tensor or None): the reference accepts a float or one depth per grasp (:428-430)."""
+    if isinstance(depth, torch.Tensor) and depth.dim() > 0:
+        d = depth.to(device, torch.float32).contiguous().view(-1)
+        if d.numel() != B:
+            raise RuntimeError("one depth per grasp expected")
+        return 0.0, d
+    return float(depth), None
+
+
+def _box_args(depth, width, B, device):
+    x_hi, per = _depth_args(depth, B, device)
+    return (-BOTTOM_LENGTH, x_hi, per.data_ptr() if per is not None else None, HALF_HAND_THICKNESS,
+            float(width) / 2 + FINGER_WIDTH, float(width) / 2, -BACK_COLLISION_MARGIN), per
+
+
+def collision_counts(points, T, depth, width):
+    """points (N,3) float32 on the GPU (any strides), T (B,4,4) -> int32 (B,4): points in the closing slab / behind the
+    hand / inside a finger / between the fingers, for every grasp (evaluation_data_generator.py:200-229, :438-476)."""
+    _points_ok(points)
     T = T.to(points.device, torch.float32).contiguous()
     B, N = T.shape[0], points.shape[0]
     with torch.cuda.device(points.device):
-        counts = torch.zeros((B, 3), dtype=torch.int32, device=points.device)
+        counts = torch.zeros((B, 4), dtype=torch.int32, device=points.device)
+        box, keep = _box_args(depth, width, B, points.device)
         _check(_L.regnet_grasp_collision_counts_f32(points.data_ptr(), points.stride(0), points.stride(1), N, T.data_ptr(),
-                                                    B, -BOTTOM_LENGTH, float(depth), HALF_HAND_THICKNESS,
-                                                    float(width) / 2 + FINGER_WIDTH, float(width) / 2,
-                                                    -BACK_COLLISION_MARGIN, counts.data_ptr(),
+                                                    B, *box, counts.data_ptr(),
                                                     torch.cuda.current_stream(points.device).cuda_stream),
                "grasp_collision_counts")
     return counts
+
+
+def antipodal_scores(points, normals, T, depth, width):
+    """float32 (B,): product of the mean |n_y| near the two y extremes of every grasp's closing region
+    (evaluation_data_generator.py:392-418 on the region of :521-534); meaningful where the region is not empty."""
+    _points_ok(points)
+    _points_ok(normals, "normals")
+    T = T.to(points.device, torch.float32).contiguous()
+    B, N = T.shape[0], points.shape[0]
+    with torch.cuda.device(points.device):
+        stats = torch.zeros((B, 4), dtype=torch.float32, device=points.device)
+        sides = torch.zeros((B, 2), dtype=torch.int32, device=points.device)
+        box, keep = _box_args(depth, width, B, points.device)
+        _check(_L.regnet_grasp_antipodal_stats_f32(points.data_ptr(), points.stride(0), points.stride(1), normals.data_ptr(),
+                                                   normals.stride(0), normals.stride(1), N, T.data_ptr(), B, *box,
+                                                   NEIGHBOR_DEPTH, stats.data_ptr(), sides.data_ptr(),
+                                                   torch.cuda.current_stream(points.device).cuda_stream),
+               "grasp_antipodal_stats")
+    return (stats[:, 2] / sides[:, 0]) * (stats[:, 3] / sides[:, 1])
+
+
+def _passes(counts, with_region):
+    ok = (counts[:, 0] >= NUM_POINTS_THRESHOLD) & ~(counts[:, 1] > BACK_COLLISION_THRESHOLD) \
+        & ~(counts[:, 2] > FINGER_COLLISION_THRESHOLD)
+    return ok & (counts[:, 3] >= CLOSE_REGION_MIN_POINTS) if with_region else ok
 
 
 def no_collision_mask(points, grasp, table_height, depth, width):
@@ -89,8 +138,7 @@ def no_collision_mask(points, grasp, table_height, depth, width):
     frame, center = grasp_frames(grasp)
     counts = collision_counts(points, global_to_local(frame, center), depth, width)
     above = ~((center[:, 2] + frame[:, 2, 0] * depth) < (table_height + TABLE_MARGIN))
-    return (above & (counts[:, 0] >= NUM_POINTS_THRESHOLD) & ~(counts[:, 1] > BACK_COLLISION_THRESHOLD)
-            & ~(counts[:, 2] > FINGER_COLLISION_THRESHOLD))
+    return above & _passes(counts, False)
 
 
 def eval_test(points, predicted_grasp, view_num, table_height, depth, width, gpu=0):
@@ -104,3 +152,38 @@ def eval_test(points, predicted_grasp, view_num, table_height, depth, width, gpu
         return grasp
     pts = torch.as_tensor(points).float().to(dev)
     return grasp[no_collision_mask(pts, grasp, table_height, depth, width)]
+
+
+def eval_validate(formal_dict, predicted_grasp, view_num, table_height, depth, width, gpu=0):
+    """eval.py:14-24 / EvalDataValidate.run_collision (:352-366).  ``formal_dict``: a validation record with
+    ``view_cloud`` (N1,3), ``scene_cloud`` (N2,3) and ``scene_normal`` (N2,3); ``predicted_grasp`` (B,8) rows or (B,4,4)
+    frames.  -> (vgr, antipodal score sum, grasps without view collision (count), those grasps, the ones that also clear
+    the scene cloud)."""
+    if gpu == -1:
+        raise RuntimeError("eval_validate: this package has no CPU mode (gpu=-1)")
+    if "scene_normal" not in formal_dict:
+        raise RuntimeError("eval_validate needs the record's scene_normal (normal estimation is outside this package)")
+    dev = torch.device("cuda", int(gpu))
+    grasp = torch.as_tensor(predicted_grasp).float().to(dev)
+    if grasp.dim() == 3:                                                    # (B,4,4) frames (:273-275)
+        frame, center = grasp[:, :3, :3].contiguous(), grasp[:, :3, 3].contiguous()
+    else:
+        grasp = grasp.view(-1, 8)
+        frame, center = grasp_frames(grasp)
+    if grasp.shape[0] == 0:
+        return 0, 0.0, 0, grasp, grasp
+    T = global_to_local(frame, center)
+    dep = depth.to(dev, torch.float32).view(-1) if isinstance(depth, torch.Tensor) and depth.dim() > 0 else depth
+    view = collision_counts(torch.as_tensor(formal_dict["view_cloud"]).float().to(dev), T, dep, width)
+    above = ~((center[:, 2] + frame[:, 2, 0] * dep) < (table_height - TABLE_MARGIN))              # :427-432
+    keep_view = torch.nonzero(above & _passes(view, True)).view(-1)
+    grasp_view = grasp[keep_view]
+    if keep_view.numel() == 0:
+        return 0, 0.0, 0, grasp_view, grasp_view
+    Tv = T[keep_view]
+    dv = dep[keep_view] if isinstance(dep, torch.Tensor) else dep
+    scene = torch.as_tensor(formal_dict["scene_cloud"]).float().to(dev)
+    ok = _passes(collision_counts(scene, Tv, dv, width), True)
+    score = antipodal_scores(scene, torch.as_tensor(formal_dict["scene_normal"]).float().to(dev), Tv, dv, width)
+    score = torch.where(ok, score, torch.zeros_like(score))
+    return int(ok.sum()), float(score.sum().item()), int(keep_view.numel()), grasp_view, grasp_view[torch.nonzero(ok).view(-1)]

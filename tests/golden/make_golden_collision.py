@@ -1,11 +1,13 @@
 """AUTHORING-CONTAINER ONLY: generate tests/golden/s6_collision.npz from the reference's own view-cloud collision
 filter (dataset_utils/eval_score/eval.py:eval_test -> EvalDataTest.run_collision_view).
 
-The reference class imports open3d and transforms3d, which the image lacks.  Neither influences what eval_test returns:
-transforms3d is only referenced by an unused helper (evaluation_data_generator.py:40-43) and open3d only estimates
-normals (:77-80) whose transformed copy (:199) is never read by finger_hand_view.  They are therefore replaced by inert
-stand-ins (a point-cloud object that stores its points and returns zero normals), and the fixture records exactly what
-the reference returned for seeded inputs.  Run:  python tests/golden/make_golden_collision.py
+The reference classes import open3d and transforms3d, which the image lacks.  Neither influences what eval_test /
+eval_validate return for these inputs: transforms3d is only referenced by an unused helper
+(evaluation_data_generator.py:40-43); open3d estimates normals of the VIEW cloud (:77-80, :261-262) whose transformed
+copy (:199, :437) is never read, builds kd-trees nobody queries (:260) and would estimate SCENE normals only when the
+record carries none (torch_scene_point_cloud.py:13-19; the fixture's records carry ``scene_normal``).  They are therefore
+replaced by inert stand-ins (a point-cloud object that stores its points and returns zero normals), and the fixture
+records exactly what the reference's code returned for seeded inputs.  Run:  python tests/golden/make_golden_collision.py
 """
 import contextlib
 import importlib
@@ -39,7 +41,8 @@ def _inert_open3d():
         def orient_normals_towards_camera_location(self, cam):
             pass
 
-    o3d.geometry = types.SimpleNamespace(PointCloud=_Cloud, KDTreeSearchParamHybrid=lambda **kw: None)
+    o3d.geometry = types.SimpleNamespace(PointCloud=_Cloud, KDTreeSearchParamHybrid=lambda **kw: None,
+                                         KDTreeFlann=lambda cloud: None)
     o3d.utility = types.SimpleNamespace(Vector3dVector=lambda a: np.asarray(a))
     o3d.visualization = types.SimpleNamespace(draw_geometries=lambda *a, **k: None)
     return o3d
@@ -82,6 +85,18 @@ def main():
         out["c%d_kept_index" % i] = idx
         out["c%d_kept" % i] = kept
         print("case %d: %d of %d grasps kept" % (i, len(idx), len(g)))
+    # validation flavour: eval_validate = view filter + scene filter + antipodal score (scene normals from the record)
+    for i, c in enumerate(golden_util.VALIDATE_CASES):
+        data, g = golden_util.validate_case(i)
+        with contextlib.redirect_stdout(io.StringIO()):
+            vgr, score, n_view, g_view, g_scene = mod.eval_validate(data, g, c["view_num"], c["table_height"], c["depth"],
+                                                                    c["width"], -1)
+        out["v%d_vgr" % i] = np.int64(vgr)
+        out["v%d_score" % i] = np.float64(score)
+        out["v%d_n_view" % i] = np.int64(n_view)
+        out["v%d_view" % i] = g_view.numpy()
+        out["v%d_scene" % i] = g_scene.numpy()
+        print("validate case %d: %d grasps, %d without view collision, vgr %d, score %.6f" % (i, len(g), n_view, vgr, score))
     np.savez_compressed(os.path.join(HERE, "s6_collision.npz"), **out)
 
 

@@ -51,9 +51,9 @@ def test_rules_known_answers():
         return counts[0], bool(co.accept(counts, frame.numpy(), center.numpy(), th, depth)[0])
 
     assert run(np.zeros((0, 3)))[1]                                             # 20 slab points >= 16, no collision
-    assert run(np.zeros((0, 3)))[0].tolist() == [20, 0, 0]
+    assert run(np.zeros((0, 3)))[0].tolist() == [20, 0, 0, 0]                  # the slab points sit above the hand plane
     assert not run([[-0.01, 0.0, 0.0]])[1]                                      # a point behind the hand (x < 0)
-    assert run([[-0.01, 0.0, 0.0]])[0].tolist() == [21, 1, 0]
+    assert run([[-0.01, 0.0, 0.0]])[0].tolist() == [21, 1, 0, 1]
     assert run([[0.0, 0.0, 0.0]])[1]                                            # x == 0 is not behind (strict <)
     assert not run([[0.02, 0.045, 0.0]])[1]                                     # inside the left finger
     assert run([[0.02, 0.04, 0.0]])[1] and run([[0.02, 0.05, 0.0]])[1]          # finger faces are exclusive
@@ -69,7 +69,31 @@ def test_rules_known_answers():
     low = _grasp((0.0, 0.0, 0.81), angle=-float(np.pi / 2))   # approach = cos t * x + sin t * z = -z
     frame, center = co.grasp_frames(low)
     assert frame[0, 2, 0] < -0.99
-    big = np.full((1, 3), 20, dtype=np.int32) * np.array([[1, 0, 0]], dtype=np.int32)
+    big = np.array([[20, 0, 0, 20]], dtype=np.int32)
     assert not co.accept(big, frame.numpy(), center.numpy(), 0.75, depth)[0]
     assert co.accept(big, frame.numpy(), center.numpy(), 0.70, depth)[0]
     assert co.eval_test(slab, torch.zeros(0, 8), None, th, depth, width).shape == (0, 8)
+
+
+def test_oracle_reproduces_reference_eval_validate_fixture():
+    fx = golden_util.load("s6_collision.npz")
+    for i, c in enumerate(golden_util.VALIDATE_CASES):
+        data, g = golden_util.validate_case(i)
+        vgr, score, n_view, g_view, g_scene = co.eval_validate(data, torch.from_numpy(g), c["view_num"], c["table_height"],
+                                                               c["depth"], c["width"])
+        assert vgr == int(fx["v%d_vgr" % i]) and n_view == int(fx["v%d_n_view" % i]) and vgr > 0
+        assert np.array_equal(g_view.numpy(), fx["v%d_view" % i]) and np.array_equal(g_scene.numpy(), fx["v%d_scene" % i])
+        assert abs(score - float(fx["v%d_score" % i])) <= 1e-5 * max(1.0, abs(score))
+
+
+def test_antipodal_score_known_answer():
+    # identity frame at the origin; closing region |y| < 0.04, |z| < 0.005, -0.06 < x < 0.06
+    pts = np.array([[0.01, 0.030, 0.0], [0.01, 0.029, 0.0], [0.01, 0.020, 0.0],      # left: y_max = 0.03
+                    [0.01, -0.030, 0.0], [0.01, -0.0295, 0.0], [0.01, 0.0, 0.0],     # right: y_min = -0.03
+                    [0.01, 0.030, 0.02]], dtype=np.float32)                            # outside (|z|)
+    nrm = np.array([[0, 1.0, 0], [0, -0.5, 0], [0, 0.9, 0], [0, 0.25, 0], [0, 0.75, 0], [0, 0.1, 0], [0, 9.0, 0]], np.float32)
+    T = np.eye(4, dtype=np.float32)[None]
+    # d = min((0.03 + 0.03) / 3, 0.005) = 0.005: left = {0.030, 0.029} -> mean(1, 0.5); right = {-0.030, -0.0295} -> mean(.25, .75)
+    s = co.antipodal_scores(pts, nrm, T, 0.06, 0.08)
+    assert abs(float(s[0]) - 0.75 * 0.5) < 1e-6
+    assert np.isnan(co.antipodal_scores(pts[-1:], nrm[-1:], T, 0.06, 0.08)[0])      # empty region

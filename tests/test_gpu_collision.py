@@ -41,7 +41,7 @@ def test_strided_points_and_edge_cases():
     assert torch.equal(a, b) and torch.equal(a, t)
     assert ec.eval_test(pts, np.zeros((0, 8), np.float32), None, 0.75, 0.06, 0.08, 0).shape == (0, 8)
     empty = ec.collision_counts(torch.zeros(0, 3, device=DEV), T[:5], 0.06, 0.08)
-    assert empty.shape == (5, 3) and int(empty.abs().sum()) == 0
+    assert empty.shape == (5, 4) and int(empty.abs().sum()) == 0
     with pytest.raises(RuntimeError):
         ec.collision_counts(torch.from_numpy(pts), T, 0.06, 0.08)      # CPU tensor: no CPU path
     with pytest.raises(RuntimeError):
@@ -68,3 +68,36 @@ def test_inference_script_scale_4000_grasps_25600_points():
     # frames computed on the GPU may differ from the CPU's in the last bit (sin / cos): allow a grasp or two whose
     # decisive point sits within an ulp of a box face
     assert abs(int(keep.sum()) - out.shape[0]) <= 2 and 0 < out.shape[0] < 4000
+
+
+@pytest.mark.parametrize("case", [0, 1])
+def test_eval_validate_matches_reference_fixture_and_oracle(case):
+    """View filter + scene filter + antipodal score (EvalDataValidate.run_collision) against what the reference's own
+    eval_validate returned, and the per-grasp statistics against the oracle."""
+    from regnet_for_3d_grasping_amd import eval_collision as ec
+    c = golden_util.VALIDATE_CASES[case]
+    data, g = golden_util.validate_case(case)
+    fx = golden_util.load("s6_collision.npz")
+    vgr, score, n_view, g_view, g_scene = ec.eval_validate(data, g, c["view_num"], c["table_height"], c["depth"], c["width"], 0)
+    assert vgr == int(fx["v%d_vgr" % case]) and n_view == int(fx["v%d_n_view" % case])
+    assert np.array_equal(g_view.cpu().numpy(), fx["v%d_view" % case])
+    assert np.array_equal(g_scene.cpu().numpy(), fx["v%d_scene" % case])
+    assert abs(score - float(fx["v%d_score" % case])) <= 1e-5 * max(1.0, abs(score))
+    # kernel statistics vs the oracle on identical matrices: counts exact, scores to 1e-6
+    frame, center = co.grasp_frames(torch.from_numpy(g))
+    T = co.global_to_local(frame, center)
+    scene = torch.from_numpy(data["scene_cloud"]).to(DEV)
+    nrm = torch.from_numpy(data["scene_normal"]).to(DEV)
+    want = co.collision_counts(data["scene_cloud"], T.numpy(), c["depth"], c["width"])
+    got = ec.collision_counts(scene, T.to(DEV), c["depth"], c["width"]).cpu().numpy()
+    assert np.array_equal(got, want)
+    rows = np.nonzero(want[:, 3] > 0)[0]
+    s_want = co.antipodal_scores(data["scene_cloud"], data["scene_normal"], T.numpy()[rows], c["depth"], c["width"])
+    s_got = ec.antipodal_scores(scene, nrm, T[rows].to(DEV), c["depth"], c["width"]).cpu().numpy()
+    np.testing.assert_allclose(s_got, s_want, rtol=2e-6, atol=1e-7)
+    # one depth per grasp (the reference's tensor-depth branch, :428-430) == the scalar when they are all equal
+    per = torch.full((len(g),), float(c["depth"]))
+    assert np.array_equal(ec.collision_counts(scene, T.to(DEV), per, c["width"]).cpu().numpy(), want)
+    d2 = torch.linspace(0.03, 0.07, len(g))
+    assert np.array_equal(ec.collision_counts(scene, T.to(DEV), d2, c["width"]).cpu().numpy(),
+                          co.collision_counts(data["scene_cloud"], T.numpy(), d2.numpy(), c["width"]))
