@@ -1,5 +1,5 @@
 """Standalone timing of the FPS kernel at the ScoreNet level shapes."""
-import os, sys, time
+import os, sys
 sys.path.insert(0, os.getcwd())
 import torch
 from regnet_for_3d_grasping_amd import pn2_ext, synthetic

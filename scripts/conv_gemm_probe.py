@@ -1,5 +1,5 @@
 """Probe: rocBLAS GEMM formulations of the 1x1 convolution (forward / input gradient / weight gradient) vs F.conv2d."""
-import sys, time, torch
+import time, torch
 import torch.nn.functional as F
 dev = "cuda:0"
 def t(f, n=5):

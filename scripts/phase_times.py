@@ -3,7 +3,7 @@ import contextlib, io, os, sys, time
 sys.path.insert(0, os.getcwd())
 import numpy as np, torch
 from regnet_for_3d_grasping_amd import pipeline, synthetic
-from regnet_for_3d_grasping_amd.get_regiondataset import get_grasp_allobj, _select_score_center, _get_group_pc
+from regnet_for_3d_grasping_amd.get_regiondataset import _select_score_center, _get_group_pc
 dev = torch.device("cuda:0")
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 score_net, region_net = pipeline.build_models(dev)
