@@ -1,0 +1,47 @@
+"""bench.py's driver contract: one JSON line with the agreed fields, the roofline object of the dominant kernel, the CPU
+baseline and the parity figures; also under torch.distributed.run with one rank (the RCCL init / barrier path)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _line(cmd, env=None):
+    out = subprocess.run(cmd, cwd=REPO, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, text=True)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]            # exactly ONE JSON line on stdout
+    return json.loads(lines[0])
+
+
+def test_bench_line_has_the_contract_fields():
+    d = _line([sys.executable, "bench.py", "--steps", "6", "--warmup", "2", "--cpu-scenes", "1"])
+    for key, typ in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
+                     ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str),
+                     ("config", dict), ("roofline", dict), ("cpu_baseline", dict)):
+        assert isinstance(d[key], typ), key
+    assert d["vs_baseline"] is None and d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 2
+    assert d["scaling"] == "weak" and d["higher_is_better"] is True and d["dtype"] == "f32" and d["unit"] == "scenes/s"
+    assert "workload" in d["config"] and "model" not in d["config"] and d["config"]["batch_per_gpu"] == 8
+    assert abs(d["value"] - 8 * 6 / (d["ms_per_step"] * 6 / 1e3)) < 1e-2 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and r["kernel"]
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-5 and 0 < r["frac"] < 1
+    assert r["traffic"] is None or r["traffic"] > 0
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+    p = d["parity"]
+    assert p["region_indices_equal"] is True and p["score_max_abs_err"] <= p["tolerance"] == 1e-4
+    assert p["grasp_max_abs_err"] <= 1e-4 and p["feature_max_rel_err"] <= 1e-4
+
+
+def test_bench_under_torch_distributed_run_single_rank():
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    d = _line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+               "127.0.0.1", "--master-port", "29533", "bench.py", "--gpus", "1", "--steps", "4", "--warmup", "1", "--cpu-scenes", "1"], env)
+    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["value"] > 0 and "cpu_baseline" in d
