@@ -54,8 +54,8 @@ class ForwardPipeline:
     Scenes are independent, and inside one batch the sampling / grouping geometry depends on xyz
     only.  Level-1 furthest point sampling is a latency-bound chain of 5119 dependent rounds that
     keeps one CU per scene busy for ~10 ms, while the shared-MLP contraction wants the other ~250
-    CUs and region grouping needs the host for numpy's RNG.  So four stages run concurrently on four
-    HIP streams, each on a different batch:
+    CUs and region grouping needs the host for numpy's RNG.  So four stages run concurrently on five
+    (or more) HIP streams, each on a different batch:
 
         s_fps : sample(batch i+2, i+3) level-1 FPS, two batches at a time on two streams: a launch is a
                                       ~10 ms latency chain on ONE CU per scene, so two of them in
@@ -71,8 +71,8 @@ class ForwardPipeline:
 
     def __init__(self, score_net, region_net, with_region=True, fps_streams=2, mlp_streams=1):
         """``fps_streams``: level-1 sampling launches in flight (each ~10 ms on one CU per scene, whatever the batch
-        size): 2 keep up with the matrix cores at 8 scenes per batch.  (Smaller batches are bound by the host's ~6 ms of
-        launch work per step, not by the sampling: more streams measured slower there.)
+        size): 2 keep up with the matrix cores at 8 scenes per batch.  (Batches of 1-4 scenes are bound by the region
+        stage's ~4.6 ms on its host thread, not by the sampling: more streams measured slower there.)
         ``mlp_streams``: feature stages (consecutive batches) that may overlap.  One batch's ~30 MFMA launches leave the
         chip partly idle at every kernel tail and in the small layers (P <= 40 960 rows); a second stream fills those
         holes with the next batch's kernels: 9.70 -> 9.14 ms per batch of 8 (824 -> 875 scenes/s) with
