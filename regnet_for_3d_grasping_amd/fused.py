@@ -48,6 +48,25 @@ def _stream(t):
     return torch.cuda.current_stream(t.device).cuda_stream
 
 
+def _on_tensor_device(fn):
+    """Run a kernel wrapper with the HIP device of its first GPU tensor argument current (hipLaunchKernel on a stream
+    of another device fails with an invalid-resource-handle error): a model living on cuda:k must work whatever
+    ``torch.cuda.current_device()`` is, like pn2_ext / region_ops / bn_train.  Free when the device is already
+    current (the common case: one process per GPU)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(*args, **kwargs):
+        for a in args:
+            if isinstance(a, torch.Tensor) and a.is_cuda:
+                if a.device.index != torch.cuda.current_device():
+                    with torch.cuda.device(a.device):
+                        return fn(*args, **kwargs)
+                break
+        return fn(*args, **kwargs)
+    return wrapped
+
+
 def _round_up(x, m):
     return (x + m - 1) // m * m
 
@@ -108,6 +127,7 @@ def _packed_stack(owner, stack, first_col_order=None):
 
 
 # ---- thin kernel wrappers (module-level names so bench.py can bracket them with events) ------
+@_on_tensor_device
 def mlp_layer(A, Ka, layer, P, pool_group=0):
     """A: channels-last (P, lda) float32 buffer whose first Ka columns are valid."""
     rows = P // pool_group if pool_group else P
@@ -131,6 +151,7 @@ def mlp_layer(A, Ka, layer, P, pool_group=0):
     return out
 
 
+@_on_tensor_device
 def sa_layer1(feature, xyz, nbr, ctr, layer, B, M, group):
     """Gather-fused first SA layer.  feature (B,Cf,N) any strides or None; xyz (B,3,N) any strides."""
     out = torch.empty((B * M * group, layer.N), dtype=torch.float32, device=xyz.device)
@@ -145,6 +166,7 @@ def sa_layer1(feature, xyz, nbr, ctr, layer, B, M, group):
     return out
 
 
+@_on_tensor_device
 def sa_layer12(feature, xyz, nbr, ctr, first, layer, B, M, group, pool_group=0):
     """Gather + layer 1 (VALU, inside the operand load) + layer 2 (MFMA) of a narrow-input SA block."""
     P = B * M * group
@@ -177,6 +199,7 @@ def _premul_layers(first, Cf):
     return first.premul
 
 
+@_on_tensor_device
 def pack_rows(feature, xyz, width):
     """Channels-last rows [feature | xyz | 0] of every point: feature (B,Cf,N) or None, xyz (B,3,N) -> (B*N, width)."""
     B, _, N = xyz.shape
@@ -190,6 +213,7 @@ def pack_rows(feature, xyz, width):
     return out
 
 
+@_on_tensor_device
 def sa_premul_layer(U, V, nbr, layer, B, Nsrc, M, group, pool_group=0):
     """Layer 2 of a set-abstraction block over pre-multiplied layer-1 rows: relu(U[nbr] - V[centre]) . W."""
     P = B * M * group
@@ -202,6 +226,7 @@ def sa_premul_layer(U, V, nbr, layer, B, Nsrc, M, group, pool_group=0):
     return out
 
 
+@_on_tensor_device
 def sa_chain3(feature, xyz, nbr, ctr, l1, l2, l3, B, M, group, count=None, order=None):
     """Whole narrow-input SA block (gather, three layers, max over the neighbours) in one kernel; -> (B*M, C3).
     ``count`` (B,M) int64: members per neighbourhood (half the work for those with <= 32); ``order`` (B*M,) int64:
@@ -220,6 +245,7 @@ def sa_chain3(feature, xyz, nbr, ctr, l1, l2, l3, B, M, group, count=None, order
     return out
 
 
+@_on_tensor_device
 def sa_chain_premul(U, V, nbr, l2, l3, B, Nsrc, M, group):
     """Layers 2 + 3 + max over the neighbours of a wide SA block on pre-multiplied layer-1 rows; -> (B*M, C3)."""
     out = torch.empty((B * M, l3.N), dtype=torch.float32, device=U.device)
@@ -231,6 +257,7 @@ def sa_chain_premul(U, V, nbr, l2, l3, B, Nsrc, M, group):
     return out
 
 
+@_on_tensor_device
 def interp_concat(sparse_cl, idx, dist2, eps, dense_feature, B, Nd):
     """sparse_cl: (B,Ns,Cs) channels-last contiguous; dense_feature (B,Cd,Nd) any strides or None.
     Returns the (B*Nd, round_up(Cs+Cd,4)) channels-last operand of the first FP layer and its valid width."""
@@ -272,6 +299,7 @@ def _fp_split_layers(first, Cs):
     return first.premul
 
 
+@_on_tensor_device
 def interp_affine(Ys, idx, dist2, eps, Yd, dense_small, wd4, layer, B, Ns, Nd):
     """relu(scale * (sum_k w_k Ys[idx_k] + Yd + Wd4 . dense_small) + shift): the 3-NN interpolation of
     pre-multiplied sparse rows.  ``dense_small``: (B,Cd<=4,Nd) any strides, or None."""
@@ -305,6 +333,7 @@ def _packed_head(seg):
     return cache[1]
 
 
+@_on_tensor_device
 def score_head(x, seg, P):
     w, bias, bn_scale, bn_shift = _packed_head(seg)
     score = torch.empty((P,), dtype=torch.float32, device=x.device)

@@ -16,24 +16,74 @@ import torch
 
 def allreduce_gradients(parameters, reduce="sum"):
     """One collective for all gradients: flatten -> all_reduce(SUM) -> scatter back.
-    Parameters whose ``.grad`` is None (e.g. the reference's never-used ``linear_cls``) are skipped on
-    every rank alike.  ``reduce='mean'`` divides by the world size."""
+
+    The buffer layout depends on the PARAMETER LIST only, never on this rank's data: every parameter with
+    ``requires_grad`` owns a slot, and a parameter whose ``.grad`` is None on this rank (the reference's never-used
+    ``linear_cls``; the whole region network when this rank's region stage failed; the refine heads when this
+    rank had fewer than two grasps in the gripper) contributes zeros.  All ranks therefore always issue the same
+    all_reduce of the same length -- a rank that skipped a loss can neither shorten the collective nor miss it
+    (``nn.DataParallel``, utils.py:129-133, has no such failure mode either: its replicas reduce every parameter).
+    After the reduction a parameter receives a ``.grad`` iff ANY rank had one (decided by a per-parameter
+    participation count carried at the tail of the same buffer), so replicas apply identical optimizer steps and
+    parameters no rank touched keep ``grad is None`` (Adam leaves their state alone, like a single process).
+    ``reduce='mean'`` divides by the world size.  Returns the number of gradient elements reduced."""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return 0
-    grads = [p.grad for p in parameters if p.grad is not None]
-    if not grads:
+    params = [p for p in parameters if p.requires_grad]
+    if not params:
         return 0
-    flat = torch.cat([g.reshape(-1) for g in grads])
+    n_grad = sum(p.numel() for p in params)
+    dev = params[0].device
+    pieces = [p.grad.reshape(-1).to(torch.float32) if p.grad is not None
+              else torch.zeros(p.numel(), dtype=torch.float32, device=dev) for p in params]
+    pieces.append(torch.tensor([0.0 if p.grad is None else 1.0 for p in params], dtype=torch.float32).to(dev))
+    flat = torch.cat(pieces)
     dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     if reduce == "mean":
-        flat /= dist.get_world_size()
+        flat[:n_grad] /= dist.get_world_size()
+    present = flat[n_grad:].tolist()     # one host read per step; identical on every rank
     offset = 0
-    for g in grads:
-        n = g.numel()
-        g.copy_(flat[offset:offset + n].view_as(g))
+    for i, p in enumerate(params):
+        n = p.numel()
+        if present[i] > 0:
+            g = flat[offset:offset + n].view_as(p)
+            if p.grad is None:
+                p.grad = g.clone()
+            else:
+                p.grad.copy_(g)
         offset += n
-    return flat.numel()
+    return n_grad
+
+
+def broadcast_module_state(*modules, src=0):
+    """Make every rank start from rank ``src``'s parameters and buffers (BatchNorm running statistics included):
+    one flat broadcast per dtype.  ``nn.DataParallel`` re-replicates device 0's weights every step
+    (utils.py:129-133); with one process per GPU the replicas only stay identical if they START identical and
+    see identical (all-reduced) gradients -- without this an unseeded ``construct_scorenet(load_flag=False)``
+    would silently train N different models.  No-op without an initialised process group."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return 0
+    tensors = []
+    for m in modules:
+        tensors.extend(p.data for p in m.parameters())
+        tensors.extend(b.data for b in m.buffers())
+    total = 0
+    by_dtype = {}
+    for t in tensors:
+        by_dtype.setdefault(t.dtype, []).append(t)
+    for dtype in sorted(by_dtype, key=str):      # same order on every rank
+        group = by_dtype[dtype]
+        flat = torch.cat([t.reshape(-1) for t in group])
+        dist.broadcast(flat, src=src)
+        offset = 0
+        for t in group:
+            n = t.numel()
+            t.copy_(flat[offset:offset + n].view_as(t))
+            offset += n
+        total += flat.numel()
+    return total
 
 
 class ScoreTrainer:
@@ -43,6 +93,7 @@ class ScoreTrainer:
     def __init__(self, score_net, lr=0.001, reduce="sum"):
         self.net = score_net
         self.reduce = reduce
+        broadcast_module_state(score_net)
         self.optimizer = torch.optim.Adam([{"params": score_net.parameters(), "initial_lr": lr}], lr=lr)
         self.scheduler = torch.optim.lr_scheduler.StepLR(self.optimizer, step_size=5, gamma=0.5)
         self.geometry = GeometryPrefetcher(score_net)
@@ -111,6 +162,7 @@ class RefineTrainer:
     def __init__(self, score_net, region_net, params, gripper_params, lr=0.001, reduce="sum"):
         self.score_net, self.region_net = score_net, region_net
         self.params, self.gripper_params, self.reduce = params, gripper_params, reduce
+        broadcast_module_state(score_net, region_net)
         self.opt_score = torch.optim.Adam([{"params": score_net.parameters(), "initial_lr": lr}], lr=lr)
         self.opt_region = torch.optim.Adam([{"params": region_net.parameters(), "initial_lr": lr}], lr=lr)
         self.sched_score = torch.optim.lr_scheduler.StepLR(self.opt_score, step_size=5, gamma=0.5)
