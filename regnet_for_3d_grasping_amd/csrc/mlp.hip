@@ -21,6 +21,7 @@
 // registers (the gather prologue needs per-row pointers), prefetching tile t+1 while tile t is
 // multiplied; two LDS buffers, one barrier per k-tile.
 #include "common.h"
+#include "gemm2.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -36,6 +37,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef MLP_ABLATE
 #define MLP_ABLATE 0  // timing experiments only (scripts/ablate): 1 no global loads after tile 0, 2 also no LDS
                       // refill / barrier, 3 no epilogue, 4 = 2 + 3; results are wrong for anything but 0
+#endif
+#ifndef MLP_TRACE
+#define MLP_TRACE 0   // timing experiments only (scripts/ablate/g2_bench.cpp): per-workgroup s_memtime stamps + HW_ID, optional
+                      // start-up stagger of the co-resident workgroups
 #endif
 #define LDS_LD (BK + 4)  // +4 floats: the 16-lane service groups of ds_read_b128 then hit 64 distinct banks
 #define ROWS_PER_PASS (MLP_THREADS / (BK / 4))  // rows one staging pass of the 256 threads covers
@@ -90,6 +95,11 @@ struct MlpArgs {
   int ksplit;      // > 1: deterministic split-K for skinny problems -- workgroup (tile, s) multiplies k-slice s and writes its RAW
                    // partial sums to C + s * P * ldc (C is then a workspace); splitk_finish_kernel adds the slices in order
   int wide_store;  // C rows 16-byte aligned (ldc % 4 == 0): interior tiles use the LDS-transposed dwordx4 epilogue
+#if MLP_TRACE
+  unsigned long long* trace;   // [grid][6]: hw_id, xcc_id, t_start, t_loop, t_loop_end, t_end
+  int stagger_cycles;          // first-round workgroups wait (wave slot & 3) * stagger_cycles before starting
+  int first_round;
+#endif
 };
 
 __device__ __forceinline__ void xcd_tile(unsigned vblock, int& tm, int& tn, int tiles_m, int tiles_n) {
@@ -115,6 +125,14 @@ __global__ __launch_bounds__(MLP_THREADS, AMODE == 2 ? 3 : MLP_MIN_WAVES) void m
   static_assert(2 * BM * LDS_LD + 2 * BN * LDS_LD >= 4 * 64 * 36, "epilogue staging does not fit");
   __shared__ __attribute__((aligned(16))) float sW1[AMODE == 2 ? 256 * 10 : 4];  // [C1 <= 256][8 weights | scale | shift]
 
+#if MLP_TRACE
+  const unsigned hw_id = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc_id = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+  if (p.stagger_cycles > 0 && (int)blockIdx.x < p.first_round) {
+    const unsigned long long until = __builtin_readcyclecounter() + (unsigned long long)(hw_id & 3) * p.stagger_cycles;
+    while (__builtin_readcyclecounter() < until) __builtin_amdgcn_s_sleep(16);
+  }
+  const unsigned long long tr_start = __builtin_readcyclecounter();
+#endif
   constexpr bool GATHER = AMODE == 1 || AMODE == 2;
   constexpr bool FUSE1 = AMODE == 2;
   constexpr bool PREMUL = AMODE == 3;
@@ -293,6 +311,9 @@ __global__ __launch_bounds__(MLP_THREADS, AMODE == 2 ? 3 : MLP_MIN_WAVES) void m
   }
   __syncthreads();
   const int fr = lane & 31, fh = lane >> 5;
+#if MLP_TRACE
+  const unsigned long long tr_loop = __builtin_readcyclecounter();
+#endif
   for (int kt = kt0; kt < KT; ++kt) {
     const int buf = (kt - kt0) & 1;
     if (kt + 1 < KT && !(MLP_ABLATE == 1 || MLP_ABLATE == 2 || MLP_ABLATE == 4)) LOAD_TILE((kt + 1) * BK);
@@ -331,6 +352,9 @@ __global__ __launch_bounds__(MLP_THREADS, AMODE == 2 ? 3 : MLP_MIN_WAVES) void m
     return;
   }
 
+#if MLP_TRACE
+  const unsigned long long tr_loop_end = __builtin_readcyclecounter();
+#endif
   // ---- epilogue: folded BN affine + ReLU (+ max over the 64 rows of a group) -------------
   // C/D layout of v_mfma_f32_32x32x2_f32: element r of lane l is row (r&3) + 8*(r>>2) + 4*(l>>5), col l&31.
   const bool splitk = !POOL && p.ksplit > 1;
@@ -408,10 +432,24 @@ __global__ __launch_bounds__(MLP_THREADS, AMODE == 2 ? 3 : MLP_MIN_WAVES) void m
       }
     }
   }
+#if MLP_TRACE
+  if (p.trace && tid == 0) {
+    unsigned long long* t = p.trace + (long long)blockIdx.x * 6;
+    t[0] = hw_id; t[1] = xcc_id; t[2] = tr_start; t[3] = tr_loop; t[4] = tr_loop_end; t[5] = __builtin_readcyclecounter();
+  }
+#endif
 }
+
+#if MLP_TRACE
+static unsigned long long* g_mlp_trace = nullptr;   // set by the harness before a launch
+static int g_mlp_stagger = 0, g_mlp_first_round = 0;
+#endif
 
 static int launch_gemm(const MlpArgs& a_in, int amode, bool pool, hipStream_t st) {
   MlpArgs a = a_in;
+#if MLP_TRACE
+  a.trace = g_mlp_trace; a.stagger_cycles = g_mlp_stagger; a.first_round = g_mlp_first_round;
+#endif
   a.wide_store = ((reinterpret_cast<uintptr_t>(a.C) & 15) == 0) && (a.ldc % 4 == 0);
   const long long tiles = ((a.P + BM - 1) / BM) * ((a.N + BN - 1) / BN);
   if (tiles <= 0) return REGNET_OK;
@@ -432,6 +470,45 @@ static int launch_gemm(const MlpArgs& a_in, int amode, bool pool, hipStream_t st
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+#ifndef MLP_USE_GEMM2
+#define MLP_USE_GEMM2 1   // 0: plain layers on mlp_gemm_kernel (the round-1 kernel; kept for the gather / pre-multiplied variants)
+#endif
+#define G2_CUS 256
+
+// Tile choice (measured on the ScoreNet shapes, scripts/ablate/g2_bench.cpp): 256 x 128 x 8 waves (2 workgroups per CU)
+// when that grid still fills the chip, 128 x 128 x 4 waves (3 per CU) for few rows or N <= 128.  The last partial
+// round of tiles is cut into half-height slices (tail split) when it would occupy at most half the workgroup slots.
+template <int TBM, int TBN, int WM, int WN, int STAGES, int OCC>
+static int launch_gemm2_tile(G2Args g, bool pool, hipStream_t st) {
+  g.tiles_m = (int)((g.P + TBM - 1) / TBM);
+  g.tiles_n = (g.N + TBN - 1) / TBN;
+  const long long tiles = (long long)g.tiles_m * g.tiles_n;
+  if (tiles >= (1ll << 30)) return REGNET_ERR_UNSUPPORTED;
+  const long long slots = (long long)G2_CUS * OCC;
+  long long main_blocks = tiles, tail_tiles = 0;
+  constexpr bool can_split = (TBM / WM / 32 == 2) && ((WM * 32 + TBN) / 16) % (WM * WN) == 0;
+  if (!pool && can_split && tiles > slots) {
+    const long long rem = tiles % slots;
+    if (rem > 0 && rem * 2 <= slots) { main_blocks = tiles - rem; tail_tiles = rem; }
+  }
+  g.main_blocks = (int)main_blocks; g.tail_tiles = (int)tail_tiles; g.tail_split = 2;
+  const dim3 grid((unsigned)(main_blocks + 2 * tail_tiles)), block(WM * WN * 64);
+  if (pool) {
+    if constexpr (TBM / WM == 64) hipLaunchKernelGGL((gemm2_kernel<TBM, TBN, WM, WN, STAGES, OCC, true>), grid, block, 0, st, g);
+    else return REGNET_ERR_UNSUPPORTED;
+  } else {
+    hipLaunchKernelGGL((gemm2_kernel<TBM, TBN, WM, WN, STAGES, OCC, false>), grid, block, 0, st, g);
+  }
+  REGNET_LAUNCH_CHECK();
+  return REGNET_OK;
+}
+
+static int launch_gemm2(const G2Args& g, bool pool, hipStream_t st) {
+  const long long tiles_big = ((g.P + 255) / 256) * ((g.N + 127) / 128);
+  if (g.N > 128 && tiles_big >= G2_CUS) return launch_gemm2_tile<256, 128, 4, 2, 3, 2>(g, pool, st);
+  return launch_gemm2_tile<128, 128, 2, 2, 3, 3>(g, pool, st);
+}
+
 extern "C" int regnet_mlp_layer_f32(const float* A, int64_t lda, int64_t Ka, const float* W, int64_t Kpad,
                                     const float* scale, const float* shift, float* C, int64_t ldc, int64_t P,
                                     int64_t N, int relu, int pool_group, void* stream) {
@@ -440,6 +517,12 @@ extern "C" int regnet_mlp_layer_f32(const float* A, int64_t lda, int64_t Ka, con
   if (P == 0) return REGNET_OK;
   if (!A || !W || !scale || !shift || !C) return REGNET_ERR_NULL;
   if (!aligned16(A) || !aligned16(W)) return REGNET_ERR_SHAPE;
+  if (MLP_USE_GEMM2 && Kpad >= 2 * G2_BK) {   // LDS-DMA ring kernel (gemm2.h); needs two k-tiles for its prologue
+    G2Args g = {};
+    g.A = A; g.lda = lda; g.Ka = (int)Ka; g.W = W; g.Kpad = (int)Kpad; g.scale = scale; g.shift = shift;
+    g.C = C; g.ldc = ldc; g.P = P; g.N = (int)N; g.relu = relu;
+    return launch_gemm2(g, pool_group != 0, as_stream(stream));
+  }
   MlpArgs a = {};
   a.A = A; a.lda = lda; a.Ka = (int)Ka;
   a.W = W; a.Kpad = (int)Kpad; a.scale = scale; a.shift = shift;

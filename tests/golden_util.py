@@ -211,3 +211,54 @@ def validate_case(i):
     g[:k, 6] = rng.uniform(-1.2, 1.2, k).astype(np.float32)
     g[:, 7] = rng.uniform(0, 1, n).astype(np.float32)
     return {"view_cloud": view, "scene_cloud": scene, "scene_normal": normal}, g
+
+
+# ---- stage S7: full-size fixtures (tests/golden/make_golden_fullsize.py -> s7_*.npz, s7_meta.json) -----------------
+def meta_full():
+    with open(os.path.join(GOLDEN, "s7_meta.json")) as f:
+        return json.load(f)
+
+
+def build_scorenet_full(m, device="cpu"):
+    """ScoreNet with the S7 weights and score-head calibration."""
+    from regnet_for_3d_grasping_amd.score_network import ScoreNetwork
+    net = ScoreNetwork(training=True)
+    net.load_state_dict(synthetic.seeded_state_dict(net, m["cfg"]["score_weights_seed"]))
+    bn = net.extrat_featurePN2.bn_score
+    bn.running_mean.fill_(m["bn_score"]["running_mean"])
+    bn.running_var.fill_(m["bn_score"]["running_var"])
+    bn.weight.data.fill_(m["bn_score"]["weight"])
+    bn.bias.data.fill_(m["bn_score"]["bias"])
+    return net.to(device).eval()
+
+
+def check_ops_per_scene(log, expected_ops, scenes):
+    """``log``: OpRecorder.log of a forward over the scenes ``scenes`` (indices into the fixture's batch); every index
+    tensor must equal the reference's, scene by scene (SHA-256 of the per-scene slice)."""
+    assert [n for n, _ in log] == [o["op"] for o in expected_ops]
+    for (name, outs), exp in zip(log, expected_ops):
+        assert list(outs[0].shape[1:]) == exp["shape"][1:], name
+        for i, b in enumerate(scenes):
+            assert sha(outs[0][i]) == exp["index_sha256"][b], "%s index mismatch (scene %d)" % (name, b)
+            if exp["aux_sha256"] is not None and name == "ball_query":
+                assert sha(outs[1][i]) == exp["aux_sha256"][b], "%s count mismatch (scene %d)" % (name, b)
+
+
+def region_inputs_full(m, device="cpu"):
+    """S7c inputs: scenes 0..B-1 of S7a, the REFERENCE's scores for them, the seeded pseudo feature map."""
+    cfg = m["cfg"]
+    Bc, N = cfg["c"]["B"], cfg["a"]["N"]
+    pc = synthetic.make_batch(cfg["a"]["scene_seed"], cfg["a"]["B"], N)[:Bc].contiguous().to(device)
+    score = torch.from_numpy(load("s7a_scorenet_25600.npz")["score"][:Bc].copy()).to(device)
+    feat = pseudo_feature(cfg["c"]["feature_seed"], Bc, N).to(device)
+    return pc, score, feat
+
+
+def build_regionnet_full(m, device="cpu"):
+    from regnet_for_3d_grasping_amd.gripper_region_network import GripperRegionNetwork
+    cfg = m["cfg"]
+    net = GripperRegionNetwork(training=True, group_num=cfg["params"][2], gripper_num=cfg["gripper_num"],
+                               grasp_score_threshold=cfg["grasp_score_threshold"], radius=cfg["gripper_params"][2],
+                               reg_channel=cfg["reg_channel"])
+    net.load_state_dict(synthetic.seeded_state_dict(net, cfg["region_weights_seed"]))
+    return net.to(device).eval()
