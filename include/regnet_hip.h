@@ -320,6 +320,26 @@ int regnet_interp_affine_f32(const float* ys, int64_t sb, int64_t sn, const int6
 int regnet_score_head_f32(const float* x, int64_t ldx, int64_t C, const float* w, float bias,
                           float bn_scale, float bn_shift, float* score, int64_t P, void* stream);
 
+/* regnet_fp_head_chain_f32: the tail of the last feature-propagation block and the whole segmentation head of
+ * PointNet2Seg as ONE kernel (utils/pointnet2.py:64-84 with fp_channels[2] = (256, 256, 256), :116-119 with
+ * seg_channels = (512, 256, 256, 128); pn2_utils/modules.py:500-509):
+ *     X (P, 256: the block's first layer, e.g. from regnet_interp_affine_f32) -> 256 -> 256 = F (P, 256), the point
+ *     feature ScoreNetwork returns -> 512 -> 256 -> 256 -> 128 -> conv_score + bn_score + sigmoid = score (P).
+ * Every layer is a bias-free 1x1 convolution + eval BatchNorm (folded to scale/shift) + ReLU.  A wave keeps the
+ * activations of 16 points in registers from X to the score (csrc/rowchain.hip); only X is read and only F / score
+ * are written -- the layer-wise path moves 15x the bytes.  Same values as six regnet_mlp_layer_f32 calls +
+ * regnet_score_head_f32 up to fp32 summation order.
+ * `stream_w`: regnet_fp_head_chain_stream_floats() floats = 60 stages of 32 KiB in consumption order -- per layer
+ * pair (A: 256 -> M, B: M -> N) and per 128-channel group g of M: four A-stages (rows 128 g + 32 u .. + 32 of W_A, all
+ * 256 columns) then N/64 B-stages (rows 64 v .. + 64 of W_B, columns 128 g .. + 128); inside a stage the 16-byte
+ * chunk c of row r is stored at chunk position c ^ (r & 15) (low 4 bits) of its row (bank-conflict-free fragment
+ * reads).  `affine`: per layer [scale(N) | shift(N)], layers in order: 3328 floats.  Rows and buffers 16-byte aligned. */
+int64_t regnet_fp_head_chain_stream_floats(void);
+int regnet_fp_head_chain_f32(const float* X, int64_t ldx, const float* stream_w, int64_t n_stages,
+                             const float* affine, int64_t affine_floats, const float* wscore, float score_bias,
+                             float score_bn_scale, float score_bn_shift, float* F, int64_t ldf, float* score,
+                             int64_t P, void* stream);
+
 /* ---- host-side numpy-compatible random draws of the region stage (no GPU involved) ------------
  * Replaces the per-centre / per-grasp np.random.choice calls of the reference's Python loops
  * (dataset_utils/get_regiondataset.py:331-337, multi_model/gripper_region_network.py:532-544) while

@@ -126,8 +126,12 @@ __global__ __launch_bounds__(T) void fps_resident_kernel(const float* __restrict
     }
     const float wmax = wave_max_f32(tmax);
     if ((tid & 63) == 0) part[buf][tid >> 6] = wmax;
-    if (tid == 0) win_key[buf ^ 1] = 0xffffffffu;  // re-arm the slot the NEXT round will use
     __syncthreads();
+    // Re-arm the slot the NEXT round will use -- only now: it is the slot of the PREVIOUS round, whose winner the other
+    // waves read right after that round's last barrier; this barrier is the first point at which all of them have.
+    // (Written before the barrier, a wave that ran ahead could wipe the key under a slower wave, which then kept its
+    // old centroid: a rare divergence of the waves' `cur`, seen only in the short-scan instantiations under load.)
+    if (tid == 0) win_key[buf ^ 1] = 0xffffffffu;
     float mx = 0.f;
 #pragma unroll
     for (int w4 = 0; w4 < WP / 4; ++w4) {
@@ -349,9 +353,9 @@ __global__ __launch_bounds__(1024) void fps_sorted_kernel(const float* __restric
     FPS_T(2);
     const float wmax = wave_max_f32(tmax);
     if (lane == 0) part[buf][wave] = wmax;
-    if (tid == 0) win_key[buf ^ 1] = 0xffffffffu;
     FPS_T(3);
     __syncthreads();
+    if (tid == 0) win_key[buf ^ 1] = 0xffffffffu;   // after the barrier: see fps_resident_kernel
     FPS_T(4);
     float mx = 0.f;
 #pragma unroll
@@ -504,8 +508,8 @@ __global__ __launch_bounds__(1024) void fps_multi_kernel(const float* __restrict
     }
     const float wmax = wave_max_f32(tmax);
     if ((tid & 63) == 0) part[buf][tid >> 6] = wmax;
-    if (tid == 0) win_key[buf ^ 1] = 0xffffffffu;
     __syncthreads();
+    if (tid == 0) win_key[buf ^ 1] = 0xffffffffu;   // after the barrier: see fps_resident_kernel
     float mx = 0.f;
 #pragma unroll
     for (int w4 = 0; w4 < WP / 4; ++w4) {

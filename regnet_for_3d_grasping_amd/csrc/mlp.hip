@@ -20,6 +20,7 @@
 // 16-lane service groups of ds_read_b128 hit 64 distinct banks (SQ_LDS_BANK_CONFLICT = 0).  Global->LDS goes through
 // registers (the gather prologue needs per-row pointers), prefetching tile t+1 while tile t is
 // multiplied; two LDS buffers, one barrier per k-tile.
+#include <stdlib.h>
 #include "common.h"
 #include "gemm2.h"
 
@@ -517,7 +518,8 @@ extern "C" int regnet_mlp_layer_f32(const float* A, int64_t lda, int64_t Ka, con
   if (P == 0) return REGNET_OK;
   if (!A || !W || !scale || !shift || !C) return REGNET_ERR_NULL;
   if (!aligned16(A) || !aligned16(W)) return REGNET_ERR_SHAPE;
-  if (MLP_USE_GEMM2 && Kpad >= 2 * G2_BK) {   // LDS-DMA ring kernel (gemm2.h); needs two k-tiles for its prologue
+  static const bool use_gemm2 = MLP_USE_GEMM2 && !(getenv("REGNET_GEMM2") && getenv("REGNET_GEMM2")[0] == '0');   // debugging switch
+  if (use_gemm2 && Kpad >= 2 * G2_BK) {   // LDS-DMA ring kernel (gemm2.h); needs two k-tiles for its prologue
     G2Args g = {};
     g.A = A; g.lda = lda; g.Ka = (int)Ka; g.W = W; g.Kpad = (int)Kpad; g.scale = scale; g.shift = shift;
     g.C = C; g.ldc = ldc; g.P = P; g.N = (int)N; g.relu = relu;

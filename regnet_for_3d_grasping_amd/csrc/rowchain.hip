@@ -1,0 +1,307 @@
+// rowchain.hip -- chains of shared-MLP layers over the SAME rows in one kernel (gfx950): a wave keeps 16 points'
+// activations in registers from the first layer to the last, only the weights move (L2 -> LDS ring -> MFMA operand).
+//
+// Reference behaviour restated (paths relative to /root/reference/multi_model/utils):
+//   FP3 tail + segmentation head of PointNet2Seg (pointnet2.py:64-84, :116-119; pn2_utils/modules.py:500-509):
+//     h1 (P x 256: first FP3 layer, produced by interp_affine) -> conv 256->256 -> conv 256->256 = the network's
+//     256-channel point feature F (returned, and read by the region stage) -> SharedMLP 256->512->256->256->128
+//     -> conv_score 128->1 + bn_score + sigmoid.        Every conv is bias-free 1x1 + eval BatchNorm (folded to a
+//     per-channel affine) + ReLU (pn2_utils/nn/modules/mlp.py:55-114); dropout is identity in eval mode.
+//   The layer-by-layer path (mlp.hip / gemm2.h) writes and re-reads every (204 800 x {256, 512}) activation of a
+//   batch: 3.1 GB of HBM traffic per step for 0.2 TFLOP.  Here: h1 is read once, F and the scores are written once.
+//
+// Scheme (v_mfma_f32_16x16x4_f32: D[16x16] += A[16x4] . B[4x16]; A: lane l -> A[i = l & 15][k = l >> 4],
+// B: lane l -> B[k = l >> 4][j = l & 15], D: register r of lane l = D[i = 4 (l >> 4) + r][j = l & 15]):
+//   products are formed channel-major, D = W . X^T (rows = output channels, columns = the wave's 16 points).  Register r
+//   of output tile ot then holds, in lane (g = l >> 4, j = l & 15), channel 16 ot + 4 g + r of point j -- which is
+//   exactly a B operand of the next layer for the k-step "channels {16 kt + 4 g + r : g = 0..3}" (kt = ot).  The
+//   matching A operand is component r of the 16-byte chunk W[out][16 kt + 4 g ..]: one ds_read_b128 feeds 4 MFMAs.
+//   So a layer is   acc[ot] += mfma(Wfrag(ot, kt).r, xin[kt].r)   over kt, r, and BN + ReLU in place turn acc[] into
+//   the next layer's xin[] -- no activation ever leaves the register file.
+//   A wave owns 16 points: widths up to 512 -> (256 + 512) / 4 = 192 VGPRs for (input + output), 2 waves per SIMD.
+//   A workgroup = 8 waves = 128 rows; its waves share the weight stream: 32 KiB stages ([32 output channels][256 k],
+//   dense rows, 16-byte chunks XOR-swizzled by the row so the fragment reads are bank-conflict free) fetched by
+//   LDS-DMA into a ring of 3, two stages in flight across every barrier (counted vmcnt, written by hand).  The stream
+//   is laid out on the host in consumption order, already swizzled: the fetch is a linear copy.
+//   Rows are split statically and evenly over the workgroups (units of 16 rows): every CU finishes within one
+//   16-row unit of the others, the last partial pass runs with fewer waves per SIMD and therefore faster.
+#include "common.h"
+
+typedef float rc_f32x4 __attribute__((ext_vector_type(4)));
+
+#define RC_WAVES 8
+#define RC_THREADS (RC_WAVES * 64)
+#define RC_STAGE_FLOATS (32 * 256)             // 32 KiB
+#define RC_STAGES 3
+#define RC_PIECES 4                            // 1 KiB LDS-DMA pieces per wave per stage (32 KiB / 8 waves)
+#define RC_AFFINE_MAX 4096                     // floats of folded BN affine kept in LDS
+
+struct RcArgs {
+  const float* X;  long long ldx;              // (P, 256) first-layer activation (channels-last), 16-byte aligned rows
+  float* F;        long long ldf;              // (P, 256) point feature out
+  float* score;                                // (P)
+  long long P;
+  const float* stream;                         // weight stream: n_stages x 32 KiB, consumption order, swizzled
+  int n_stages;                                // stages per pass over a row block (the chain's total)
+  const float* affine;                         // per layer [scale(N) | shift(N)], concatenated in layer order
+  int affine_floats;
+  const float* wscore;                         // conv_score weight (128)
+  float score_bias, score_bn_scale, score_bn_shift;
+  long long units_per_wg;                      // 16-row units per workgroup (static even split)
+};
+
+__device__ __forceinline__ void rc_glds16(const float* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+template <int N> __device__ __forceinline__ void rc_wait_barrier() {
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "i"(N) : "memory");
+}
+
+// The weight-stream ring.  Stage s of the (periodic) stream lives in ring slot s % RC_STAGES.
+struct RcRing {
+  const float* src;        // this lane's source of piece 0 of the next stage to fetch
+  const float* src_begin;  // ... of stream stage 0
+  int fetch_idx;           // stream index (0 .. n_stages) of the next stage to fetch
+  int n_stages;
+  unsigned lds_fetch;      // LDS byte address of this wave's piece 0 in the slot the next fetch goes to
+  unsigned lds_lo, lds_hi; // ... in slot 0 / one past the last slot
+  int slot;                // ring slot of the stage to be consumed next
+
+  __device__ __forceinline__ void fetch() {
+#pragma unroll
+    for (int j = 0; j < RC_PIECES; ++j) rc_glds16(src + j * 256, lds_fetch + j * 1024);
+    src += RC_STAGE_FLOATS;
+    if (++fetch_idx == n_stages) { fetch_idx = 0; src = src_begin; }
+    lds_fetch += RC_STAGE_FLOATS * 4;
+    if (lds_fetch == lds_hi) lds_fetch = lds_lo;
+  }
+  // Make the next stage readable (mine: counted wait; everybody's: barrier -- which also says that nobody reads the
+  // slot consumed last any more) and start the fetch of the stage behind the ones in flight into that slot.
+  // The counted wait stays correct with other vector memory operations outstanding (activation loads, feature
+  // stores, issued after the newest fetch): loads return in order among loads, so "at most 4 operations outstanding"
+  // implies that at most the 4 newest LOADS are -- every piece of the stage wanted here is older than those; extra
+  // operations only make the wait longer.  DRAIN (vmcnt(0)) is kept as a debugging switch.
+  template <bool DRAIN> __device__ __forceinline__ int acquire() {
+    if (DRAIN) rc_wait_barrier<0>();
+    else rc_wait_barrier<(RC_STAGES - 2) * RC_PIECES>();
+    fetch();
+    const int s = slot;
+    slot = (slot + 1 == RC_STAGES) ? 0 : slot + 1;
+    return s;
+  }
+};
+
+// Per-lane fragment offsets (floats) inside a stage.  A-stages are [32 rows][256 k], B-stages [64 rows][128 k]; in both
+// the logical 16-byte chunk 4 kt + g of row (16 t + j) is stored at physical chunk (4 kt + g) ^ j =
+// 16 (kt >> 2) + ((4 (kt & 3)) ^ (g ^ j)): the 16 lanes of a ds_read_b128 service group then hit 16 distinct 16-byte
+// slots of the 256-byte bank row (the row strides, 1024 and 512 bytes, are multiples of it).
+struct RcFrag { int a[4], b[4]; };
+__device__ __forceinline__ RcFrag rc_frag_offsets() {
+  const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
+  RcFrag f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    f.a[q] = j * 256 + 4 * ((4 * q) ^ (g ^ j));
+    f.b[q] = j * 128 + 4 * ((4 * q) ^ (g ^ j));
+  }
+  return f;
+}
+
+#define RC_MFMA8(W0, W1, X, A0, A1)                                        \
+  A0 = __builtin_amdgcn_mfma_f32_16x16x4f32(W0.x, X.x, A0, 0, 0, 0);       \
+  A1 = __builtin_amdgcn_mfma_f32_16x16x4f32(W1.x, X.x, A1, 0, 0, 0);       \
+  A0 = __builtin_amdgcn_mfma_f32_16x16x4f32(W0.y, X.y, A0, 0, 0, 0);       \
+  A1 = __builtin_amdgcn_mfma_f32_16x16x4f32(W1.y, X.y, A1, 0, 0, 0);       \
+  A0 = __builtin_amdgcn_mfma_f32_16x16x4f32(W0.z, X.z, A0, 0, 0, 0);       \
+  A1 = __builtin_amdgcn_mfma_f32_16x16x4f32(W1.z, X.z, A1, 0, 0, 0);       \
+  A0 = __builtin_amdgcn_mfma_f32_16x16x4f32(W0.w, X.w, A0, 0, 0, 0);       \
+  A1 = __builtin_amdgcn_mfma_f32_16x16x4f32(W1.w, X.w, A1, 0, 0, 0);
+
+// Two consecutive layers  A: 256 -> M  and  B: M -> N  as one loop over the 128-channel groups of M:
+//     mid = actA(affA(W_A[group rows] . xin))          4 A-stages ([32 rows][256 k]),  32 registers
+//     acc += W_B[:, group columns] . mid               N/64 B-stages ([64 rows][128 k])
+// and xout = actB(affB(acc)) at the end.  Nothing in here is indexed by a loop counter except memory: xin, mid and
+// the N/16 accumulators are compile-time register arrays (a register array written at a run-time index would be
+// spilled), and the loop body -- 8 or 6 stages, 128 MFMAs each -- is small enough for the whole chain to stay in the
+// instruction cache.  Stream order: for each group, its A-stages then its B-stages.
+template <int M, int N, bool RELU_B>
+__device__ __forceinline__ void rc_pair(const rc_f32x4 (&xin)[16], rc_f32x4 (&xout)[N / 16], RcRing& ring,
+                                        const float* __restrict__ smem, const float* __restrict__ affA,
+                                        const float* __restrict__ affB, bool active, const RcFrag& fo) {
+  static_assert(M % 128 == 0 && N % 64 == 0, "groups of 128 mid channels; B-stages of 64 output channels");
+  const int g4 = ((threadIdx.x & 63) >> 4) * 4;
+#pragma unroll
+  for (int ot = 0; ot < N / 16; ++ot) xout[ot] = rc_f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int ob = 0; ob < M / 128; ++ob) {
+    rc_f32x4 mid[8];
+    // ---- layer A, channels [128 ob, 128 ob + 128)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      rc_f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+      const int slot = ring.acquire<false>();
+      if (active) {
+        const float* st = smem + slot * RC_STAGE_FLOATS;
+#pragma unroll
+        for (int kt = 0; kt < 16; ++kt) {
+          const float* wp = st + fo.a[kt & 3] + 64 * (kt >> 2);
+          const rc_f32x4 w0 = *reinterpret_cast<const rc_f32x4*>(wp);
+          const rc_f32x4 w1 = *reinterpret_cast<const rc_f32x4*>(wp + 16 * 256);
+          const rc_f32x4 x = xin[kt];
+          RC_MFMA8(w0, w1, x, acc0, acc1)
+        }
+      }
+      const float* a = affA + 128 * ob + 32 * u + g4;   // register r of tile t = channel 16 t + 4 g + r
+      const rc_f32x4 s0 = *reinterpret_cast<const rc_f32x4*>(a), s1 = *reinterpret_cast<const rc_f32x4*>(a + 16);
+      const rc_f32x4 t0 = *reinterpret_cast<const rc_f32x4*>(a + M), t1 = *reinterpret_cast<const rc_f32x4*>(a + M + 16);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        acc0[r] = fmaxf(acc0[r] * s0[r] + t0[r], 0.f);
+        acc1[r] = fmaxf(acc1[r] * s1[r] + t1[r], 0.f);
+      }
+      mid[2 * u] = acc0; mid[2 * u + 1] = acc1;
+    }
+    // ---- layer B, k-slice [128 ob, 128 ob + 128) for all N outputs
+#pragma unroll
+    for (int v = 0; v < N / 64; ++v) {
+      const int slot = ring.acquire<false>();
+      if (active) {
+        const float* st = smem + slot * RC_STAGE_FLOATS;
+#pragma unroll
+        for (int tp = 0; tp < 2; ++tp)      // tile pairs (4 v + 2 tp, + 1): two independent accumulators alternate
+#pragma unroll
+          for (int kt = 0; kt < 8; ++kt) {
+            const float* wp = st + (2 * tp) * 16 * 128 + fo.b[kt & 3] + 64 * (kt >> 2);
+            const rc_f32x4 w0 = *reinterpret_cast<const rc_f32x4*>(wp);
+            const rc_f32x4 w1 = *reinterpret_cast<const rc_f32x4*>(wp + 16 * 128);
+            const rc_f32x4 x = mid[kt];
+            RC_MFMA8(w0, w1, x, xout[4 * v + 2 * tp], xout[4 * v + 2 * tp + 1])
+          }
+      }
+    }
+  }
+#pragma unroll
+  for (int ot = 0; ot < N / 16; ++ot) {
+    const float* a = affB + 16 * ot + g4;
+    const rc_f32x4 s = *reinterpret_cast<const rc_f32x4*>(a), t = *reinterpret_cast<const rc_f32x4*>(a + N);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float y = xout[ot][r] * s[r] + t[r];
+      xout[ot][r] = RELU_B ? fmaxf(y, 0.f) : y;
+    }
+  }
+}
+
+// FP3 tail + segmentation head: 256 -> 256 -> [F] 256 -> 512 -> 256 -> 256 -> 128 -> score, as three layer pairs.
+// Stages per pass: 2 x (4 + 4) + 4 x (4 + 4) + 2 x (4 + 2) = 60.  Affine table (floats): layer i at the sum of 2 N of
+// the layers before it: 0, 512, 1024, 2048, 2560, 3072 (total 3328).
+__global__ __launch_bounds__(RC_THREADS, 2) void fp_head_chain_kernel(const RcArgs p) {
+  extern __shared__ __attribute__((aligned(1024))) float smem[];   // ring | affine | wscore
+  float* const aff = smem + RC_STAGES * RC_STAGE_FLOATS;
+  float* const wsc = aff + RC_AFFINE_MAX;
+  const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int i = tid; i < p.affine_floats; i += RC_THREADS) aff[i] = p.affine[i];
+  if (tid < 128) wsc[tid] = p.wscore[tid];
+#ifndef RC_NO_TABLE_SYNC
+  __syncthreads();   // the tables are read after the ring's barriers, which do not wait for LDS writes (lgkmcnt)
+#endif
+
+  RcRing ring;
+  ring.n_stages = p.n_stages;
+  ring.src_begin = p.stream + (wave * RC_PIECES) * 256 + lane * 4;
+  ring.src = ring.src_begin;
+  ring.fetch_idx = 0;
+  ring.lds_lo = (unsigned)(uintptr_t)smem + (unsigned)(wave * RC_PIECES * 1024);
+  ring.lds_hi = ring.lds_lo + RC_STAGES * RC_STAGE_FLOATS * 4;
+  ring.lds_fetch = ring.lds_lo;
+  ring.slot = 0;
+  const RcFrag fo = rc_frag_offsets();
+
+  const long long unit0 = (long long)blockIdx.x * p.units_per_wg;
+  const long long units_total = (p.P + 15) / 16;
+  long long unit_end = unit0 + p.units_per_wg;
+  if (unit_end > units_total) unit_end = units_total;
+  if (unit0 >= unit_end) return;
+  // prologue of the ring: RC_STAGES - 1 stages in flight
+#pragma unroll
+  for (int d = 0; d < RC_STAGES - 1; ++d) ring.fetch();
+
+  for (long long ub = unit0; ub < unit_end; ub += RC_WAVES) {
+    const long long unit = ub + wave;
+    const bool active = unit < unit_end;                       // wave-uniform
+    long long row = unit * 16 + j;
+    const bool row_ok = active && row < p.P;
+    if (!row_ok) row = 0;
+    // ---- h1: x0[kt] = X[row][16 kt + 4 g ..]
+    rc_f32x4 x0[16];
+    {
+      const float* xr = p.X + row * p.ldx + 4 * g;
+#pragma unroll
+      for (int kt = 0; kt < 16; ++kt) x0[kt] = *reinterpret_cast<const rc_f32x4*>(xr + 16 * kt);
+    }
+    rc_f32x4 x2[16];
+    rc_pair<256, 256, true>(x0, x2, ring, smem, aff + 0, aff + 512, active, fo);
+    // ---- F out
+    if (row_ok) {
+      float* fr = p.F + row * p.ldf + 4 * g;
+#pragma unroll
+      for (int ot = 0; ot < 16; ++ot) *reinterpret_cast<rc_f32x4*>(fr + 16 * ot) = x2[ot];
+    }
+    rc_f32x4 x4[16];
+    rc_pair<512, 256, true>(x2, x4, ring, smem, aff + 1024, aff + 2048, active, fo);
+    rc_f32x4 x6[8];
+    rc_pair<256, 128, true>(x4, x6, ring, smem, aff + 2560, aff + 3072, active, fo);
+    // ---- conv_score + bn_score + sigmoid
+    float acc = 0.f;
+#pragma unroll
+    for (int ot = 0; ot < 8; ++ot) {
+      const rc_f32x4 w = *reinterpret_cast<const rc_f32x4*>(wsc + 16 * ot + 4 * g);
+      acc += x6[ot].x * w.x; acc += x6[ot].y * w.y; acc += x6[ot].z * w.z; acc += x6[ot].w * w.w;
+    }
+    acc += __shfl_xor(acc, 16, 64);
+    acc += __shfl_xor(acc, 32, 64);
+    if (row_ok && g == 0) {
+      const float v = (acc + p.score_bias) * p.score_bn_scale + p.score_bn_shift;
+      p.score[row] = 1.0f / (1.0f + expf(-v));
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the ring's look-ahead fetches must land before the LDS is released
+}
+
+static bool rc_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+extern "C" int64_t regnet_fp_head_chain_stream_floats(void) { return 60ll * RC_STAGE_FLOATS; }
+
+extern "C" int regnet_fp_head_chain_f32(const float* X, int64_t ldx, const float* stream, int64_t n_stages,
+                                        const float* affine, int64_t affine_floats, const float* wscore,
+                                        float score_bias, float score_bn_scale, float score_bn_shift, float* F,
+                                        int64_t ldf, float* score, int64_t P, void* stream_handle) {
+  if (P < 0 || ldx < 256 || ldf < 256 || (ldx & 3) || (ldf & 3) || n_stages != 60 || affine_floats != 3328)
+    return REGNET_ERR_SHAPE;
+  if (P == 0) return REGNET_OK;
+  if (!X || !stream || !affine || !wscore || !F || !score) return REGNET_ERR_NULL;
+  if (!rc_aligned16(X) || !rc_aligned16(F) || !rc_aligned16(stream) || !rc_aligned16(affine) || !rc_aligned16(wscore))
+    return REGNET_ERR_SHAPE;
+  RcArgs a = {};
+  a.X = X; a.ldx = ldx; a.F = F; a.ldf = ldf; a.score = score; a.P = P;
+  a.stream = stream; a.n_stages = (int)n_stages; a.affine = affine; a.affine_floats = (int)affine_floats;
+  a.wscore = wscore; a.score_bias = score_bias; a.score_bn_scale = score_bn_scale; a.score_bn_shift = score_bn_shift;
+  const long long units = (P + 15) / 16;
+  const int cus = 256;
+  long long wgs = units < cus ? units : cus;
+  a.units_per_wg = (units + wgs - 1) / wgs;
+  wgs = (units + a.units_per_wg - 1) / a.units_per_wg;
+  const size_t lds = (size_t)(RC_STAGES * RC_STAGE_FLOATS + RC_AFFINE_MAX + 128) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fp_head_chain_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(fp_head_chain_kernel, dim3((unsigned)wgs), dim3(RC_THREADS), lds, as_stream(stream_handle), a);
+  REGNET_LAUNCH_CHECK();
+  return REGNET_OK;
+}

@@ -357,6 +357,7 @@ TIMED_OPS = {
     "sa_chain3": lambda feature, xyz, nbr, ctr, l1, l2, l3, B, M, group, count=None, order=None:
         "P%d K%d N%d flop%d" % (B * M * group, l3.K, l3.N,
                                 2 * B * M * group * (l1.K * l1.N + l2.K * l2.N + l3.K * l3.N)),
+    "fp_head_chain": lambda h1, seg, fp_layers, P: "P%d K256 N256 flop%d" % (P, 2 * P * 491520),
     "sa_layer12": lambda feature, xyz, nbr, ctr, first, layer, B, M, group, pool_group=0:
         "P%d K%d N%d flop%d" % (B * M * group, layer.K, layer.N,
                                 2 * B * M * group * (layer.K * layer.N + first.K * first.N)),
@@ -464,25 +465,34 @@ def fp_geometry(module, dense_xyz, sparse_xyz):
     return {"idx": idx, "dist2": dist2}
 
 
+def _fp_first_layer(module, layers, dense_xyz, dense_feature, sparse_feature, geo):
+    """First layer of a feature-propagation block evaluated on the SPARSE rows (see fp_features); -> (B*Nd, C1)
+    channels-last activation after BN + ReLU, or None when the split does not apply."""
+    B, _, Nd = dense_xyz.shape
+    Cs, Ns = sparse_feature.size(1), sparse_feature.size(2)
+    Cd = 0 if dense_feature is None else dense_feature.size(1)
+    first = layers[0]
+    if not (PREMUL and first.N % 4 == 0 and 256 % (first.N // 4) == 0 and Cs % 4 == 0 and (Cd % 4 == 0 or Cd <= 4)
+            and Ns < Nd and first.K == Cs + Cd and (dense_feature is None or dense_feature.dtype == torch.float32)):
+        return None
+    # layer 1 is linear in [interpolated | skip]: multiply the SPARSE rows (and the skip rows by their own
+    # weight columns), interpolate the products
+    lay_s, lay_d, wd4 = _fp_split_layers(first, Cs)
+    Ys = mlp_layer(_as_channels_last(sparse_feature).view(B * Ns, Cs), Cs, lay_s, B * Ns)
+    Yd = None
+    if lay_d is not None:
+        Yd = mlp_layer(_as_channels_last(dense_feature).view(B * Nd, Cd), Cd, lay_d, B * Nd)
+    return interp_affine(Ys, geo["idx"], geo["dist2"], module.interpolator._eps, Yd,
+                         dense_feature if wd4 is not None else None, wd4, first, B, Ns, Nd)
+
+
 def fp_features(module, dense_xyz, dense_feature, sparse_feature, geo):
     """Interpolate + concat + SharedMLP of a PointnetFPModule (modules.py:117-131, :507)."""
     B, _, Nd = dense_xyz.shape
     layers = _packed_stack(module, module.mlp)
-    Cs, Ns = sparse_feature.size(1), sparse_feature.size(2)
-    Cd = 0 if dense_feature is None else dense_feature.size(1)
-    first = layers[0]
-    if (PREMUL and first.N % 4 == 0 and 256 % (first.N // 4) == 0 and Cs % 4 == 0 and (Cd % 4 == 0 or Cd <= 4)
-            and Ns < Nd and first.K == Cs + Cd and (dense_feature is None or dense_feature.dtype == torch.float32)):
-        # layer 1 is linear in [interpolated | skip]: multiply the SPARSE rows (and the skip rows by their own
-        # weight columns), interpolate the products
-        lay_s, lay_d, wd4 = _fp_split_layers(first, Cs)
-        Ys = mlp_layer(_as_channels_last(sparse_feature).view(B * Ns, Cs), Cs, lay_s, B * Ns)
-        Yd = None
-        if lay_d is not None:
-            Yd = mlp_layer(_as_channels_last(dense_feature).view(B * Nd, Cd), Cd, lay_d, B * Nd)
-        h = interp_affine(Ys, geo["idx"], geo["dist2"], module.interpolator._eps, Yd,
-                          dense_feature if wd4 is not None else None, wd4, first, B, Ns, Nd)
-        Ka, P = first.N, B * Nd
+    h = _fp_first_layer(module, layers, dense_xyz, dense_feature, sparse_feature, geo)
+    if h is not None:
+        Ka, P = layers[0].N, B * Nd
         for layer in layers[1:]:
             h = mlp_layer(h, Ka, layer, P)
             Ka = layer.N
@@ -516,6 +526,91 @@ def head_forward(seg, sparse_feature):
         h = mlp_layer(h, Ka, layer, B * N)
         Ka = layer.N
     return score_head(h, seg, B * N).view(B, N)
+
+
+# ---- FP3 tail + segmentation head as ONE kernel (csrc/rowchain.hip) --------------------------------------------------
+ROWCHAIN = True   # last FP block's layers 2-3 + the whole head in one register-chained kernel
+
+
+def _swizzle_stage(block):
+    """(R, KC) weight block -> the LDS image of a rowchain stage: 16-byte chunk c' of row r holds logical chunk
+    c' ^ (r & 15) (XOR on the low 4 bits of the chunk index; see csrc/rowchain.hip:rc_frag_offsets)."""
+    R, KC = block.shape
+    chunks = block.reshape(R, KC // 4, 4)
+    r = torch.arange(R, device=block.device)[:, None]
+    cp = torch.arange(KC // 4, device=block.device)[None, :]
+    src = (cp & ~15) | ((cp ^ r) & 15)
+    return chunks.gather(1, src[:, :, None].expand(R, KC // 4, 4)).reshape(-1)
+
+
+def _rowchain_pair_stream(la, lb):
+    """Stream of one layer pair (A: 256 -> M, B: M -> N) in consumption order: per 128-channel group of M, four
+    A-stages [32 rows][256 k] then N/64 B-stages [64 rows][128 k]."""
+    WA, WB = la.W[:la.N, :la.K], lb.W[:lb.N, :lb.K]
+    M, N = la.N, lb.N
+    assert la.K == 256 and lb.K == M and M % 128 == 0 and N % 64 == 0
+    out = []
+    for ob in range(M // 128):
+        for u in range(4):
+            out.append(_swizzle_stage(WA[128 * ob + 32 * u:128 * ob + 32 * u + 32, :]))
+        for v in range(N // 64):
+            out.append(_swizzle_stage(WB[64 * v:64 * v + 64, 128 * ob:128 * ob + 128]))
+    return out
+
+
+def _packed_rowchain(seg, fp_layers):
+    """Weight stream + affine table of the FP3-tail + head chain, cached on ``seg`` per weight version."""
+    head = _packed_stack(seg.mlp, seg.mlp)
+    layers = list(fp_layers[1:]) + list(head)
+    sig = _signature(seg.fp_modules[-1]) + _signature(seg.mlp)
+    cache = getattr(seg, "_regnet_rowchain", None)
+    if cache is None or cache[0] != sig:
+        stages = []
+        for a, b in ((layers[0], layers[1]), (layers[2], layers[3]), (layers[4], layers[5])):
+            stages += _rowchain_pair_stream(a, b)
+        stream = torch.cat(stages).contiguous()
+        affine = torch.cat([torch.cat([L.scale[:L.N], L.shift[:L.N]]) for L in layers]).contiguous()
+        assert stream.numel() == _L.regnet_fp_head_chain_stream_floats() and affine.numel() == 3328
+        cache = (sig, (stream, affine))
+        seg._regnet_rowchain = cache
+    return cache[1]
+
+
+def supports_rowchain(seg, fp_module):
+    """The chained kernel covers exactly the reference's configuration (pointnet2.py:44-46): FP channels
+    (256, 256, 256) and head channels (512, 256, 256, 128) with ReLU everywhere, one score channel."""
+    if not ROWCHAIN or seg.k_score != 1:
+        return False
+    widths = [b.conv.out_channels for b in fp_module.mlp] + [b.conv.out_channels for b in seg.mlp]
+    relus = [b.relu is not None and b.bn is not None for b in list(fp_module.mlp) + list(seg.mlp)]
+    return widths == [256, 256, 256, 512, 256, 256, 128] and all(relus) and seg.mlp[0].conv.in_channels == 256
+
+
+@_on_tensor_device
+def fp_head_chain(h1, seg, fp_layers, P):
+    """h1 (P, 256) -> (F (P, 256), score (P,)): FP layers 2-3 and the segmentation head in one launch."""
+    stream, affine = _packed_rowchain(seg, fp_layers)
+    w, bias, bn_scale, bn_shift = _packed_head(seg)
+    F = torch.empty((P, 256), dtype=torch.float32, device=h1.device)
+    score = torch.empty((P,), dtype=torch.float32, device=h1.device)
+    _check(_L.regnet_fp_head_chain_f32(h1.data_ptr(), h1.stride(0), stream.data_ptr(), 60, affine.data_ptr(),
+                                       affine.numel(), w.data_ptr(), bias, bn_scale, bn_shift, F.data_ptr(),
+                                       F.stride(0), score.data_ptr(), P, _stream(h1)), "fp_head_chain")
+    return F, score
+
+
+def fp_head_forward(seg, fp_module, dense_xyz, dense_feature, sparse_feature, geo):
+    """Last feature-propagation block + segmentation head (pointnet2.py:64-84, :116-119) -> (feature (B,256,N) view,
+    score (B,N)); None when the chained kernel does not apply (the caller then runs the two blocks separately)."""
+    if not supports_rowchain(seg, fp_module):
+        return None
+    B, _, Nd = dense_xyz.shape
+    layers = _packed_stack(fp_module, fp_module.mlp)
+    h1 = _fp_first_layer(fp_module, layers, dense_xyz, dense_feature, sparse_feature, geo)
+    if h1 is None:
+        return None
+    F, score = fp_head_chain(h1, seg, layers, B * Nd)
+    return F.view(B, Nd, 256).transpose(1, 2), score.view(B, Nd)
 
 
 def plan_tensors(plan):

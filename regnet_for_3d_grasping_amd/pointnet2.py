@@ -99,9 +99,17 @@ class PointNet2Seg(nn.Module):
             xyz_stack.append(xyz)
             feat_stack.append(feat)
 
+        from . import fused
         sparse_xyz, sparse_feature = xyz_stack[-1], feat_stack[-1]
         for level, fp in enumerate(self.fp_modules):
             dense_xyz = xyz_stack[-2 - level]
+            if (level == len(self.fp_modules) - 1 and add_channel1 is None and fused.usable(self, dense_xyz)
+                    and fused.usable(fp, dense_xyz) and fused.supports_fp(fp, sparse_feature)):
+                # last FP block + head as one chained kernel (csrc/rowchain.hip)
+                geo = plan["fp"][level] if plan is not None else fused.fp_geometry(fp, dense_xyz, sparse_xyz)
+                chained = fused.fp_head_forward(self, fp, dense_xyz, feat_stack[-2 - level], sparse_feature, geo)
+                if chained is not None:
+                    return chained
             if plan is not None:
                 sparse_feature = fp(dense_xyz, sparse_xyz, feat_stack[-2 - level], sparse_feature,
                                     geo=plan["fp"][level])
@@ -113,7 +121,6 @@ class PointNet2Seg(nn.Module):
             extra = [c.view(B, 1, N).repeat(1, sparse_feature.shape[1], 1).float() for c in (add_channel1, add_channel2)]
             sparse_feature = torch.cat([sparse_feature] + extra, dim=1)
 
-        from . import fused
         if fused.usable(self, sparse_feature):
             return sparse_feature, fused.head_forward(self, sparse_feature)
         x = self.bn_score(self.conv_score(self.mlp(sparse_feature)))

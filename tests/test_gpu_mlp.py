@@ -369,3 +369,45 @@ def test_unsupported_configurations_take_the_operator_path(monkeypatch):
             monkeypatch.setattr(fused, "ENABLED", False)
             nx0, nf0 = sa(xyz, rgb)
         assert torch.equal(nx0, nx1) and torch.equal(nf0, nf1)
+
+
+@pytest.mark.parametrize("P", [128 * 256 + 48, 1000, 16, 7])
+def test_fp_head_chain_equals_layerwise_kernels(P):
+    """csrc/rowchain.hip (FP3 layers 2-3 + head + score in one kernel) against the same layers run one launch at a
+    time, and against an fp64 reference: rows not a multiple of 16 / 128, fewer rows than workgroups, one unit."""
+    from regnet_for_3d_grasping_amd import fused, pipeline
+    torch.manual_seed(P)
+    score_net, _ = pipeline.build_models(DEV)
+    seg = score_net.extrat_featurePN2
+    seg.bn_score.running_var.fill_(30.0)
+    fp = seg.fp_modules[-1]
+    assert fused.supports_rowchain(seg, fp)
+    fp_layers = fused._packed_stack(fp, fp.mlp)
+    h1 = torch.relu(torch.randn(P, 256, device=DEV))
+    F, score = fused.fp_head_chain(h1, seg, fp_layers, P)
+    # layer-wise
+    h = h1
+    for layer in fp_layers[1:]:
+        h = fused.mlp_layer(h, layer.K, layer, P)
+    F_ref = h
+    for layer in fused._packed_stack(seg.mlp, seg.mlp):
+        h = fused.mlp_layer(h, layer.K, layer, P)
+    score_ref = fused.score_head(h, seg, P)
+    torch.cuda.synchronize()
+    assert torch.isfinite(F).all() and torch.isfinite(score).all()
+    torch.testing.assert_close(F, F_ref, rtol=2e-5, atol=2e-5)
+    torch.testing.assert_close(score, score_ref, rtol=0, atol=2e-5)
+    # fp64 torch reference of the module stack itself (eval mode)
+    with torch.no_grad():
+        x = h1.double().t()[None]                                       # (1, 256, P)
+        mods = [m.double() for m in list(fp.mlp)[1:]]
+        for m in mods:
+            x = torch.relu(m.bn(m.conv(x)))
+        F64 = x[0].t()
+        head = [m.double() for m in seg.mlp]
+        for m in head:
+            x = torch.relu(m.bn(m.conv(x)))
+        s64 = torch.sigmoid(seg.bn_score.double()(seg.conv_score.double()(x)))[0, 0]
+        score_net.float()
+    torch.testing.assert_close(F.double(), F64, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(score.double(), s64, rtol=0, atol=1e-4)
