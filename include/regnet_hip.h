@@ -333,12 +333,14 @@ int regnet_score_head_f32(const float* x, int64_t ldx, int64_t C, const float* w
  * pair (A: 256 -> M, B: M -> N) and per 128-channel group g of M: four A-stages (rows 128 g + 32 u .. + 32 of W_A, all
  * 256 columns) then N/64 B-stages (rows 64 v .. + 64 of W_B, columns 128 g .. + 128); inside a stage the 16-byte
  * chunk c of row r is stored at chunk position c ^ (r & 15) (low 4 bits) of its row (bank-conflict-free fragment
- * reads).  `affine`: per layer [scale(N) | shift(N)], layers in order: 3328 floats.  Rows and buffers 16-byte aligned. */
+ * reads).  `affine`: per layer [scale(N) | shift(N)], layers in order: 3328 floats.  Rows and buffers 16-byte aligned.
+ * `ticket`: one int32 in device memory, ZERO when the kernel starts (the caller clears it on the same stream): the
+ * work queue through which the resident workgroups draw their 128-row blocks.                                          */
 int64_t regnet_fp_head_chain_stream_floats(void);
 int regnet_fp_head_chain_f32(const float* X, int64_t ldx, const float* stream_w, int64_t n_stages,
                              const float* affine, int64_t affine_floats, const float* wscore, float score_bias,
                              float score_bn_scale, float score_bn_shift, float* F, int64_t ldf, float* score,
-                             int64_t P, void* stream);
+                             int64_t P, int32_t* ticket, void* stream);
 
 /* ---- host-side numpy-compatible random draws of the region stage (no GPU involved) ------------
  * Replaces the per-centre / per-grasp np.random.choice calls of the reference's Python loops

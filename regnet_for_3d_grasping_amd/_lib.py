@@ -70,7 +70,8 @@ SIGNATURES = {
                                         _vp, _vp, _int, _i64, _i64, _i64, _vp, _i64, _vp]),
     "regnet_score_head_f32": (_int, [_vp, _i64, _i64, _vp, _f32, _f32, _f32, _vp, _i64, _vp]),
     "regnet_fp_head_chain_stream_floats": (_i64, []),
-    "regnet_fp_head_chain_f32": (_int, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _f32, _f32, _f32, _vp, _i64, _vp, _i64, _vp]),
+    "regnet_fp_head_chain_f32": (_int, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _f32, _f32, _f32, _vp, _i64, _vp, _i64, _vp,
+                                        _vp]),
     "regnet_np_choice_rows": (_int, [_vp, _vp, _vp, _i64, _i64, _int, _vp, _vp]),
 }
 

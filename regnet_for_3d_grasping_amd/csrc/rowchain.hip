@@ -23,8 +23,8 @@
 //   dense rows, 16-byte chunks XOR-swizzled by the row so the fragment reads are bank-conflict free) fetched by
 //   LDS-DMA into a ring of 3, two stages in flight across every barrier (counted vmcnt, written by hand).  The stream
 //   is laid out on the host in consumption order, already swizzled: the fetch is a linear copy.
-//   Rows are split statically and evenly over the workgroups (units of 16 rows): every CU finishes within one
-//   16-row unit of the others, the last partial pass runs with fewer waves per SIMD and therefore faster.
+//   One resident workgroup per CU draws 128-row blocks from a ticket counter (a block = one pass over the stream), so a
+//   CU that another stream's kernel keeps busy simply takes fewer blocks.
 #include "common.h"
 
 typedef float rc_f32x4 __attribute__((ext_vector_type(4)));
@@ -47,7 +47,8 @@ struct RcArgs {
   int affine_floats;
   const float* wscore;                         // conv_score weight (128)
   float score_bias, score_bn_scale, score_bn_shift;
-  long long units_per_wg;                      // 16-row units per workgroup (static even split)
+  int* ticket;                                 // work queue head (zeroed by the caller before the launch)
+  long long n_blocks;                          // 128-row blocks = passes to hand out
 };
 
 __device__ __forceinline__ void rc_glds16(const float* gsrc, unsigned lds_dst) {
@@ -109,15 +110,26 @@ __device__ __forceinline__ RcFrag rc_frag_offsets() {
   return f;
 }
 
+// One step = 8 MFMAs on two accumulators, alternating (v_mfma_f32_16x16x4_f32 issues every 32 cycles but its result is
+// ready after 40: back-to-back MFMAs on ONE accumulator would each wait).  The order is pinned with scheduling
+// barriers: left alone, hipcc clusters the four MFMAs of each accumulator and sinks the fragment reads to just in
+// front of their first use, so the two waves of a SIMD -- released by the same barrier, running the same code -- sit
+// out every LDS round trip together (67 TFLOP/s).  The stage loops below are software-pipelined at source level: the
+// reads of step k + 1 are issued in front of the MFMAs of step k.
+#define RC_PIN() __builtin_amdgcn_sched_barrier(0)
 #define RC_MFMA8(W0, W1, X, A0, A1)                                        \
   A0 = __builtin_amdgcn_mfma_f32_16x16x4f32(W0.x, X.x, A0, 0, 0, 0);       \
   A1 = __builtin_amdgcn_mfma_f32_16x16x4f32(W1.x, X.x, A1, 0, 0, 0);       \
+  RC_PIN();                                                                \
   A0 = __builtin_amdgcn_mfma_f32_16x16x4f32(W0.y, X.y, A0, 0, 0, 0);       \
   A1 = __builtin_amdgcn_mfma_f32_16x16x4f32(W1.y, X.y, A1, 0, 0, 0);       \
+  RC_PIN();                                                                \
   A0 = __builtin_amdgcn_mfma_f32_16x16x4f32(W0.z, X.z, A0, 0, 0, 0);       \
   A1 = __builtin_amdgcn_mfma_f32_16x16x4f32(W1.z, X.z, A1, 0, 0, 0);       \
+  RC_PIN();                                                                \
   A0 = __builtin_amdgcn_mfma_f32_16x16x4f32(W0.w, X.w, A0, 0, 0, 0);       \
-  A1 = __builtin_amdgcn_mfma_f32_16x16x4f32(W1.w, X.w, A1, 0, 0, 0);
+  A1 = __builtin_amdgcn_mfma_f32_16x16x4f32(W1.w, X.w, A1, 0, 0, 0);       \
+  RC_PIN();
 
 // Two consecutive layers  A: 256 -> M  and  B: M -> N  as one loop over the 128-channel groups of M:
 //     mid = actA(affA(W_A[group rows] . xin))          4 A-stages ([32 rows][256 k]),  32 registers
@@ -143,11 +155,17 @@ __device__ __forceinline__ void rc_pair(const rc_f32x4 (&xin)[16], rc_f32x4 (&xo
       const int slot = ring.acquire<false>();
       if (active) {
         const float* st = smem + slot * RC_STAGE_FLOATS;
+        rc_f32x4 w0n = *reinterpret_cast<const rc_f32x4*>(st + fo.a[0]);
+        rc_f32x4 w1n = *reinterpret_cast<const rc_f32x4*>(st + fo.a[0] + 16 * 256);
 #pragma unroll
         for (int kt = 0; kt < 16; ++kt) {
-          const float* wp = st + fo.a[kt & 3] + 64 * (kt >> 2);
-          const rc_f32x4 w0 = *reinterpret_cast<const rc_f32x4*>(wp);
-          const rc_f32x4 w1 = *reinterpret_cast<const rc_f32x4*>(wp + 16 * 256);
+          const rc_f32x4 w0 = w0n, w1 = w1n;
+          if (kt + 1 < 16) {
+            const float* wp = st + fo.a[(kt + 1) & 3] + 64 * ((kt + 1) >> 2);
+            w0n = *reinterpret_cast<const rc_f32x4*>(wp);
+            w1n = *reinterpret_cast<const rc_f32x4*>(wp + 16 * 256);
+          }
+          RC_PIN();
           const rc_f32x4 x = xin[kt];
           RC_MFMA8(w0, w1, x, acc0, acc1)
         }
@@ -168,16 +186,23 @@ __device__ __forceinline__ void rc_pair(const rc_f32x4 (&xin)[16], rc_f32x4 (&xo
       const int slot = ring.acquire<false>();
       if (active) {
         const float* st = smem + slot * RC_STAGE_FLOATS;
+        rc_f32x4 w0n = *reinterpret_cast<const rc_f32x4*>(st + fo.b[0]);
+        rc_f32x4 w1n = *reinterpret_cast<const rc_f32x4*>(st + fo.b[0] + 16 * 128);
 #pragma unroll
-        for (int tp = 0; tp < 2; ++tp)      // tile pairs (4 v + 2 tp, + 1): two independent accumulators alternate
-#pragma unroll
-          for (int kt = 0; kt < 8; ++kt) {
-            const float* wp = st + (2 * tp) * 16 * 128 + fo.b[kt & 3] + 64 * (kt >> 2);
-            const rc_f32x4 w0 = *reinterpret_cast<const rc_f32x4*>(wp);
-            const rc_f32x4 w1 = *reinterpret_cast<const rc_f32x4*>(wp + 16 * 128);
-            const rc_f32x4 x = mid[kt];
-            RC_MFMA8(w0, w1, x, xout[4 * v + 2 * tp], xout[4 * v + 2 * tp + 1])
+        for (int step = 0; step < 16; ++step) {   // tile pair tp = step / 8 (tiles 4 v + 2 tp, + 1), k-step kt = step % 8
+          constexpr int dummy = 0; (void)dummy;
+          const int tp = step >> 3, kt = step & 7;
+          const rc_f32x4 w0 = w0n, w1 = w1n;
+          if (step + 1 < 16) {
+            const int tpn = (step + 1) >> 3, ktn = (step + 1) & 7;
+            const float* wp = st + (2 * tpn) * 16 * 128 + fo.b[ktn & 3] + 64 * (ktn >> 2);
+            w0n = *reinterpret_cast<const rc_f32x4*>(wp);
+            w1n = *reinterpret_cast<const rc_f32x4*>(wp + 16 * 128);
           }
+          RC_PIN();
+          const rc_f32x4 x = mid[kt];
+          RC_MFMA8(w0, w1, x, xout[4 * v + 2 * tp], xout[4 * v + 2 * tp + 1])
+        }
       }
     }
   }
@@ -219,18 +244,25 @@ __global__ __launch_bounds__(RC_THREADS, 2) void fp_head_chain_kernel(const RcAr
   ring.slot = 0;
   const RcFrag fo = rc_frag_offsets();
 
-  const long long unit0 = (long long)blockIdx.x * p.units_per_wg;
+  // Row blocks (128 rows = one pass of the 8 waves over the whole weight stream) are handed out through a ticket
+  // counter: workgroups that start late -- their CU was busy with another stream's kernel, e.g. a 10 ms furthest-
+  // point-sampling workgroup -- simply take fewer.  (A static split over 256 workgroups ran 2.86 ms inside the
+  // pipeline against 1.55 ms stand-alone: the workgroups whose CU was taken ran as a second round.)
+  int* const s_blk = reinterpret_cast<int*>(wsc + 128);
   const long long units_total = (p.P + 15) / 16;
-  long long unit_end = unit0 + p.units_per_wg;
-  if (unit_end > units_total) unit_end = units_total;
-  if (unit0 >= unit_end) return;
-  // prologue of the ring: RC_STAGES - 1 stages in flight
+  bool primed = false;
+  for (;;) {
+    if (tid == 0) *s_blk = atomicAdd(p.ticket, 1);
+    __syncthreads();
+    const long long blk = __builtin_amdgcn_readfirstlane(*s_blk);
+    if (blk >= p.n_blocks) break;
+    if (!primed) {   // prologue of the ring: RC_STAGES - 1 stages in flight
 #pragma unroll
-  for (int d = 0; d < RC_STAGES - 1; ++d) ring.fetch();
-
-  for (long long ub = unit0; ub < unit_end; ub += RC_WAVES) {
-    const long long unit = ub + wave;
-    const bool active = unit < unit_end;                       // wave-uniform
+      for (int d = 0; d < RC_STAGES - 1; ++d) ring.fetch();
+      primed = true;
+    }
+    const long long unit = blk * RC_WAVES + wave;
+    const bool active = unit < units_total;                    // wave-uniform
     long long row = unit * 16 + j;
     const bool row_ok = active && row < p.P;
     if (!row_ok) row = 0;
@@ -277,23 +309,22 @@ extern "C" int64_t regnet_fp_head_chain_stream_floats(void) { return 60ll * RC_S
 extern "C" int regnet_fp_head_chain_f32(const float* X, int64_t ldx, const float* stream, int64_t n_stages,
                                         const float* affine, int64_t affine_floats, const float* wscore,
                                         float score_bias, float score_bn_scale, float score_bn_shift, float* F,
-                                        int64_t ldf, float* score, int64_t P, void* stream_handle) {
+                                        int64_t ldf, float* score, int64_t P, int32_t* ticket, void* stream_handle) {
   if (P < 0 || ldx < 256 || ldf < 256 || (ldx & 3) || (ldf & 3) || n_stages != 60 || affine_floats != 3328)
     return REGNET_ERR_SHAPE;
   if (P == 0) return REGNET_OK;
-  if (!X || !stream || !affine || !wscore || !F || !score) return REGNET_ERR_NULL;
+  if (!X || !stream || !affine || !wscore || !F || !score || !ticket) return REGNET_ERR_NULL;
   if (!rc_aligned16(X) || !rc_aligned16(F) || !rc_aligned16(stream) || !rc_aligned16(affine) || !rc_aligned16(wscore))
     return REGNET_ERR_SHAPE;
   RcArgs a = {};
   a.X = X; a.ldx = ldx; a.F = F; a.ldf = ldf; a.score = score; a.P = P;
   a.stream = stream; a.n_stages = (int)n_stages; a.affine = affine; a.affine_floats = (int)affine_floats;
   a.wscore = wscore; a.score_bias = score_bias; a.score_bn_scale = score_bn_scale; a.score_bn_shift = score_bn_shift;
-  const long long units = (P + 15) / 16;
+  a.ticket = ticket;
+  a.n_blocks = (P + 127) / 128;
   const int cus = 256;
-  long long wgs = units < cus ? units : cus;
-  a.units_per_wg = (units + wgs - 1) / wgs;
-  wgs = (units + a.units_per_wg - 1) / a.units_per_wg;
-  const size_t lds = (size_t)(RC_STAGES * RC_STAGE_FLOATS + RC_AFFINE_MAX + 128) * sizeof(float);
+  const long long wgs = a.n_blocks < cus ? a.n_blocks : cus;
+  const size_t lds = (size_t)(RC_STAGES * RC_STAGE_FLOATS + RC_AFFINE_MAX + 128 + 4) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fp_head_chain_kernel),

@@ -593,9 +593,11 @@ def fp_head_chain(h1, seg, fp_layers, P):
     w, bias, bn_scale, bn_shift = _packed_head(seg)
     F = torch.empty((P, 256), dtype=torch.float32, device=h1.device)
     score = torch.empty((P,), dtype=torch.float32, device=h1.device)
+    ticket = torch.zeros((1,), dtype=torch.int32, device=h1.device)   # work-queue head, cleared on this stream
     _check(_L.regnet_fp_head_chain_f32(h1.data_ptr(), h1.stride(0), stream.data_ptr(), 60, affine.data_ptr(),
                                        affine.numel(), w.data_ptr(), bias, bn_scale, bn_shift, F.data_ptr(),
-                                       F.stride(0), score.data_ptr(), P, _stream(h1)), "fp_head_chain")
+                                       F.stride(0), score.data_ptr(), P, ticket.data_ptr(), _stream(h1)),
+           "fp_head_chain")
     return F, score
 
 
