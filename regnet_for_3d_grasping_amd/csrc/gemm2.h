@@ -118,6 +118,15 @@ __device__ __forceinline__ void g2_tile(const G2Args& p, float* smem, long long 
   }
 
   const int KT = p.Kpad / G2_BK;
+#ifndef G2_PINNED
+#define G2_PINNED 1   // 1: both k-halves' fragment reads are issued in front of the k-tile's MFMAs (scheduling barrier);
+                      // 0: hipcc's order (it sinks the second half's reads to mid-way)
+#endif
+#if G2_PINNED
+#define G2_PIN() __builtin_amdgcn_sched_barrier(0)
+#else
+#define G2_PIN()
+#endif
 #define G2_COMPUTE(STAGE_)                                                                                        \
   {                                                                                                               \
     const float* st = smem + (STAGE_) * STAGE_FLOATS;                                                             \
@@ -128,6 +137,7 @@ __device__ __forceinline__ void g2_tile(const G2Args& p, float* smem, long long 
       _Pragma("unroll") for (int ni = 0; ni < TN; ++ni)                                                           \
         b[kk][ni] = *reinterpret_cast<const float4*>(st + offW[kk] + ni * 32 * G2_BK);                            \
     }                                                                                                             \
+    G2_PIN();                                                                                                     \
     _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                              \
       _Pragma("unroll") for (int mi = 0; mi < TM; ++mi)                                                           \
         _Pragma("unroll") for (int ni = 0; ni < TN; ++ni) {                                                       \

@@ -133,19 +133,26 @@ __device__ __forceinline__ void chain_group(const ChainArgs& p, const float* __r
     // operand just as well (lane -> point l & 31, k -> channel pair), and the max over the points then is a max over
     // the accumulator's registers + one cross-half exchange instead of a 32-lane reduction per register (which cost
     // 6 % of the kernel: VALU work is not free next to MFMAs; measured with scripts/ablate/chain_ablate.cpp).
+    // Software-pipelined at source level and pinned: the weight fragment of step k + 1 is read in front of the MFMAs of
+    // step k.  (hipcc's own order reads a fragment right before its first use; the two waves of a SIMD are released by
+    // the same barrier and run the same code, so they would sit out every LDS round trip together.)
+    float4 wn = *reinterpret_cast<const float4*>(wt);
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
+    for (int step = 0; step < 16; ++step) {
+      const int dt = step >> 2, q = step & 3;
+      const float4 w = wn;
+      if (step + 1 < 16) wn = *reinterpret_cast<const float4*>(wt + ((step + 1) >> 2) * 32 + 8 * ((step + 1) & 3));
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float4 w = *reinterpret_cast<const float4*>(wt + dt * 32 + 8 * q);
+      for (int pt = 0; pt < NPT; ++pt) acc3[pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(acc2[dt][pt][4 * q + 0], w.x, acc3[pt], 0, 0, 0);
 #pragma unroll
-        for (int pt = 0; pt < NPT; ++pt) {
-          acc3[pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(acc2[dt][pt][4 * q + 0], w.x, acc3[pt], 0, 0, 0);
-          acc3[pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(acc2[dt][pt][4 * q + 1], w.y, acc3[pt], 0, 0, 0);
-          acc3[pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(acc2[dt][pt][4 * q + 2], w.z, acc3[pt], 0, 0, 0);
-          acc3[pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(acc2[dt][pt][4 * q + 3], w.w, acc3[pt], 0, 0, 0);
-        }
-      }
+      for (int pt = 0; pt < NPT; ++pt) acc3[pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(acc2[dt][pt][4 * q + 1], w.y, acc3[pt], 0, 0, 0);
+#pragma unroll
+      for (int pt = 0; pt < NPT; ++pt) acc3[pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(acc2[dt][pt][4 * q + 2], w.z, acc3[pt], 0, 0, 0);
+#pragma unroll
+      for (int pt = 0; pt < NPT; ++pt) acc3[pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(acc2[dt][pt][4 * q + 3], w.w, acc3[pt], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
     // lane l holds channel et*32 + (l & 31) of 16 points per point tile (+ the other 16 in lane l ^ 32)
     {
       const float sc = p.scale3[et * 32 + fr], sh = p.shift3[et * 32 + fr];
