@@ -260,22 +260,6 @@ int regnet_bn_relu_train_bwd_f32(const float* x, const float* y, const float* dy
                                  const float* save_invstd, int relu, int64_t pool_group, float* dx, float* dgamma,
                                  float* dbeta, void* workspace, void* stream);
 
-/* regnet_sa_chain_premul_f32: layers 2 and 3 + the max over the 64 neighbours of a WIDE set-abstraction block
- * (levels 2 and 3 of PointNet2Seg, pointnet2.py:40-42) in one kernel, on pre-multiplied layer-1 rows as
- * regnet_sa_premul_layer_f32: A1[p][k] = max(U[b*Nsrc + nbr[p]][k] - V[p / 64][k], 0), k < C1 (C1 % 16 == 0);
- * layer 2 (W2 packed [>= C2][K2pad >= C1], folded BN affine + ReLU) stays in registers (16x16x4 fp32 MFMA, its
- * accumulator is layer 3's operand); layer 3 (W3 packed [>= C3][K3pad >= C2], affine, ReLU if relu3) -> max over
- * the group -> out (B*M, ldo).  Supported: group == 64, C2 in {256, 512}, C3 % 16 == 0; otherwise
- * REGNET_ERR_UNSUPPORTED.  Same values as regnet_sa_premul_layer_f32 + regnet_mlp_layer_f32(pool) up to fp32
- * summation order.  Experimental: measured slower than those two launches (see csrc/sa_chain2.hip), not used by
- * the default forward.                                                                                           */
-int regnet_sa_chain_premul_f32(const float* U, int64_t ldu, const float* V, int64_t ldv, int64_t C1,
-                               const int64_t* nbr, int64_t B, int64_t Nsrc, int64_t M, int64_t group,
-                               const float* W2, int64_t K2pad, const float* scale2, const float* shift2,
-                               int64_t C2, const float* W3, int64_t K3pad, const float* scale3,
-                               const float* shift3, int64_t C3, int relu3, float* out, int64_t ldo,
-                               void* stream);
-
 /* ---- set-abstraction layers 1+2 with layer 1 evaluated per SOURCE point ---------------------------
  * The first SharedMLP layer of a set-abstraction block (pn2_utils/modules.py:44-55: conv over
  * [xyz_j - xyz_c | feature_j]) is linear in the gathered row, so

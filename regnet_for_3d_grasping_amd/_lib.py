@@ -58,8 +58,6 @@ SIGNATURES = {
     "regnet_bn_relu_train_bwd_f32": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _int, _i64, _vp, _vp,
                                             _vp, _vp, _vp]),
     "regnet_pack_rows_f32": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp]),
-    "regnet_sa_chain_premul_f32": (_int, [_vp, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _vp, _vp, _i64,
-                                          _vp, _i64, _vp, _vp, _i64, _int, _vp, _i64, _vp]),
     "regnet_sa_premul_layer_f32": (_int, [_vp, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _vp, _vp,
                                           _vp, _i64, _i64, _int, _int, _vp]),
     "regnet_sa_layer12_f32": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _i64,

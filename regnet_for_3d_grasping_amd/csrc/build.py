@@ -21,8 +21,7 @@ SOURCES = [
     ("region.hip", ["-ffp-contract=off"]),
     ("grid.hip", ["-ffp-contract=off"]),
     ("mlp.hip", []),
-    ("sa_chain.hip", ["-fno-slp-vectorize"]),
-    ("sa_chain2.hip", ["-fno-slp-vectorize"]),  # SLP turns the layer-1 FMAs into v_pk_mul + separate adds
+    ("sa_chain.hip", ["-fno-slp-vectorize"]),   # SLP turns the layer-1 FMAs into v_pk_mul + separate adds
     ("rowchain.hip", ["-fno-slp-vectorize"]),
     ("bn_train.hip", []),
     ("np_random.hip", []),

@@ -19,9 +19,6 @@ from . import _lib, pn2_ext
 ENABLED = True
 CHAIN3 = True   # level-1 set-abstraction block as one register-chained kernel (see sa_features)
 SPLITK_MAX_ROWS = 1024   # at most this many rows: the GEMM is "skinny" and is split along K (see mlp_layer)
-# layer-2 widths for which sa_features uses the register-chained kernel of csrc/sa_chain2.hip (measured slower than the
-# two generic launches, hence off by default)
-CHAIN_PREMUL_WIDTHS = tuple(int(w) for w in __import__('os').environ.get('REGNET_CHAIN_WIDTHS', '').split(',') if w)
 PREMUL = True   # evaluate the first layer of wide set-abstraction blocks per source point (see sa_features)
 
 _check = _lib.check
@@ -246,18 +243,6 @@ def sa_chain3(feature, xyz, nbr, ctr, l1, l2, l3, B, M, group, count=None, order
 
 
 @_on_tensor_device
-def sa_chain_premul(U, V, nbr, l2, l3, B, Nsrc, M, group):
-    """Layers 2 + 3 + max over the neighbours of a wide SA block on pre-multiplied layer-1 rows; -> (B*M, C3)."""
-    out = torch.empty((B * M, l3.N), dtype=torch.float32, device=U.device)
-    _check(_L.regnet_sa_chain_premul_f32(U.data_ptr(), U.stride(0), V.data_ptr(), V.stride(0), U.size(1),
-                                         nbr.data_ptr(), B, Nsrc, M, group, l2.W.data_ptr(), l2.Kpad,
-                                         l2.scale.data_ptr(), l2.shift.data_ptr(), l2.N, l3.W.data_ptr(), l3.Kpad,
-                                         l3.scale.data_ptr(), l3.shift.data_ptr(), l3.N, l3.relu, out.data_ptr(),
-                                         out.stride(0), _stream(U)), "sa_chain_premul")
-    return out
-
-
-@_on_tensor_device
 def interp_concat(sparse_cl, idx, dist2, eps, dense_feature, B, Nd):
     """sparse_cl: (B,Ns,Cs) channels-last contiguous; dense_feature (B,Cd,Nd) any strides or None.
     Returns the (B*Nd, round_up(Cs+Cd,4)) channels-last operand of the first FP layer and its valid width."""
@@ -352,8 +337,6 @@ TIMED_OPS = {
     "sa_layer1": lambda feature, xyz, nbr, ctr, layer, B, M, group: _flop_meta(B * M * group, layer.K, layer.N),
     "sa_premul_layer": lambda U, V, nbr, layer, B, Nsrc, M, group, pool_group=0:
         _flop_meta(B * M * group, layer.K, layer.N),
-    "sa_chain_premul": lambda U, V, nbr, l2, l3, B, Nsrc, M, group:
-        "P%d K%d N%d flop%d" % (B * M * group, l3.K, l3.N, 2 * B * M * group * (l2.K * l2.N + l3.K * l3.N)),
     "sa_chain3": lambda feature, xyz, nbr, ctr, l1, l2, l3, B, M, group, count=None, order=None:
         "P%d K%d N%d flop%d" % (B * M * group, l3.K, l3.N,
                                 2 * B * M * group * (l1.K * l1.N + l2.K * l2.N + l3.K * l3.N)),
@@ -435,11 +418,6 @@ def sa_features(module, xyz, feature, geo):
         width = _round_up(Cf + 3, 4)
         U = mlp_layer(pack_rows(feature, xyz, width), width, u_layer, B * N1)
         V = mlp_layer(pack_rows(None, geo["new_xyz"], 4), 4, v_layer, B * M)
-        if (CHAIN3 and len(layers) == 3 and layers[1].N in CHAIN_PREMUL_WIDTHS and layers[1].relu and first.N % 16 == 0
-                and layers[2].N % 16 == 0 and layers[2].K == layers[1].N):
-            # layers 2 and 3 + the pooling in one kernel, layer-2 activation in registers (csrc/sa_chain2.hip)
-            pooled = sa_chain_premul(U, V, geo["nbr"], layers[1], layers[2], B, N1, M, K)
-            return geo["new_xyz"], pooled.view(B, M, -1).transpose(1, 2)
         if len(layers) == 2:
             pooled = sa_premul_layer(U, V, geo["nbr"], layers[1], B, N1, M, K, pool_group=K)
             return geo["new_xyz"], pooled.view(B, M, -1).transpose(1, 2)
@@ -613,6 +591,34 @@ def fp_head_forward(seg, fp_module, dense_xyz, dense_feature, sparse_feature, ge
         return None
     F, score = fp_head_chain(h1, seg, layers, B * Nd)
     return F.view(B, Nd, 256).transpose(1, 2), score.view(B, Nd)
+
+
+def prepack(score_net, region_net=None):
+    """Build every packed-weight cache of the fused forward NOW, on the current stream.  The caches are otherwise
+    filled lazily by whichever stream first runs a block; with several feature-stage streams
+    (``ForwardPipeline(mlp_streams=2)``) a second stream could then read a cache whose packing kernels, enqueued on
+    the first stream, have not finished.  ``ForwardPipeline.run`` calls this before its streams start."""
+    seg = getattr(score_net, "extrat_featurePN2", score_net)
+    dev = next(seg.parameters()).device
+    for sa in seg.sa_modules:
+        Cf = sa.in_channels
+        layers = _packed_stack(sa, sa.mlp, lambda Cf=Cf: torch.cat([torch.arange(3, 3 + Cf), torch.arange(0, 3)]).to(dev))
+        if layers[0].W8 is None and Cf > 0:
+            _premul_layers(layers[0], Cf)
+    sparse = seg.sa_modules[-1].out_channels
+    for fp in seg.fp_modules:
+        layers = _packed_stack(fp, fp.mlp)
+        Cs = sparse
+        if Cs <= layers[0].K:
+            _fp_split_layers(layers[0], Cs)
+        sparse = fp.out_channels
+    _packed_stack(seg.mlp, seg.mlp)
+    _packed_head(seg)
+    if supports_rowchain(seg, seg.fp_modules[-1]):
+        _packed_rowchain(seg, _packed_stack(seg.fp_modules[-1], seg.fp_modules[-1].mlp))
+    if region_net is not None:
+        _packed_named(region_net.extrat_feature_region, _TWOSTAGE)
+        _packed_named(region_net.extrat_feature_refine, _REFINE)
 
 
 def plan_tensors(plan):

@@ -169,7 +169,10 @@ class ForwardPipeline:
         import queue
         import threading
 
+        from . import fused
         cur = torch.cuda.current_stream(self.device)
+        with torch.no_grad():
+            fused.prepack(self.score_net, self.region_net)   # packed-weight caches: built on `cur`, before the streams fork
         streams = tuple(self.s_fps) + tuple(self.s_mlps) + (self.s_geo, self.s_reg)
         for s in streams:
             s.wait_stream(cur)

@@ -18,7 +18,7 @@ import glob
 import json
 import sys
 
-FAMILY = [("mlp_gemm_kernel", "mlp_gemm_kernel"), ("sa_chain2_kernel", "sa_chain2_kernel"), ("sa_chain_kernel", "sa_chain_kernel"), ("fps_", "fps_kernel"), ("ball_query_kernel", "ball_query_kernel"),
+FAMILY = [("mlp_gemm_kernel", "mlp_gemm_kernel"), ("fp_head_chain_kernel", "fp_head_chain_kernel"), ("sa_chain_kernel", "sa_chain_kernel"), ("fps_", "fps_kernel"), ("ball_query_kernel", "ball_query_kernel"),
           ("ball_query_grid_kernel", "ball_query_grid_kernel"), ("three_nn_kernel", "three_nn_kernel"),
           ("three_nn_grid_kernel", "three_nn_grid_kernel"), ("interp_concat_kernel", "interp_concat_kernel"),
           ("interp_affine_kernel", "interp_affine_kernel"), ("gather_max_kernel", "gather_max_kernel"),

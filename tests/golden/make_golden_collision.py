@@ -6,7 +6,8 @@ eval_validate return for these inputs: transforms3d is only referenced by an unu
 (evaluation_data_generator.py:40-43); open3d estimates normals of the VIEW cloud (:77-80, :261-262) whose transformed
 copy (:199, :437) is never read, builds kd-trees nobody queries (:260) and would estimate SCENE normals only when the
 record carries none (torch_scene_point_cloud.py:13-19; the fixture's records carry ``scene_normal``).  They are therefore
-replaced by inert stand-ins (a point-cloud object that stores its points and returns zero normals), and the fixture
+replaced by inert stand-ins (a point-cloud object that stores its points and returns NaN normals, so any read of them
+would poison the fixture), and the fixture
 records exactly what the reference's code returned for seeded inputs.  Run:  python tests/golden/make_golden_collision.py
 """
 import contextlib
@@ -29,10 +30,12 @@ def _inert_open3d():
     class _Cloud:
         def __init__(self):
             self.points = np.zeros((0, 3))
-            self.normals = np.zeros((0, 3))
+            self.normals = np.full((0, 3), np.nan)
 
         def estimate_normals(self, **kw):
-            self.normals = np.zeros((len(self.points), 3))
+            # NaN, not zero: a code path that READ these stand-in normals would poison the fixture instead of
+            # silently agreeing with it (the claim "never read on these paths" is thereby checked, not just stated)
+            self.normals = np.full((len(self.points), 3), np.nan)
 
         def normalize_normals(self):
             pass

@@ -328,29 +328,6 @@ def test_mlp_layer_split_k_is_exact_and_deterministic(P, K, N, monkeypatch):
     torch.testing.assert_close(got, plain, rtol=1e-5, atol=1e-5)
 
 
-@pytest.mark.parametrize("C1,C2,C3,M", [(256, 256, 512, 9), (512, 512, 1024, 5), (128, 256, 48, 3), (64, 512, 160, 4)])
-def test_sa_chain_premul_equals_layerwise_kernels(C1, C2, C3, M):
-    """Layers 2 + 3 + pooling of a wide SA block in one kernel (16x16x4 MFMA chain) == premul layer 2 + pooled layer 3,
-    and == the fp64 reference of relu(U[nbr] - V) -> layer 2 -> layer 3 -> max."""
-    from regnet_for_3d_grasping_amd import fused
-    B, Nsrc, G = 2, 300, 64
-    rng = np.random.default_rng(51)
-    U = torch.from_numpy(rng.normal(size=(B * Nsrc, C1)).astype(np.float32)).to(DEV)
-    V = torch.from_numpy(rng.normal(size=(B * M, C1)).astype(np.float32) * 0.5).to(DEV)
-    nbr = torch.from_numpy(rng.integers(0, Nsrc, (B, M, G))).to(DEV)
-    conv2, bn2, layer2 = _layer(C2, C1, seed=61)
-    conv3, bn3, layer3 = _layer(C3, C2, seed=62)
-    got = fused.sa_chain_premul(U, V, nbr, layer2, layer3, B, Nsrc, M, G)
-    assert tuple(got.shape) == (B * M, C3)
-    h2 = fused.sa_premul_layer(U, V, nbr, layer2, B, Nsrc, M, G)
-    want_k = fused.mlp_layer(h2, layer3.K, layer3, B * M * G, pool_group=G)
-    torch.testing.assert_close(got, want_k, rtol=1e-5, atol=5e-5)
-    rows = (nbr + torch.arange(B, device=DEV).view(B, 1, 1) * Nsrc).view(-1)
-    a1 = torch.relu(U[rows].double() - V.double().repeat_interleave(G, dim=0))
-    want = _ref(_ref(a1, conv2, bn2, True).float(), conv3, bn3, True).view(B * M, G, C3).max(dim=1)[0]
-    torch.testing.assert_close(got.double(), want, rtol=1e-5, atol=1e-4)
-
-
 def test_unsupported_configurations_take_the_operator_path(monkeypatch):
     """A set-abstraction block the fused chain does not cover (32 neighbours, one MLP layer) must still run on the GPU
     through the operator-granular kernels -- same result as with the fused path switched off, no exception."""
