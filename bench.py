@@ -150,7 +150,8 @@ def algorithmic_work(name, meta):
 
 
 # host wrapper -> device kernel it launches (for grouping launches into kernel families)
-KERNEL_OF = {"mlp_layer": "mlp_gemm_kernel", "sa_layer1": "mlp_gemm_kernel", "sa_layer12": "mlp_gemm_kernel",
+KERNEL_OF = {"native_fwd": "tgemm_kernel", "native_dgrad": "tgemm_kernel", "native_wgrad": "tgemm_kernel",
+             "mlp_layer": "mlp_gemm_kernel", "sa_layer1": "mlp_gemm_kernel", "sa_layer12": "mlp_gemm_kernel",
              "sa_premul_layer": "mlp_gemm_kernel", "sa_chain3": "sa_chain_kernel", "fp_head_chain": "fp_head_chain_kernel",
              "farthest_point_sample": "fps_kernel", "ball_query": "ball_query_kernel",
              "point_search": "three_nn_kernel", "radius_candidates": "radius_group_kernel",
@@ -257,6 +258,12 @@ def run_train(args, rank, world, dev):
     trainer = RefineTrainer(score_net.to(dev), region_net.to(dev), pipeline.PARAMS, pipeline.GRIPPER_PARAMS)
     pc = pc_cpu.to(dev)
     np.random.seed(rank)
+    # HIP events around the native 1x1-convolution kernels (forward / input gradient / weight gradient: the MFMA work of
+    # the iteration) on the stream they are launched on, inside the timed region
+    from regnet_for_3d_grasping_amd import conv1x1_train
+    timer = OpTimer(every=args.time_every)
+    for name, meta in conv1x1_train.TIMED_OPS.items():
+        timer.wrap(conv1x1_train, name, meta)
 
     def fence():
         if world > 1:
@@ -271,6 +278,7 @@ def run_train(args, rank, world, dev):
         trainer.step(pc, target, records, plan=ahead)
         ahead = nxt
     fence()
+    timer.enabled = True
     t0 = time.perf_counter()
     region_steps = 0
     for _ in range(args.steps):
@@ -280,13 +288,15 @@ def run_train(args, rank, world, dev):
         region_steps += "region_error" not in parts
     fence()
     dt = sharding.max_over_ranks(time.perf_counter() - t0, dev)
+    timer.enabled = False
     if rank == 0:
+        _, roofline = roofline_of(timer.summary(), args.steps, B)
         grads = sum(p.numel() for net in (score_net, region_net) for p in net.parameters())
         print(json.dumps({
             "metric": "train scenes/sec (%s-pt ScoreNet+GRN+Refine training iteration)" % _pts(N), "value": round(B * args.steps * world / dt, 3),
             "unit": "scenes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32", "data": "synthetic", "roofline": roofline,
             "config": {"workload": "configs[3]: training iteration (forward with labels, stage-2 + refine losses, backward, "
                                    "two Adam steps), %d-pt synthetic scenes, batch=%d per GPU" % (N, B),
                        "points": N, "batch_per_gpu": B, "global_batch": B * world,

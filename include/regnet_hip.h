@@ -326,6 +326,26 @@ int regnet_fp_head_chain_f32(const float* X, int64_t ldx, const float* stream_w,
                              float score_bn_scale, float score_bn_shift, float* F, int64_t ldf, float* score,
                              int64_t P, int32_t* ticket, void* stream);
 
+/* ---- training: the 1x1 convolutions of the shared-MLP blocks on the matrix cores (csrc/tgemm.hip) ------------------
+ * nn.Conv1d / nn.Conv2d(kernel_size = 1, bias = False) of pn2_utils/nn/modules/conv.py:20-36, :60-76 under autograd
+ * (train.py:376-384), in the tensors' own channel-first layout: X (B, Ci, L), W (Co, Ci), Y (B, Co, L), all contiguous.
+ *   fwd    Y[b]  = W . X[b]            dgrad  dX[b] = W^T . dY[b]            wgrad  dW = sum_b dY[b] . X[b]^T
+ * regnet_conv1x1_train_supported(Co, Ci, L) != 0: this build runs the shape (channel counts multiples of 16 and >= 32,
+ * L a multiple of 4 and >= 64; wgrad additionally L % 16 == 0); otherwise the entry points return REGNET_ERR_SHAPE and
+ * the caller keeps its library GEMM.  The weight gradient is split over the point axis into
+ * regnet_conv1x1_wgrad_slices() slices per scene whose partial sums (workspace of
+ * regnet_conv1x1_wgrad_workspace_bytes() bytes, 16-byte aligned; may be NULL when that is 0) are added in slice
+ * order by a second kernel: deterministic.  Same values as the library path up to fp32 summation order.          */
+int regnet_conv1x1_train_supported(int64_t Co, int64_t Ci, int64_t L);
+int regnet_conv1x1_fwd_f32(const float* W, const float* X, float* Y, int64_t B, int64_t Co, int64_t Ci, int64_t L,
+                           void* stream);
+int regnet_conv1x1_dgrad_f32(const float* W, const float* dY, float* dX, int64_t B, int64_t Co, int64_t Ci, int64_t L,
+                             void* stream);
+int64_t regnet_conv1x1_wgrad_slices(int64_t B, int64_t Co, int64_t Ci, int64_t L);
+int64_t regnet_conv1x1_wgrad_workspace_bytes(int64_t B, int64_t Co, int64_t Ci, int64_t L);
+int regnet_conv1x1_wgrad_f32(const float* dY, const float* X, float* dW, int64_t B, int64_t Co, int64_t Ci, int64_t L,
+                             void* workspace, void* stream);
+
 /* ---- host-side numpy-compatible random draws of the region stage (no GPU involved) ------------
  * Replaces the per-centre / per-grasp np.random.choice calls of the reference's Python loops
  * (dataset_utils/get_regiondataset.py:331-337, multi_model/gripper_region_network.py:532-544) while

@@ -70,6 +70,12 @@ SIGNATURES = {
     "regnet_fp_head_chain_stream_floats": (_i64, []),
     "regnet_fp_head_chain_f32": (_int, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _f32, _f32, _f32, _vp, _i64, _vp, _i64, _vp,
                                         _vp]),
+    "regnet_conv1x1_train_supported": (_int, [_i64, _i64, _i64]),
+    "regnet_conv1x1_fwd_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp]),
+    "regnet_conv1x1_dgrad_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp]),
+    "regnet_conv1x1_wgrad_slices": (_i64, [_i64, _i64, _i64, _i64]),
+    "regnet_conv1x1_wgrad_workspace_bytes": (_i64, [_i64, _i64, _i64, _i64]),
+    "regnet_conv1x1_wgrad_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
     "regnet_np_choice_rows": (_int, [_vp, _vp, _vp, _i64, _i64, _int, _vp, _vp]),
 }
 

@@ -13,6 +13,20 @@ import os
 import torch
 
 ENABLED = os.environ.get("REGNET_CONV1X1_TRAIN", "1") != "0"
+# 1: forward / input gradient / weight gradient on this repo's own fp32-MFMA kernels (csrc/tgemm.hip) whenever the
+# shape qualifies (channel counts multiples of 16, see regnet_conv1x1_train_supported); 0: rocBLAS batched GEMMs only
+NATIVE = os.environ.get("REGNET_CONV1X1_NATIVE", "1") != "0"
+
+
+def _native_ok(B, Co, Ci, L, wgrad=False):
+    if not NATIVE:
+        return False
+    from . import _lib
+    return bool(_lib.lib.regnet_conv1x1_train_supported(Co, Ci, L)) and (not wgrad or L % 16 == 0)
+
+
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
 
 
 def supported(conv, x):
@@ -22,6 +36,57 @@ def supported(conv, x):
     zero = (0,) * (x.dim() - 2)
     return (tuple(conv.kernel_size) == one and tuple(conv.stride) == one and tuple(conv.dilation) == one
             and tuple(conv.padding) == zero and conv.groups == 1 and x.numel() > 0)
+
+
+# ---- thin wrappers of the native kernels (module-level names so bench.py --train can bracket them with events) --------
+def native_fwd(x, w):
+    """x (B, Ci, L) contiguous, w (Co, Ci) contiguous -> Y (B, Co, L) on csrc/tgemm.hip."""
+    from . import _lib
+    B, Ci, L = x.shape
+    Co = w.shape[0]
+    y = torch.empty((B, Co, L), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib.regnet_conv1x1_fwd_f32(w.data_ptr(), x.data_ptr(), y.data_ptr(), B, Co, Ci, L, _stream(x)),
+                   "conv1x1_fwd")
+    return y
+
+
+def native_dgrad(w, dy):
+    """w (Co, Ci), dy (B, Co, L), both contiguous -> dX (B, Ci, L)."""
+    from . import _lib
+    B, Co, L = dy.shape
+    Ci = w.shape[1]
+    dx = torch.empty((B, Ci, L), dtype=torch.float32, device=dy.device)
+    with torch.cuda.device(dy.device):
+        _lib.check(_lib.lib.regnet_conv1x1_dgrad_f32(w.data_ptr(), dy.data_ptr(), dx.data_ptr(), B, Co, Ci, L,
+                                                     _stream(dy)), "conv1x1_dgrad")
+    return dx
+
+
+def native_wgrad(dy, x):
+    """dy (B, Co, L), x (B, Ci, L), both contiguous -> dW (Co, Ci); deterministic split over the point axis."""
+    from . import _lib
+    L_ = _lib.lib
+    B, Co, L = dy.shape
+    Ci = x.shape[1]
+    dw = torch.empty((Co, Ci), dtype=torch.float32, device=x.device)
+    ws_bytes = L_.regnet_conv1x1_wgrad_workspace_bytes(B, Co, Ci, L)
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=x.device) if ws_bytes else None
+    with torch.cuda.device(x.device):
+        _lib.check(L_.regnet_conv1x1_wgrad_f32(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), B, Co, Ci, L,
+                                               ws.data_ptr() if ws is not None else None, _stream(x)), "conv1x1_wgrad")
+    return dw
+
+
+# what bench.py --train brackets: name -> meta(args)
+TIMED_OPS = {
+    "native_fwd": lambda x, w: "B%d Co%d Ci%d L%d flop%d" % (x.shape[0], w.shape[0], x.shape[1], x.shape[2],
+                                                             2 * x.shape[0] * w.shape[0] * x.shape[1] * x.shape[2]),
+    "native_dgrad": lambda w, dy: "B%d Co%d Ci%d L%d flop%d" % (dy.shape[0], w.shape[0], w.shape[1], dy.shape[2],
+                                                                2 * dy.shape[0] * w.shape[0] * w.shape[1] * dy.shape[2]),
+    "native_wgrad": lambda dy, x: "B%d Co%d Ci%d L%d flop%d" % (dy.shape[0], dy.shape[1], x.shape[1], x.shape[2],
+                                                                2 * dy.shape[0] * dy.shape[1] * x.shape[1] * x.shape[2]),
+}
 
 
 def _chunks(L, tiles, B):
@@ -38,6 +103,10 @@ class _Conv1x1(torch.autograd.Function):
     def forward(ctx, x, w):
         """x (B, Ci, L) contiguous, w (Co, Ci) -> (B, Co, L)."""
         ctx.save_for_backward(x, w)
+        B, Ci, L = x.shape
+        Co = w.shape[0]
+        if _native_ok(B, Co, Ci, L):
+            return native_fwd(x, w.contiguous())
         # bmm on the expanded weight, NOT torch.matmul: for (2-D, 3-D) operands matmul folds the batch by transposing the
         # activation -- a full copy each way
         return torch.bmm(w.unsqueeze(0).expand(x.shape[0], -1, -1), x)
@@ -48,7 +117,16 @@ class _Conv1x1(torch.autograd.Function):
         dy = dy.contiguous()
         B, Ci, L = x.shape
         Co = w.shape[0]
-        dx = torch.bmm(w.t().unsqueeze(0).expand(B, -1, -1), dy) if ctx.needs_input_grad[0] else None
+        if _native_ok(B, Co, Ci, L):
+            dx = dw = None
+            if ctx.needs_input_grad[0]:
+                dx = native_dgrad(w.contiguous(), dy)
+            if ctx.needs_input_grad[1] and _native_ok(B, Co, Ci, L, wgrad=True):
+                dw = native_wgrad(dy, x)
+            if dw is not None or not ctx.needs_input_grad[1]:
+                return dx, dw
+        else:
+            dx = torch.bmm(w.t().unsqueeze(0).expand(B, -1, -1), dy) if ctx.needs_input_grad[0] else None
         dw = None
         if ctx.needs_input_grad[1]:
             S = _chunks(L, ((Co + 127) // 128) * ((Ci + 127) // 128), B)

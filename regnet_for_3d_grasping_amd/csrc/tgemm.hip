@@ -1,0 +1,296 @@
+// tgemm.hip -- the 1x1 convolutions of the shared-MLP blocks in TRAINING (forward, input gradient, weight gradient) on
+// gfx950 matrix cores, in the tensors' own channel-first layout (B, C, L) -- no transposes, no library GEMM.
+//
+// Reference behaviour restated (paths relative to /root/reference/multi_model/utils): SharedMLP blocks are
+// nn.Conv1d / nn.Conv2d(kernel_size=1, bias=False) (pn2_utils/nn/modules/conv.py:20-36, :60-76) under torch autograd
+// (train.py:376-384); per scene b with X[b] (Ci x L), W (Co x Ci):
+//     forward           Y[b]  = W   . X[b]                       (Co x L)
+//     input gradient    dX[b] = W^T . dY[b]                      (Ci x L)
+//     weight gradient   dW    = sum_b dY[b] . X[b]^T             (Co x Ci), reduction over all B*L points
+//
+// One kernel, C[M x N] = A[M x K] . B[K x N] per batch / slice, with each operand in one of two memory layouts:
+//   "row"   operand element (r, k) at base + r * ld + k   -- K contiguous  (W in the forward; dY and X in the weight gradient)
+//   "kmaj"  operand element (r, k) at base + k * ld + r   -- rows contiguous (X, dY with r = point; W^T in the input gradient)
+// Both are fetched by LDS-DMA in 16-byte chunks into a 3-stage ring with counted waits (gemm2.h's scheme).  A "row"
+// tile is stored [row][16 k] with the chunk swizzle of gemm2.h and read with ds_read_b128 (4 k-steps per read); a "kmaj"
+// tile is stored [16 k][rows] exactly as it lies in memory (a k-row of the tile is one contiguous run: ideal global
+// reads) and read with one conflict-free ds_read_b32 per MFMA operand (lanes = consecutive rows = consecutive banks).
+// Tile 128 (M) x 256 (N) x 16 (K), 8 waves as 2 x 4, 64 x 64 per wave, v_mfma_f32_32x32x2_f32: M is the channel axis
+// (128 .. 1024), N the long axis (points, or Ci in the weight gradient); 2 workgroups per CU.
+// The weight gradient cuts the point axis into slices (split-K): slice partial sums go to a workspace and a second
+// kernel adds them in slice order (deterministic).
+#include "common.h"
+
+typedef float tg_f32x16 __attribute__((ext_vector_type(16)));
+
+#define TG_BM 128
+#define TG_BK 16
+#define TG_STAGES 3
+#define TG_THREADS 512
+
+struct TgArgs {
+  const float* A; long long lda, a_batch, a_slice;   // per block: A + batch * a_batch + slice * a_slice
+  const float* B; long long ldb, b_batch, b_slice;
+  float* C;       long long ldc, c_batch, c_slice;
+  int M, N, K;                                        // K = per-slice depth, multiple of 16
+  int tiles_m, tiles_n, slices;                       // grid = tiles_m * tiles_n * slices * batches
+};
+
+__device__ __forceinline__ void tg_glds16(const float* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+template <int N> __device__ __forceinline__ void tg_wait_barrier() {
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "i"(N) : "memory");
+}
+
+// TG_BN = 256 (wave tile 64 x 64) or 128 (64 x 32: the weight gradient of layers with <= 128 input channels, whose N
+// axis is only that wide).
+template <bool A_KMAJ, bool B_KMAJ, int TG_BN>
+__global__ __launch_bounds__(TG_THREADS, 4) void tgemm_kernel(const TgArgs p) {
+  constexpr int TG_STAGE_FLOATS = (TG_BM + TG_BN) * TG_BK;
+  constexpr int TNI = TG_BN / 128;                      // 32-column accumulators per wave along N
+  constexpr int WN_COLS = TG_BN / 4;                    // columns per wave
+  constexpr int NPIECE = (TG_BM + TG_BN) / 16 / 8;      // LDS-DMA pieces per wave per k-tile: 3 or 2
+  static_assert(!(B_KMAJ && TG_BN != 256), "k-major B tiles are 256 wide (one piece = one k row)");
+  __shared__ __attribute__((aligned(1024))) float smem[TG_STAGES * TG_STAGE_FLOATS];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;            // 2 x 4 waves
+  const int fr = lane & 31, fh = lane >> 5;
+  // block -> (batch, slice, tile): tiles of one (batch, slice) are consecutive so they share the operand panels in L2
+  const int tiles = p.tiles_m * p.tiles_n;
+  const int bid = blockIdx.x;
+  const int unit = bid / tiles, t = bid - unit * tiles;
+  const int batch = unit / p.slices, slice = unit - batch * p.slices;
+  const int tm = t / p.tiles_n, tn = t - tm * p.tiles_n;
+  const int m0 = tm * TG_BM, n0 = tn * TG_BN;
+  const float* Ab = p.A + batch * p.a_batch + slice * p.a_slice;
+  const float* Bb = p.B + batch * p.b_batch + slice * p.b_slice;
+  float* Cb = p.C + batch * p.c_batch + slice * p.c_slice;
+
+  // ---- this wave's LDS-DMA pieces: 8 pieces for A, 16 for B, 24 / 8 waves = 3 per wave (piece = 1 KiB)
+  const float* gp[NPIECE];       // per-lane source at k = 0
+  long long kstep[NPIECE];       // floats to advance per k-tile
+  unsigned dst[NPIECE];          // byte offset inside a stage
+#pragma unroll
+  for (int j = 0; j < NPIECE; ++j) {
+    const int piece = wave + 8 * j;                  // wave-uniform; pieces 0..7 = A, 8.. = B (16 or 8 of them)
+    const bool isA = piece < 8;
+    const int q = isA ? piece : piece - 8;
+    dst[j] = (unsigned)((isA ? 0 : TG_BM * TG_BK * 4) + q * 1024);
+    if (isA) {
+      if (A_KMAJ) {          // piece q = k rows 2q, 2q + 1 of [16 k][128 m]: lane -> (k = 2q + l/32, m chunk l % 32)
+        int m = m0 + 4 * (lane & 31);
+        if (m >= p.M) m = 0;                          // past the edge: any valid chunk (never stored)
+        gp[j] = Ab + (long long)(2 * q + (lane >> 5)) * p.lda + m;
+        kstep[j] = (long long)TG_BK * p.lda;
+      } else {               // piece q = rows 16q .. 16q + 15 of [128 rows][16 k], chunk swizzle (gemm2.h)
+        int r = m0 + 16 * q + (lane >> 2);
+        if (r >= p.M) r = 0;
+        gp[j] = Ab + (long long)r * p.lda + 4 * ((lane & 3) ^ ((lane >> 4) & 3));
+        kstep[j] = TG_BK;
+      }
+    } else {
+      if (B_KMAJ) {          // piece q = k row q of [16 k][256 n]: lane -> n chunk l
+        int n = n0 + 4 * lane;
+        if (n >= p.N) n = 0;
+        gp[j] = Bb + (long long)q * p.ldb + n;
+        kstep[j] = (long long)TG_BK * p.ldb;
+      } else {               // piece q = rows 16q .. of [256 rows][16 k]
+        int r = n0 + 16 * q + (lane >> 2);
+        if (r >= p.N) r = 0;
+        gp[j] = Bb + (long long)r * p.ldb + 4 * ((lane & 3) ^ ((lane >> 4) & 3));
+        kstep[j] = TG_BK;
+      }
+    }
+  }
+  const unsigned smem_base = (unsigned)(uintptr_t)smem;
+#define TG_ISSUE(KT_, STAGE_)                                                                         \
+  _Pragma("unroll") for (int j = 0; j < NPIECE; ++j)                                                   \
+    tg_glds16(gp[j] + (long long)(KT_) * kstep[j], smem_base + (unsigned)((STAGE_) * TG_STAGE_FLOATS * 4) + dst[j]);
+
+  tg_f32x16 acc[2][TNI];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < TNI; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  // fragment addressing (floats inside a stage)
+  const int sw = (fr >> 2) & 3;
+  int offA[2], offB[2];      // "row" layout: [kk] -> float4 of 4 k-steps
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    offA[kk] = (wm * 64 + fr) * TG_BK + 4 * ((2 * kk + fh) ^ sw);
+    offB[kk] = TG_BM * TG_BK + (wn * WN_COLS + fr) * TG_BK + 4 * ((2 * kk + fh) ^ sw);
+  }
+  const int kmA = 4 * fh * TG_BM + wm * 64 + fr;                     // "kmaj": + (8 kk + t) * TG_BM + 32 mi
+  const int kmB = TG_BM * TG_BK + 4 * fh * TG_BN + wn * WN_COLS + fr;     //         + (8 kk + t) * TG_BN + 32 ni
+
+#define TG_COMPUTE(STAGE_)                                                                                         \
+  {                                                                                                                \
+    const float* st = smem + (STAGE_) * TG_STAGE_FLOATS;                                                           \
+    float a[2][2][4], b[2][TNI][4];   /* all fragments of the k-tile first, order pinned (see gemm2.h) */           \
+    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                                             \
+      _Pragma("unroll") for (int mi = 0; mi < 2; ++mi) {                                                           \
+        if (A_KMAJ) {                                                                                              \
+          _Pragma("unroll") for (int t = 0; t < 4; ++t) a[kk][mi][t] = st[kmA + (8 * kk + t) * TG_BM + 32 * mi];   \
+        } else {                                                                                                   \
+          const float4 v = *reinterpret_cast<const float4*>(st + offA[kk] + mi * 32 * TG_BK);                      \
+          a[kk][mi][0] = v.x; a[kk][mi][1] = v.y; a[kk][mi][2] = v.z; a[kk][mi][3] = v.w;                          \
+        }                                                                                                          \
+      }                                                                                                            \
+      _Pragma("unroll") for (int ni = 0; ni < TNI; ++ni) {                                                         \
+        if (B_KMAJ) {                                                                                              \
+          _Pragma("unroll") for (int t = 0; t < 4; ++t) b[kk][ni][t] = st[kmB + (8 * kk + t) * TG_BN + 32 * ni];   \
+        } else {                                                                                                   \
+          const float4 v = *reinterpret_cast<const float4*>(st + offB[kk] + ni * 32 * TG_BK);                      \
+          b[kk][ni][0] = v.x; b[kk][ni][1] = v.y; b[kk][ni][2] = v.z; b[kk][ni][3] = v.w;                          \
+        }                                                                                                          \
+      }                                                                                                            \
+    }                                                                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                                             \
+    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                               \
+      _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                                \
+        _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)                                                           \
+          _Pragma("unroll") for (int ni = 0; ni < TNI; ++ni)                                                       \
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk][mi][t], b[kk][ni][t], acc[mi][ni], 0, 0, 0);  \
+  }
+
+  const int KT = p.K / TG_BK;           // >= 2 (launcher)
+  TG_ISSUE(0, 0)
+  TG_ISSUE(1, 1)
+  int stage = 0;
+  for (int kt = 0; kt < KT - 2; ++kt) {
+    tg_wait_barrier<NPIECE>();
+    int ns = stage + 2; if (ns >= TG_STAGES) ns -= TG_STAGES;
+    TG_ISSUE(kt + 2, ns)
+    TG_COMPUTE(stage)
+    if (++stage == TG_STAGES) stage = 0;
+  }
+#pragma unroll
+  for (int d = 0; d < 2; ++d) {
+    tg_wait_barrier<0>();
+    TG_COMPUTE(stage)
+    if (++stage == TG_STAGES) stage = 0;
+  }
+#undef TG_ISSUE
+#undef TG_COMPUTE
+
+  // ---- store: element r of lane l is row (r & 3) + 8 (r >> 2) + 4 (l >> 5), column l & 31
+#pragma unroll
+  for (int ni = 0; ni < TNI; ++ni) {
+    const int col = n0 + wn * WN_COLS + ni * 32 + fr;
+    const bool col_ok = col < p.N;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      const int row0 = m0 + wm * 64 + mi * 32 + 4 * fh;
+      float* cp = Cb + (long long)row0 * p.ldc + col;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = row0 + (r & 3) + 8 * (r >> 2);
+        if (col_ok && row < p.M) *cp = acc[mi][ni][r];
+        cp += ((r & 3) == 3) ? 5 * p.ldc : p.ldc;
+      }
+    }
+  }
+}
+
+// out[i] = sum_s part[s][i], slices added in index order
+__global__ __launch_bounds__(256) void tg_reduce_kernel(const float* __restrict__ part, int S, long long n,
+                                                        float* __restrict__ out) {
+  const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= n) return;
+  float4 acc = *reinterpret_cast<const float4*>(part + i);
+  for (int s = 1; s < S; ++s) {
+    const float4 v = *reinterpret_cast<const float4*>(part + (long long)s * n + i);
+    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  }
+  *reinterpret_cast<float4*>(out + i) = acc;
+}
+
+static bool tg_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+template <bool A_KMAJ, bool B_KMAJ, int TG_BN>
+static int tg_launch(TgArgs a, long long batches, hipStream_t st) {
+  a.tiles_m = (a.M + TG_BM - 1) / TG_BM;
+  a.tiles_n = (a.N + TG_BN - 1) / TG_BN;
+  const long long blocks = (long long)a.tiles_m * a.tiles_n * a.slices * batches;
+  if (blocks <= 0) return REGNET_OK;
+  if (blocks >= (1ll << 31)) return REGNET_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL((tgemm_kernel<A_KMAJ, B_KMAJ, TG_BN>), dim3((unsigned)blocks), dim3(TG_THREADS), 0, st, a);
+  REGNET_LAUNCH_CHECK();
+  return REGNET_OK;
+}
+
+// Shapes this build handles (everything else: the caller keeps its library path): channel counts multiples of 16,
+// points a multiple of 4, 16-byte aligned buffers.
+extern "C" int regnet_conv1x1_train_supported(int64_t Co, int64_t Ci, int64_t L) {
+  return Co >= 32 && Ci >= 32 && (Co % 16) == 0 && (Ci % 16) == 0 && L >= 64 && (L % 4) == 0;
+}
+
+extern "C" int regnet_conv1x1_fwd_f32(const float* W, const float* X, float* Y, int64_t B, int64_t Co, int64_t Ci,
+                                      int64_t L, void* stream) {
+  if (B < 0 || !regnet_conv1x1_train_supported(Co, Ci, L)) return REGNET_ERR_SHAPE;
+  if (B == 0) return REGNET_OK;
+  if (!W || !X || !Y) return REGNET_ERR_NULL;
+  if (!tg_aligned16(W) || !tg_aligned16(X) || !tg_aligned16(Y)) return REGNET_ERR_SHAPE;
+  TgArgs a = {};
+  a.A = W; a.lda = Ci;                                   // row: (o, i) at W + o * Ci + i
+  a.B = X; a.ldb = L; a.b_batch = Ci * L;                // kmaj: (l, i) at X[b] + i * L + l
+  a.C = Y; a.ldc = L; a.c_batch = Co * L;
+  a.M = (int)Co; a.N = (int)L; a.K = (int)Ci; a.slices = 1;
+  return tg_launch<false, true, 256>(a, B, as_stream(stream));
+}
+
+extern "C" int regnet_conv1x1_dgrad_f32(const float* W, const float* dY, float* dX, int64_t B, int64_t Co, int64_t Ci,
+                                        int64_t L, void* stream) {
+  if (B < 0 || !regnet_conv1x1_train_supported(Co, Ci, L)) return REGNET_ERR_SHAPE;
+  if (B == 0) return REGNET_OK;
+  if (!W || !dY || !dX) return REGNET_ERR_NULL;
+  if (!tg_aligned16(W) || !tg_aligned16(dY) || !tg_aligned16(dX)) return REGNET_ERR_SHAPE;
+  TgArgs a = {};
+  a.A = W; a.lda = Ci;                                   // kmaj: W^T element (i, o) at W + o * Ci + i
+  a.B = dY; a.ldb = L; a.b_batch = Co * L;               // kmaj: (l, o) at dY[b] + o * L + l
+  a.C = dX; a.ldc = L; a.c_batch = Ci * L;
+  a.M = (int)Ci; a.N = (int)L; a.K = (int)Co; a.slices = 1;
+  return tg_launch<true, true, 256>(a, B, as_stream(stream));
+}
+
+// Slices of the point axis for the weight gradient: enough (slice x tile) workgroups to fill the chip, slices of at
+// least 256 points and a multiple of 16; 1 when L does not divide.
+extern "C" int64_t regnet_conv1x1_wgrad_slices(int64_t B, int64_t Co, int64_t Ci, int64_t L) {
+  const int64_t tiles = ((Co + TG_BM - 1) / TG_BM) * ((Ci + 255) / 256);
+  int64_t s = 1;
+  while (L % (2 * s) == 0 && (L / (2 * s)) % 16 == 0 && L / (2 * s) >= 256 && s * tiles * B < 1024) s *= 2;
+  return s;
+}
+
+extern "C" int64_t regnet_conv1x1_wgrad_workspace_bytes(int64_t B, int64_t Co, int64_t Ci, int64_t L) {
+  const int64_t n = B * regnet_conv1x1_wgrad_slices(B, Co, Ci, L);
+  return n > 1 ? n * Co * Ci * (int64_t)sizeof(float) : 0;
+}
+
+extern "C" int regnet_conv1x1_wgrad_f32(const float* dY, const float* X, float* dW, int64_t B, int64_t Co, int64_t Ci,
+                                        int64_t L, void* workspace, void* stream) {
+  if (B <= 0 || !regnet_conv1x1_train_supported(Co, Ci, L) || (L % 16)) return REGNET_ERR_SHAPE;
+  if (!dY || !X || !dW) return REGNET_ERR_NULL;
+  const int64_t S = regnet_conv1x1_wgrad_slices(B, Co, Ci, L), n = B * S;
+  if (n > 1 && !workspace) return REGNET_ERR_NULL;
+  if (!tg_aligned16(dY) || !tg_aligned16(X) || !tg_aligned16(dW) || (n > 1 && !tg_aligned16(workspace))) return REGNET_ERR_SHAPE;
+  TgArgs a = {};
+  a.A = dY; a.lda = L; a.a_batch = Co * L; a.a_slice = L / S;      // row: (o, l)
+  a.B = X;  a.ldb = L; a.b_batch = Ci * L; a.b_slice = L / S;      // row: (i, l)
+  a.C = n > 1 ? (float*)workspace : dW; a.ldc = Ci; a.c_batch = S * Co * Ci; a.c_slice = Co * Ci;
+  a.M = (int)Co; a.N = (int)Ci; a.K = (int)(L / S); a.slices = (int)S;
+  int rc = Ci <= 128 ? tg_launch<false, false, 128>(a, B, as_stream(stream)) : tg_launch<false, false, 256>(a, B, as_stream(stream));
+  if (rc || n == 1) return rc;
+  const long long total = Co * Ci;                                 // multiple of 4 (both multiples of 16)
+  hipLaunchKernelGGL(tg_reduce_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, as_stream(stream),
+                     (const float*)workspace, (int)n, total, dW);
+  REGNET_LAUNCH_CHECK();
+  return REGNET_OK;
+}

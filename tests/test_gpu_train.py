@@ -126,7 +126,9 @@ def test_prefetched_geometry_plan_gives_the_same_training_forward():
     assert torch.isfinite(out)
 
 
-@pytest.mark.parametrize("shape,co", [((2, 6, 40, 64), 32), ((3, 259, 4096), 64), ((1, 128, 2048, 64), 128), ((2, 5, 77), 3)])
+@pytest.mark.parametrize("shape,co", [((2, 6, 40, 64), 32), ((3, 259, 4096), 64), ((1, 128, 2048, 64), 128), ((2, 5, 77), 3),
+                                      ((2, 256, 65, 64), 128), ((3, 64, 2064), 48), ((1, 512, 1024), 1024),
+                                      ((2, 1024, 192), 512), ((4, 128, 8192), 256)])
 def test_gemm_conv1x1_matches_torch_convolution(shape, co):
     """conv1x1_train: the kernel-size-1 convolutions of the shared-MLP blocks as batched GEMMs (split over the point axis
     for the weight gradient) == F.conv1d / F.conv2d, forward and both gradients."""
@@ -149,6 +151,21 @@ def test_gemm_conv1x1_matches_torch_convolution(shape, co):
     def close(a, b):
         assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max()))
     close(ya, yb), close(xa.grad, xb.grad), close(ga, conv.weight.grad)
+    # against fp64 (the reference for BOTH implementations): the native kernels must be as accurate as the library's
+    x64, w64, up64 = xb.detach().double().flatten(2), conv.weight.detach().double().flatten(1), up.double().flatten(2)
+    y64 = torch.einsum("oi,bil->bol", w64, x64)
+    dx64 = torch.einsum("oi,bol->bil", w64, up64)
+    dw64 = torch.einsum("bol,bil->oi", up64, x64)
+    for got, ref in ((ya.flatten(2), y64), (xa.grad.flatten(2), dx64), (ga.flatten(1), dw64)):
+        assert float((got.double() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
+    from regnet_for_3d_grasping_amd import _lib
+    B, Ci, L = shape[0], shape[1], int(np.prod(shape[2:]))
+    if _lib.lib.regnet_conv1x1_train_supported(co, Ci, L):   # the native kernels ran: they are deterministic
+        xc = xa.detach().clone().requires_grad_(True)
+        conv.weight.grad = None
+        yc = conv1x1_train.conv1x1(conv, xc)
+        yc.backward(up)
+        assert torch.equal(yc, ya) and torch.equal(xc.grad, xa.grad) and torch.equal(conv.weight.grad, ga)
 
 
 def test_training_first_layer_before_gather_matches_plain_path():
