@@ -1,11 +1,67 @@
-"""Train-mode step on the GPU (operator-granular kernels + autograd) against the same step through
-the CPU oracle: equal loss, gradients within the fp32 tolerance of the atomic scatter-adds."""
+"""Train-mode step on the GPU (operator-granular kernels + own MFMA convolution kernels under autograd): the loss
+against the same step through the CPU oracle, every parameter gradient against an fp64 evaluation of the same graph
+(per tensor, relative 1e-3), full-size iterations (25 600- and 51 200-point scenes)."""
 import numpy as np
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
+
+
+def _fp64_reference_grads(net32, pc, target):
+    """Parameter gradients of ``net32``'s training forward evaluated in float64: a deep copy in double precision runs
+    the operator-granular graph with torch implementations of grouping / interpolation (any dtype), while every INDEX
+    (FPS, ball query, 3-NN) comes from the fp32 kernels on the fp32 coordinates -- the same indices the fp32 pass used.
+    BatchNorm uses batch statistics (train mode) in both; dropout must be off."""
+    import copy
+    from regnet_for_3d_grasping_amd import fused
+    from regnet_for_3d_grasping_amd.pn2_utils import modules
+    F32 = modules._F
+
+    class F64:
+        gather_points = staticmethod(F32.gather_points)
+
+        @staticmethod
+        def farthest_point_sample(points, m):
+            return F32.farthest_point_sample(points.float().contiguous(), m)
+
+        @staticmethod
+        def ball_query(points, centroids, radius, k):
+            return F32.ball_query(points.float().contiguous(), centroids.float().contiguous(), radius, k)
+
+        @staticmethod
+        def group_points(points, index):
+            B, C, _ = points.shape
+            _, M, K = index.shape
+            return torch.gather(points, 2, index.reshape(B, 1, M * K).expand(B, C, M * K)).view(B, C, M, K)
+
+        @staticmethod
+        def search_nn_distance(query, key, k):
+            index, _ = F32.search_nn_distance(query.float().contiguous(), key.float().contiguous(), k)
+            picked = torch.gather(key, 2, index.reshape(index.shape[0], 1, -1).expand(-1, 3, -1)).view(
+                key.shape[0], 3, index.shape[1], k)
+            dist2 = ((query.unsqueeze(-1) - picked) ** 2).sum(1)
+            return index, dist2
+
+        @staticmethod
+        def feature_interpolate(feature, index, weight):
+            B, C, _ = feature.shape
+            N, K = index.shape[1], index.shape[2]
+            picked = torch.gather(feature, 2, index.reshape(B, 1, N * K).expand(B, C, N * K)).view(B, C, N, K)
+            return (picked * weight.unsqueeze(1)).sum(-1)
+
+    net64 = copy.deepcopy(net32).double().train()
+    for p in net64.parameters():
+        p.grad = None
+    saved = (modules._F, fused.ENABLED)
+    modules._F, fused.ENABLED = F64, False
+    try:
+        _, score, _ = net64(pc.double())
+        net64.criterion_reg(score, target.double()).sum().backward()   # compute_loss casts the target to fp32
+    finally:
+        modules._F, fused.ENABLED = saved
+    return {k: p.grad for k, p in net64.named_parameters() if p.grad is not None}
 
 
 def test_scorenet_train_step_matches_cpu_oracle():
@@ -29,23 +85,44 @@ def test_scorenet_train_step_matches_cpu_oracle():
     _, _, loss = gpu(pc.to(DEV), target.to(DEV))
     loss.backward()
     assert abs(float(loss) - float(loss_ref)) < 1e-5
-    # Train-mode gradients are only piecewise continuous (max-pool / ReLU routing, batch statistics)
-    # and torch's GPU convolution backward differs from the CPU's in summation order, so individual
-    # tensors agree to a few percent (measured 1-6 %); the exactness of the native backward kernels
-    # themselves is pinned op by op in test_gpu_ops.py.  Here: same sparsity pattern, direction, size.
-    g_gpu, g_ref = [], []
-    for (k, p), (_, q) in zip(gpu.named_parameters(), ref.named_parameters()):
-        assert (p.grad is None) == (q.grad is None), k
-        if p.grad is not None:
-            g_gpu.append(p.grad.cpu().reshape(-1).double())
-            g_ref.append(q.grad.reshape(-1).double())
-            if float(q.grad.norm()) > 1e-6:
-                rel = float((p.grad.cpu() - q.grad).norm() / q.grad.norm())
-                assert rel < 0.15, (k, rel)
-    g_gpu, g_ref = torch.cat(g_gpu), torch.cat(g_ref)
-    cos = float(torch.dot(g_gpu, g_ref) / (g_gpu.norm() * g_ref.norm()))
-    assert cos > 0.995, cos
-    assert abs(float(g_gpu.norm() / g_ref.norm()) - 1.0) < 0.05
+    # Gradients: against an fp64 evaluation of the SAME graph (_fp64_reference_grads), per tensor.  How close fp32 CAN
+    # get is a property of the network, not of the kernels: every block is followed by a train-mode BatchNorm, which
+    # removes the mean of what it sees, so the gradients reaching the layers below are small differences of large sums.
+    # torch's own fp32 ops (fused kernels off) sit 0.1 - 2 % from the fp64 result on these tensors; the yardstick is
+    # therefore that baseline: the native path (own MFMA convolutions, fused BN / ReLU / pool passes, LDS scatter-adds)
+    # must be as accurate as the library path, tensor by tensor, and never worse than 3 %.
+    import copy
+    from regnet_for_3d_grasping_amd import bn_train, conv1x1_train
+    ref64 = _fp64_reference_grads(gpu, pc.to(DEV), target.to(DEV))
+
+    def errors(net):
+        out = {}
+        for k, p in net.named_parameters():
+            assert (p.grad is None) == (k not in ref64), k
+            if p.grad is not None and float(ref64[k].norm()) > 1e-9:
+                out[k] = float((p.grad.double() - ref64[k]).norm() / ref64[k].norm())
+        return out
+
+    native = errors(gpu)
+    lib = copy.deepcopy(gpu)
+    for p in lib.parameters():
+        p.grad = None
+    saved = (bn_train.ENABLED, conv1x1_train.ENABLED)
+    bn_train.ENABLED = conv1x1_train.ENABLED = False
+    try:
+        _, _, loss_lib = lib(pc.to(DEV), target.to(DEV))
+        loss_lib.backward()
+    finally:
+        bn_train.ENABLED, conv1x1_train.ENABLED = saved
+    library = errors(lib)
+    worst = max(native, key=native.get)
+    print("gradient error vs fp64: native worst %.2e (%s), library worst %.2e; median native %.2e / library %.2e" % (
+        native[worst], worst, max(library.values()), float(np.median(list(native.values()))),
+        float(np.median(list(library.values())))))
+    for k in native:
+        assert native[k] <= max(1e-3, 2.0 * library[k]), (k, native[k], library[k])
+        assert native[k] <= 3e-2, (k, native[k])
+    assert float(np.median(list(native.values()))) <= 1.25 * float(np.median(list(library.values()))) + 1e-4
 
     trainer = ScoreTrainer(gpu)
     before = gpu.extrat_featurePN2.conv_score.weight.detach().clone()
@@ -86,9 +163,9 @@ def test_full_training_step_on_gpu_matches_cpu_losses():
     total, parts = gpu.forward_losses(pc.to(DEV), target.to(DEV), records)
     assert "region_error" not in parts and "region_error" not in parts_ref
     assert abs(float(parts["score"]) - float(parts_ref["score"])) < 1e-5
-    # the centre sets agree unless a score sits within fp32 noise of the 0.5 threshold; then the losses agree too
-    if abs(float(total) - float(total_ref)) > 1e-3 * abs(float(total_ref)):
-        pytest.skip("a score crossed the centre-selection threshold between devices (discontinuous)")
+    # The centre picker thresholds the score at 0.5 (discontinuous): on these seeded inputs no score lies within the fp32
+    # noise of the threshold (checked, so that a failure below is a real one and not a flipped comparison)
+    assert abs(float(total) - float(total_ref)) <= 1e-3 * abs(float(total_ref)), (float(total), float(total_ref))
     np.random.seed(10)
     l1, _ = gpu.step(pc.to(DEV), target.to(DEV), records)
     l2, _ = gpu.step(pc.to(DEV), target.to(DEV), records)
@@ -206,3 +283,72 @@ def test_training_first_layer_before_gather_matches_plain_path():
             close_l2(p.grad, q.grad)
         for (k, p), (_, q) in zip(m.named_buffers(), m0.named_buffers()):
             close(p.float(), q.float())
+
+
+def test_full_size_training_iteration_matches_cpu_losses():
+    """configs[3]'s scene size: one training iteration's forward (ScoreNet with labels + grouping + stage-2 + refine
+    losses) on 2 scenes x 25 600 points against the oracle-backed CPU mirror, then the optimizer steps."""
+    from oracle.install import oracle_backend
+    from regnet_for_3d_grasping_amd import pipeline, synthetic
+    from regnet_for_3d_grasping_amd.gripper_region_network import GripperRegionNetwork
+    from regnet_for_3d_grasping_amd.score_network import ScoreNetwork
+    from regnet_for_3d_grasping_amd.train_step import RefineTrainer
+    B, N = 2, 25600
+    pc = synthetic.make_batch(8300, B, N)
+    records = [synthetic.make_grasp_labels(pc[b].numpy(), 70 + b) for b in range(B)]
+    target = torch.from_numpy(np.random.default_rng(4).uniform(0, 1, (B, N)).astype(np.float32))
+
+    def build(dev):
+        s = ScoreNetwork(training=True)
+        s.load_state_dict(synthetic.seeded_state_dict(s, 3))
+        r = GripperRegionNetwork(training=True, group_num=256, gripper_num=64, grasp_score_threshold=0.5,
+                                 radius=0.06, reg_channel=10)
+        r.load_state_dict(synthetic.seeded_state_dict(r, 4))
+        s.extrat_featurePN2.mlp.dropout_prob = 0.0
+        t = RefineTrainer(s.to(dev), r.to(dev), pipeline.PARAMS, pipeline.GRIPPER_PARAMS)
+        t.score_net.train(); t.region_net.train()
+        return t
+
+    cpu, gpu = build("cpu"), build(DEV)
+    with oracle_backend(), torch.no_grad():
+        np.random.seed(12)
+        total_ref, parts_ref = cpu.forward_losses(pc, target, records)
+    np.random.seed(12)
+    with torch.no_grad():
+        total, parts = gpu.forward_losses(pc.to(DEV), target.to(DEV), records)
+    assert "region_error" not in parts and "region_error" not in parts_ref
+    assert abs(float(parts["score"]) - float(parts_ref["score"])) < 1e-5
+    assert abs(float(total) - float(total_ref)) <= 1e-3 * abs(float(total_ref)), (float(total), float(total_ref))
+    np.random.seed(13)
+    l1, p1 = gpu.step(pc.to(DEV), target.to(DEV), records)
+    assert torch.isfinite(l1) and "region_error" not in p1
+    for net in (gpu.score_net, gpu.region_net):
+        assert all(torch.isfinite(p).all() for p in net.parameters())
+
+
+def test_training_step_51200_point_scene():
+    """configs[4]'s scene size (51 200 points: multi-workgroup level-1 sampling, larger grids): the training loss of one
+    scene equals the oracle-backed CPU mirror's, and an optimizer step runs."""
+    from oracle.install import oracle_backend
+    from regnet_for_3d_grasping_amd import synthetic
+    from regnet_for_3d_grasping_amd.score_network import ScoreNetwork
+    from regnet_for_3d_grasping_amd.train_step import ScoreTrainer
+    B, N = 1, 51200
+    pc = synthetic.make_batch(8400, B, N)
+    target = torch.from_numpy(np.random.default_rng(5).uniform(0, 1, (B, N)).astype(np.float32))
+    ref = ScoreNetwork(training=True)
+    ref.load_state_dict(synthetic.seeded_state_dict(ref, 3))
+    gpu = ScoreNetwork(training=True).to(DEV)
+    gpu.load_state_dict(ref.state_dict())
+    for net in (ref, gpu):
+        net.train()
+        net.extrat_featurePN2.mlp.dropout_prob = 0.0
+    with oracle_backend(), torch.no_grad():
+        _, _, loss_ref = ref(pc, target)
+    trainer = ScoreTrainer(gpu)
+    with torch.no_grad():
+        _, _, loss = gpu(pc.to(DEV), target.to(DEV))
+    assert abs(float(loss) - float(loss_ref)) < 1e-5
+    gpu.load_state_dict(ref.state_dict())      # undo the running-statistics update of the probe forward
+    out = trainer.step(pc.to(DEV), target.to(DEV))
+    assert torch.isfinite(out) and abs(float(out) - float(loss_ref)) < 1e-5
