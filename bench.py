@@ -150,8 +150,14 @@ def algorithmic_work(name, meta):
 
 
 # host wrapper -> device kernel it launches (for grouping launches into kernel families)
+def _mlp_layer_kernel(d):
+    """fused.mlp_layer launches gemm2_kernel (LDS-DMA ring) except for skinny problems (<= 1024 rows: the region heads),
+    which take the split-K path of the round-1 kernel."""
+    return "mlp_gemm_kernel" if d.get("P", 0) <= 1024 else "gemm2_kernel"
+
+
 KERNEL_OF = {"native_fwd": "tgemm_kernel", "native_dgrad": "tgemm_kernel", "native_wgrad": "tgemm_kernel",
-             "mlp_layer": "mlp_gemm_kernel", "sa_layer1": "mlp_gemm_kernel", "sa_layer12": "mlp_gemm_kernel",
+             "mlp_layer": _mlp_layer_kernel, "sa_layer1": "mlp_gemm_kernel", "sa_layer12": "mlp_gemm_kernel",
              "sa_premul_layer": "mlp_gemm_kernel", "sa_chain3": "sa_chain_kernel", "fp_head_chain": "fp_head_chain_kernel",
              "farthest_point_sample": "fps_kernel", "ball_query": "ball_query_kernel",
              "point_search": "three_nn_kernel", "radius_candidates": "radius_group_kernel",
@@ -311,6 +317,14 @@ def roofline_of(agg, steps, batch):
     for (name, meta), (tot, cnt) in agg.items():
         bound, units = algorithmic_work(name, meta)
         key = KERNEL_OF.get(name, name)
+        if callable(key):
+            d = {}
+            for tok in meta.split():
+                i = 0
+                while i < len(tok) and not tok[i].isdigit():
+                    i += 1
+                d[tok[:i]] = int(tok[i:])
+            key = key(d)
         f = fam.setdefault(key, {"ms": 0.0, "launches": 0, "units": 0, "bound": bound})
         f["ms"] += tot
         f["launches"] += cnt
