@@ -153,7 +153,7 @@ def algorithmic_work(name, meta):
 def _mlp_layer_kernel(d):
     """fused.mlp_layer launches gemm2_kernel (LDS-DMA ring) except for skinny problems (<= 1024 rows: the region heads),
     which take the split-K path of the round-1 kernel."""
-    return "mlp_gemm_kernel" if d.get("P", 0) <= 1024 else "gemm2_kernel"
+    return "mlp_gemm_kernel" if d.get("P", 0) <= 1024 or d.get("K", 0) < 17 else "gemm2_kernel"   # Kpad < 32: round-1 kernel
 
 
 KERNEL_OF = {"native_fwd": "tgemm_kernel", "native_dgrad": "tgemm_kernel", "native_wgrad": "tgemm_kernel",
