@@ -304,6 +304,23 @@ int regnet_interp_affine_f32(const float* ys, int64_t sb, int64_t sn, const int6
 int regnet_score_head_f32(const float* x, int64_t ldx, int64_t C, const float* w, float bias,
                           float bn_scale, float bn_shift, float* score, int64_t P, void* stream);
 
+/* regnet_sa_premul_chain_f32: layers 2 and 3 + the max over the 64 neighbours of the level-2 set-abstraction block of
+ * PointNet2Seg (utils/pointnet2.py:40-42: sa_channels[1] = (256, 256, 512); pn2_utils/modules.py:39-56, :244-245) in one
+ * kernel, on pre-multiplied layer-1 rows as regnet_sa_premul_layer_f32 takes them:
+ *     x0[p] = relu(U[b * Nsrc + nbr[p]] - V[p / 64])  ->  256 -> 256 -> 512 (folded BN affine, ReLU; ReLU of the last
+ *     layer if relu3)  ->  out[p / 64] = max over the neighbourhood.
+ * U (B*Nsrc, ldu >= 256), V (B*M, ldv >= 256), nbr (B, M, 64) int64, out (B*M, ldo >= 512).  Activations stay in
+ * registers (csrc/rowchain.hip); the (B*M*64 x 256) layer-2 activation of the two-launch path is never written.
+ * `stream_w`: regnet_sa_premul_chain_stream_floats() floats = 24 stages [32 output channels][256 k] -- the 8 row
+ * blocks of W2, then the 16 of W3 -- chunk-swizzled like regnet_fp_head_chain_f32's; `affine` = [scale2 | shift2 |
+ * scale3 | shift3] (1536 floats); `ticket`: one zeroed int32 (work-queue head).  Same values as
+ * regnet_sa_premul_layer_f32 + regnet_mlp_layer_f32(pool) up to fp32 summation order.                              */
+int64_t regnet_sa_premul_chain_stream_floats(void);
+int regnet_sa_premul_chain_f32(const float* U, int64_t ldu, const float* V, int64_t ldv, const int64_t* nbr, int64_t B,
+                               int64_t Nsrc, int64_t M, const float* stream_w, int64_t n_stages, const float* affine,
+                               int64_t affine_floats, int relu3, float* out, int64_t ldo, int32_t* ticket,
+                               void* stream);
+
 /* regnet_fp_head_chain_f32: the tail of the last feature-propagation block and the whole segmentation head of
  * PointNet2Seg as ONE kernel (utils/pointnet2.py:64-84 with fp_channels[2] = (256, 256, 256), :116-119 with
  * seg_channels = (512, 256, 256, 128); pn2_utils/modules.py:500-509):

@@ -8,7 +8,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libregnet_hip.so")
+LIB_PATH = os.environ.get("REGNET_HIP_LIB") or os.path.join(_HERE, "csrc", "libregnet_hip.so")   # override: A/B builds only
 
 _i64, _f32, _vp, _int = ctypes.c_int64, ctypes.c_float, ctypes.c_void_p, ctypes.c_int
 
@@ -67,6 +67,9 @@ SIGNATURES = {
     "regnet_interp_affine_f32": (_int, [_vp, _i64, _i64, _vp, _vp, _f32, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp,
                                         _vp, _vp, _int, _i64, _i64, _i64, _vp, _i64, _vp]),
     "regnet_score_head_f32": (_int, [_vp, _i64, _i64, _vp, _f32, _f32, _f32, _vp, _i64, _vp]),
+    "regnet_sa_premul_chain_stream_floats": (_i64, []),
+    "regnet_sa_premul_chain_f32": (_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _int, _vp, _i64,
+                                          _vp, _vp]),
     "regnet_fp_head_chain_stream_floats": (_i64, []),
     "regnet_fp_head_chain_f32": (_int, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _f32, _f32, _f32, _vp, _i64, _vp, _i64, _vp,
                                         _vp]),

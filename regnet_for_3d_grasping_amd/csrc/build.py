@@ -50,6 +50,25 @@ def _stamp():
     return h.hexdigest()
 
 
+def build_variant(out_path, defines):
+    """An extra copy of the library with -D defines applied to every source (A/B measurements only, e.g.
+    ``build_variant('/tmp/x.so', ['-DRC_WAVES=4'])``); the product library is ``build()``'s."""
+    hipcc = _hipcc()
+    objs = []
+    tmp = out_path + ".objs"
+    os.makedirs(tmp, exist_ok=True)
+    procs = []
+    for src, extra in SOURCES:
+        obj = os.path.join(tmp, src.replace(".hip", ".o"))
+        procs.append(subprocess.Popen([hipcc] + COMMON + extra + list(defines) + ["-c", os.path.join(HERE, src), "-o", obj]))
+        objs.append(obj)
+    for p in procs:
+        if p.wait() != 0:
+            raise RuntimeError("hipcc failed")
+    subprocess.check_call([hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", out_path] + objs)
+    return out_path
+
+
 def build(force=False, verbose=False):
     stamp_file = os.path.join(HERE, ".build_stamp")
     stamp = _stamp()

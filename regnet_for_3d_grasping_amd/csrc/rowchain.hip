@@ -29,11 +29,16 @@
 
 typedef float rc_f32x4 __attribute__((ext_vector_type(4)));
 
-#define RC_WAVES 8
+#ifndef RC_WAVES
+#define RC_WAVES 8                             // waves per workgroup: 8 (one workgroup per CU) or 4 (two per CU)
+#endif
+#define RC_WG_PER_CU (8 / RC_WAVES)
 #define RC_THREADS (RC_WAVES * 64)
 #define RC_STAGE_FLOATS (32 * 256)             // 32 KiB
-#define RC_STAGES 3
-#define RC_PIECES 4                            // 1 KiB LDS-DMA pieces per wave per stage (32 KiB / 8 waves)
+#ifndef RC_STAGES
+#define RC_STAGES (RC_WAVES == 8 ? 3 : 2)      // ring depth (two workgroups per CU: 2 x 2 x 32 KiB)
+#endif
+#define RC_PIECES (32 / RC_WAVES)              // 1 KiB LDS-DMA pieces per wave per stage
 #define RC_AFFINE_MAX 4096                     // floats of folded BN affine kept in LDS
 
 struct RcArgs {
@@ -129,6 +134,22 @@ __device__ __forceinline__ RcFrag rc_frag_offsets() {
   RC_PIN();                                                                \
   A0 = __builtin_amdgcn_mfma_f32_16x16x4f32(W0.w, X.w, A0, 0, 0, 0);       \
   A1 = __builtin_amdgcn_mfma_f32_16x16x4f32(W1.w, X.w, A1, 0, 0, 0);       \
+  RC_PIN();
+
+// The same step with the roles swapped: the activation registers as the A operand (rows = points), the weight fragment as
+// the B operand (columns = output channels) -> D[point 4 g + r][channel l & 15].
+#define RC_MFMA8_T(W0, W1, X, A0, A1)                                      \
+  A0 = __builtin_amdgcn_mfma_f32_16x16x4f32(X.x, W0.x, A0, 0, 0, 0);       \
+  A1 = __builtin_amdgcn_mfma_f32_16x16x4f32(X.x, W1.x, A1, 0, 0, 0);       \
+  RC_PIN();                                                                \
+  A0 = __builtin_amdgcn_mfma_f32_16x16x4f32(X.y, W0.y, A0, 0, 0, 0);       \
+  A1 = __builtin_amdgcn_mfma_f32_16x16x4f32(X.y, W1.y, A1, 0, 0, 0);       \
+  RC_PIN();                                                                \
+  A0 = __builtin_amdgcn_mfma_f32_16x16x4f32(X.z, W0.z, A0, 0, 0, 0);       \
+  A1 = __builtin_amdgcn_mfma_f32_16x16x4f32(X.z, W1.z, A1, 0, 0, 0);       \
+  RC_PIN();                                                                \
+  A0 = __builtin_amdgcn_mfma_f32_16x16x4f32(X.w, W0.w, A0, 0, 0, 0);       \
+  A1 = __builtin_amdgcn_mfma_f32_16x16x4f32(X.w, W1.w, A1, 0, 0, 0);       \
   RC_PIN();
 
 // Two consecutive layers  A: 256 -> M  and  B: M -> N  as one loop over the 128-channel groups of M:
@@ -228,7 +249,7 @@ __global__ __launch_bounds__(RC_THREADS, 2) void fp_head_chain_kernel(const RcAr
   const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   for (int i = tid; i < p.affine_floats; i += RC_THREADS) aff[i] = p.affine[i];
-  if (tid < 128) wsc[tid] = p.wscore[tid];
+  for (int i = tid; i < 128; i += RC_THREADS) wsc[i] = p.wscore[i];
 #ifndef RC_NO_TABLE_SYNC
   __syncthreads();   // the tables are read after the ring's barriers, which do not wait for LDS writes (lgkmcnt)
 #endif
@@ -302,7 +323,209 @@ __global__ __launch_bounds__(RC_THREADS, 2) void fp_head_chain_kernel(const RcAr
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the ring's look-ahead fetches must land before the LDS is released
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Level-2 set-abstraction block of PointNet2Seg on pre-multiplied layer-1 rows (pointnet2.py:40-42: 259 -> 256 -> 256
+// -> 512 over 1024 x 64 rows per scene; pn2_utils/modules.py:39-56, :244-245), layers 2 + 3 + the max over the 64
+// neighbours in one kernel:
+//     x0[p] = relu(U[b, nbr[p]] - V[p / 64])        (layer 1, evaluated per source point / per centre: fused.sa_features)
+//     x1 = relu(aff2(W2 . x0))   256 -> 256         channel-major, as in rc_pair's layer A
+//     y  = relu(aff3(x1 . W3^T)) 256 -> 512         POINT-major: x1's registers are just as well the A operand
+//                                                   (lane -> point l & 15, k -> channel 4 g + r), the weight fragment the B
+//                                                   operand; D[point 4 g + r][channel j'] -- the max over the points is then
+//                                                   a max over the 4 registers + two lane-group exchanges, no 16-lane reduction
+//     out[p / 64] = max over the neighbourhood's 4 waves (LDS)
+// The 537 MB (batch of 8) layer-2 activation the two-launch path writes and re-reads never exists.  24 stages per pass,
+// all [32 output channels][256 k]; a block = 128 rows = 2 neighbourhoods.
+struct ScArgs {
+  const float* U; long long ldu, scene_stride;   // U row of source point j of scene b: U + b * scene_stride + j * ldu
+  const float* V; long long ldv;                 // V row of neighbourhood g
+  const long long* nbr;                          // (groups, 64)
+  long long groups, groups_per_scene;
+  const float* stream; int n_stages;
+  const float* affine; int affine_floats;        // [scale2(256) | shift2(256) | scale3(512) | shift3(512)]
+  int relu3;
+  float* out; long long ldo;                     // (groups, 512)
+  int* ticket; long long n_blocks;
+};
+
+__global__ __launch_bounds__(RC_THREADS, 2) void sa_premul_chain_kernel(const ScArgs p) {
+  extern __shared__ __attribute__((aligned(1024))) float smem[];   // ring | affine (1536) | pool (8 x 512) | ticket
+  float* const aff = smem + RC_STAGES * RC_STAGE_FLOATS;
+  float* const pool = aff + 1536;
+  int* const s_blk = reinterpret_cast<int*>(pool + RC_WAVES * 512);
+  const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int i = tid; i < p.affine_floats; i += RC_THREADS) aff[i] = p.affine[i];
+  __syncthreads();
+
+  RcRing ring;
+  ring.n_stages = p.n_stages;
+  ring.src_begin = p.stream + (wave * RC_PIECES) * 256 + lane * 4;
+  ring.src = ring.src_begin;
+  ring.fetch_idx = 0;
+  ring.lds_lo = (unsigned)(uintptr_t)smem + (unsigned)(wave * RC_PIECES * 1024);
+  ring.lds_hi = ring.lds_lo + RC_STAGES * RC_STAGE_FLOATS * 4;
+  ring.lds_fetch = ring.lds_lo;
+  ring.slot = 0;
+  const RcFrag fo = rc_frag_offsets();
+  const int g4 = 4 * g;
+
+  bool primed = false;
+  for (;;) {
+    if (tid == 0) *s_blk = atomicAdd(p.ticket, 1);
+    __syncthreads();
+    const long long blk = __builtin_amdgcn_readfirstlane(*s_blk);
+    if (blk >= p.n_blocks) break;
+    if (!primed) {
+#pragma unroll
+      for (int d = 0; d < RC_STAGES - 1; ++d) ring.fetch();
+      primed = true;
+    }
+    const long long grp = blk * (RC_WAVES / 4) + (wave >> 2);  // this wave's neighbourhood
+    const bool active = grp < p.groups;                        // wave-uniform
+    const long long gs = active ? grp : 0;
+    // ---- layer-1 rows of this wave's 16 points
+    rc_f32x4 x0[16];
+    {
+      const long long b = gs / p.groups_per_scene;
+      const long long src = p.nbr[gs * 64 + (wave & 3) * 16 + j];
+      const float* ur = p.U + b * p.scene_stride + src * p.ldu + g4;
+      const float* vr = p.V + gs * p.ldv + g4;
+#pragma unroll
+      for (int kq = 0; kq < 4; ++kq) {     // four loads of each kind in flight at a time (all 32 at once spill)
+        rc_f32x4 u[4], v[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          u[t] = *reinterpret_cast<const rc_f32x4*>(ur + 16 * (4 * kq + t));
+          v[t] = *reinterpret_cast<const rc_f32x4*>(vr + 16 * (4 * kq + t));
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) x0[4 * kq + t][r] = fmaxf(u[t][r] - v[t][r], 0.f);
+        RC_PIN();
+      }
+    }
+    // ---- layer 2: 8 stages, fully unrolled (x1 is a compile-time register array)
+    rc_f32x4 x1[16];
+#pragma unroll
+    for (int st8 = 0; st8 < 8; ++st8) {
+      rc_f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+      const int slot = ring.acquire<false>();
+      if (active) {
+        const float* st = smem + slot * RC_STAGE_FLOATS;
+        rc_f32x4 w0n = *reinterpret_cast<const rc_f32x4*>(st + fo.a[0]);
+        rc_f32x4 w1n = *reinterpret_cast<const rc_f32x4*>(st + fo.a[0] + 16 * 256);
+#pragma unroll
+        for (int kt = 0; kt < 16; ++kt) {
+          const rc_f32x4 w0 = w0n, w1 = w1n;
+          if (kt + 1 < 16) {
+            const float* wp = st + fo.a[(kt + 1) & 3] + 64 * ((kt + 1) >> 2);
+            w0n = *reinterpret_cast<const rc_f32x4*>(wp);
+            w1n = *reinterpret_cast<const rc_f32x4*>(wp + 16 * 256);
+          }
+          RC_PIN();
+          const rc_f32x4 x = x0[kt];
+          RC_MFMA8(w0, w1, x, acc0, acc1)
+        }
+      }
+      const float* a = aff + 32 * st8 + g4;
+      const rc_f32x4 s0 = *reinterpret_cast<const rc_f32x4*>(a), s1 = *reinterpret_cast<const rc_f32x4*>(a + 16);
+      const rc_f32x4 t0 = *reinterpret_cast<const rc_f32x4*>(a + 256), t1 = *reinterpret_cast<const rc_f32x4*>(a + 256 + 16);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        acc0[r] = fmaxf(acc0[r] * s0[r] + t0[r], 0.f);
+        acc1[r] = fmaxf(acc1[r] * s1[r] + t1[r], 0.f);
+      }
+      x1[2 * st8] = acc0; x1[2 * st8 + 1] = acc1;
+    }
+    // ---- layer 3 + max over the points, one stage (32 channels) at a time
+    for (int s3 = 0; s3 < 16; ++s3) {
+      rc_f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+      const int slot = ring.acquire<false>();
+      if (active) {
+        const float* st = smem + slot * RC_STAGE_FLOATS;
+        rc_f32x4 w0n = *reinterpret_cast<const rc_f32x4*>(st + fo.a[0]);
+        rc_f32x4 w1n = *reinterpret_cast<const rc_f32x4*>(st + fo.a[0] + 16 * 256);
+#pragma unroll
+        for (int kt = 0; kt < 16; ++kt) {
+          const rc_f32x4 w0 = w0n, w1 = w1n;
+          if (kt + 1 < 16) {
+            const float* wp = st + fo.a[(kt + 1) & 3] + 64 * ((kt + 1) >> 2);
+            w0n = *reinterpret_cast<const rc_f32x4*>(wp);
+            w1n = *reinterpret_cast<const rc_f32x4*>(wp + 16 * 256);
+          }
+          RC_PIN();
+          const rc_f32x4 x = x1[kt];
+          RC_MFMA8_T(w0, w1, x, acc0, acc1)
+        }
+        // folded BN affine (+ ReLU) per channel (32 s3 + 16 t + j), max over this wave's 16 points: registers, then lane groups
+        const float sc0 = aff[512 + 32 * s3 + j], sc1 = aff[512 + 32 * s3 + 16 + j];
+        const float sh0 = aff[1024 + 32 * s3 + j], sh1 = aff[1024 + 32 * s3 + 16 + j];
+        float m0 = -__builtin_inff(), m1 = -__builtin_inff();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          m0 = fmaxf(m0, acc0[r] * sc0 + sh0);
+          m1 = fmaxf(m1, acc1[r] * sc1 + sh1);
+        }
+        if (p.relu3) { m0 = fmaxf(m0, 0.f); m1 = fmaxf(m1, 0.f); }
+        m0 = fmaxf(m0, __shfl_xor(m0, 16, 64)); m1 = fmaxf(m1, __shfl_xor(m1, 16, 64));
+        m0 = fmaxf(m0, __shfl_xor(m0, 32, 64)); m1 = fmaxf(m1, __shfl_xor(m1, 32, 64));
+        if (g == 0) {
+          pool[wave * 512 + 32 * s3 + j] = m0;
+          pool[wave * 512 + 32 * s3 + 16 + j] = m1;
+        }
+      }
+    }
+    // ---- max over the 4 waves of each neighbourhood (the ring's next barriers separate this from the next pass's writes)
+    __syncthreads();
+#pragma unroll
+    for (int n = 0; n < RC_WAVES / 4; ++n) {
+      const long long gn = blk * (RC_WAVES / 4) + n;
+      if (gn < p.groups)
+        for (int c = tid; c < 512; c += RC_THREADS) {
+          const float* q = pool + (4 * n) * 512 + c;
+          p.out[gn * p.ldo + c] = fmaxf(fmaxf(q[0], q[512]), fmaxf(q[1024], q[1536]));
+        }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 static bool rc_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+extern "C" int64_t regnet_sa_premul_chain_stream_floats(void) { return 24ll * RC_STAGE_FLOATS; }
+
+extern "C" int regnet_sa_premul_chain_f32(const float* U, int64_t ldu, const float* V, int64_t ldv, const int64_t* nbr,
+                                          int64_t B, int64_t Nsrc, int64_t M, const float* stream, int64_t n_stages,
+                                          const float* affine, int64_t affine_floats, int relu3, float* out, int64_t ldo,
+                                          int32_t* ticket, void* stream_handle) {
+  if (B < 0 || M < 0 || Nsrc <= 0 || ldu < 256 || ldv < 256 || (ldu & 3) || (ldv & 3) || ldo < 512 || n_stages != 24 ||
+      affine_floats != 1536)
+    return REGNET_ERR_SHAPE;
+  const long long groups = B * M;
+  if (groups == 0) return REGNET_OK;
+  if (!U || !V || !nbr || !stream || !affine || !out || !ticket) return REGNET_ERR_NULL;
+  if (!rc_aligned16(U) || !rc_aligned16(V) || !rc_aligned16(stream) || !rc_aligned16(affine)) return REGNET_ERR_SHAPE;
+  ScArgs a = {};
+  a.U = U; a.ldu = ldu; a.scene_stride = Nsrc * ldu; a.V = V; a.ldv = ldv; a.nbr = (const long long*)nbr;
+  a.groups = groups; a.groups_per_scene = M; a.stream = stream; a.n_stages = (int)n_stages;
+  a.affine = affine; a.affine_floats = (int)affine_floats; a.relu3 = relu3; a.out = out; a.ldo = ldo;
+  a.ticket = ticket; a.n_blocks = (groups + RC_WAVES / 4 - 1) / (RC_WAVES / 4);
+  const int cus = 256 * RC_WG_PER_CU;
+  const long long wgs = a.n_blocks < cus ? a.n_blocks : cus;
+  const size_t lds = (size_t)(RC_STAGES * RC_STAGE_FLOATS + 1536 + RC_WAVES * 512 + 4) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sa_premul_chain_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(sa_premul_chain_kernel, dim3((unsigned)wgs), dim3(RC_THREADS), lds, as_stream(stream_handle), a);
+  REGNET_LAUNCH_CHECK();
+  return REGNET_OK;
+}
 
 extern "C" int64_t regnet_fp_head_chain_stream_floats(void) { return 60ll * RC_STAGE_FLOATS; }
 
@@ -321,8 +544,8 @@ extern "C" int regnet_fp_head_chain_f32(const float* X, int64_t ldx, const float
   a.stream = stream; a.n_stages = (int)n_stages; a.affine = affine; a.affine_floats = (int)affine_floats;
   a.wscore = wscore; a.score_bias = score_bias; a.score_bn_scale = score_bn_scale; a.score_bn_shift = score_bn_shift;
   a.ticket = ticket;
-  a.n_blocks = (P + 127) / 128;
-  const int cus = 256;
+  a.n_blocks = (P + 16 * RC_WAVES - 1) / (16 * RC_WAVES);
+  const int cus = 256 * RC_WG_PER_CU;
   const long long wgs = a.n_blocks < cus ? a.n_blocks : cus;
   const size_t lds = (size_t)(RC_STAGES * RC_STAGE_FLOATS + RC_AFFINE_MAX + 128 + 4) * sizeof(float);
   static bool attr_set = false;

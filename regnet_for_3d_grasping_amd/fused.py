@@ -340,6 +340,8 @@ TIMED_OPS = {
     "sa_chain3": lambda feature, xyz, nbr, ctr, l1, l2, l3, B, M, group, count=None, order=None:
         "P%d K%d N%d flop%d" % (B * M * group, l3.K, l3.N,
                                 2 * B * M * group * (l1.K * l1.N + l2.K * l2.N + l3.K * l3.N)),
+    "sa_premul_chain": lambda U, V, nbr, module, layers, B, Nsrc, M:
+        "P%d K256 N512 flop%d" % (B * M * 64, 2 * B * M * 64 * (256 * 256 + 256 * 512)),
     "fp_head_chain": lambda h1, seg, fp_layers, P: "P%d K256 N256 flop%d" % (P, 2 * P * 491520),
     "sa_layer12": lambda feature, xyz, nbr, ctr, first, layer, B, M, group, pool_group=0:
         "P%d K%d N%d flop%d" % (B * M * group, layer.K, layer.N,
@@ -418,6 +420,10 @@ def sa_features(module, xyz, feature, geo):
         width = _round_up(Cf + 3, 4)
         U = mlp_layer(pack_rows(feature, xyz, width), width, u_layer, B * N1)
         V = mlp_layer(pack_rows(None, geo["new_xyz"], 4), 4, v_layer, B * M)
+        if supports_sa_chain(layers) and U.size(1) == 256:
+            # layers 2 and 3 + the pooling in one kernel, layer-2 activation in registers (csrc/rowchain.hip)
+            pooled = sa_premul_chain(U, V, geo["nbr"], module, layers, B, N1, M)
+            return geo["new_xyz"], pooled.view(B, M, -1).transpose(1, 2)
         if len(layers) == 2:
             pooled = sa_premul_layer(U, V, geo["nbr"], layers[1], B, N1, M, K, pool_group=K)
             return geo["new_xyz"], pooled.view(B, M, -1).transpose(1, 2)
@@ -504,6 +510,41 @@ def head_forward(seg, sparse_feature):
         h = mlp_layer(h, Ka, layer, B * N)
         Ka = layer.N
     return score_head(h, seg, B * N).view(B, N)
+
+
+# ---- level-2 set-abstraction block: layers 2 + 3 + pooling as ONE kernel (csrc/rowchain.hip) ---------------------------
+def _packed_sa_chain(module, layers):
+    """Weight stream (24 stages [32 rows][256 k], layer 2 then layer 3) + affine table of sa_premul_chain."""
+    sig = _signature(module.mlp)
+    cache = getattr(module, "_regnet_sa_chain", None)
+    if cache is None or cache[0] != sig:
+        l2, l3 = layers[1], layers[2]
+        stages = [_swizzle_stage(l2.W[32 * s:32 * s + 32, :256]) for s in range(8)]
+        stages += [_swizzle_stage(l3.W[32 * s:32 * s + 32, :256]) for s in range(16)]
+        stream = torch.cat(stages).contiguous()
+        affine = torch.cat([l2.scale[:256], l2.shift[:256], l3.scale[:512], l3.shift[:512]]).contiguous()
+        assert stream.numel() == _L.regnet_sa_premul_chain_stream_floats() and affine.numel() == 1536
+        cache = (sig, (stream, affine))
+        module._regnet_sa_chain = cache
+    return cache[1]
+
+
+def supports_sa_chain(layers):
+    return (ROWCHAIN and len(layers) == 3 and layers[0].N == 256 and layers[1].K == 256 and layers[1].N == 256
+            and layers[1].relu and layers[2].K == 256 and layers[2].N == 512)
+
+
+@_on_tensor_device
+def sa_premul_chain(U, V, nbr, module, layers, B, Nsrc, M):
+    """relu(U[nbr] - V[centre]) -> 256 -> 512 -> max over the 64 neighbours, one launch; -> (B*M, 512)."""
+    stream, affine = _packed_sa_chain(module, layers)
+    out = torch.empty((B * M, 512), dtype=torch.float32, device=U.device)
+    ticket = torch.zeros((1,), dtype=torch.int32, device=U.device)
+    _check(_L.regnet_sa_premul_chain_f32(U.data_ptr(), U.stride(0), V.data_ptr(), V.stride(0), nbr.data_ptr(), B, Nsrc,
+                                         M, stream.data_ptr(), 24, affine.data_ptr(), affine.numel(), layers[2].relu,
+                                         out.data_ptr(), out.stride(0), ticket.data_ptr(), _stream(U)),
+           "sa_premul_chain")
+    return out
 
 
 # ---- FP3 tail + segmentation head as ONE kernel (csrc/rowchain.hip) --------------------------------------------------
@@ -605,6 +646,8 @@ def prepack(score_net, region_net=None):
         layers = _packed_stack(sa, sa.mlp, lambda Cf=Cf: torch.cat([torch.arange(3, 3 + Cf), torch.arange(0, 3)]).to(dev))
         if layers[0].W8 is None and Cf > 0:
             _premul_layers(layers[0], Cf)
+            if supports_sa_chain(layers):
+                _packed_sa_chain(sa, layers)
     sparse = seg.sa_modules[-1].out_channels
     for fp in seg.fp_modules:
         layers = _packed_stack(fp, fp.mlp)
