@@ -429,6 +429,22 @@ def main():
         timer.enabled = False
         exclusive = (timer.summary(), dt1)
 
+    latency_ms = None
+    if rank == 0 and world == 1:
+        # latency of ONE scene through the whole forward (batch 1, nothing else in flight), outside the timed region:
+        # the level-1 furthest-point-sampling chain (5119 dependent rounds on one CU) is most of it
+        one = pc[:1].contiguous()
+        state = np.random.get_state()
+        for _ in range(2):
+            pipeline.forward_scenes(score_net, region_net, one, with_region=not args.score_only)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            pipeline.forward_scenes(score_net, region_net, one, with_region=not args.score_only)
+            torch.cuda.synchronize()
+        latency_ms = round((time.perf_counter() - t1) / 5 * 1e3, 3)
+        np.random.set_state(state)
+
     if rank == 0:
         total_scenes = args.batch * args.steps * world
         agg = main_summary
@@ -455,6 +471,7 @@ def main():
                                                          / 1e9 / max(args.steps * args.batch, 1), 2)},
             "roofline": roofline,
             "roofline_exclusive": None,
+            "latency_ms_single_scene": latency_ms,
             "mlp_tflops": round(SCORENET_GFLOP_PER_SCENE.get(args.points, 0.0) * total_scenes / world / dt / 1e3, 3),
             "kernels": kernels[:40],
             "grasps_last_step": int(out["next_grasp"].shape[0]) if "next_grasp" in out else None,
