@@ -151,9 +151,21 @@ def algorithmic_work(name, meta):
 
 # host wrapper -> device kernel it launches (for grouping launches into kernel families)
 def _mlp_layer_kernel(d):
-    """fused.mlp_layer launches gemm2_kernel (LDS-DMA ring) except for skinny problems (<= 1024 rows: the region heads),
-    which take the split-K path of the round-1 kernel."""
-    return "mlp_gemm_kernel" if d.get("P", 0) <= 1024 or d.get("K", 0) < 17 else "gemm2_kernel"   # Kpad < 32: round-1 kernel
+    """Device kernel a fused.mlp_layer call launches, at rocprofv3's granularity (one name per template instantiation;
+    the choice mirrors csrc/mlp.hip:launch_gemm2): skinny problems (<= 1024 rows: the region heads) and K < 17 take the
+    round-1 kernel, everything else gemm2_kernel -- 256 x 128 tiles (pooling or not) or 128 x 128."""
+    P, K, N = d.get("P", 0), d.get("K", 0), d.get("N", 0)
+    if P <= 1024 or K < 17:
+        return "mlp_gemm_kernel"
+    nt = (N + 127) // 128
+    t256, t128, kpad = ((P + 255) // 256) * nt, ((P + 127) // 128) * nt, (K + 15) // 16 * 16
+    if N > 128 and (t256 >= 512 or (t256 >= 256 and kpad >= 1024)):
+        tile = "256,128"
+    elif 256 <= t128 <= 512 or t128 >= 1536:
+        tile = "128,128"
+    else:
+        tile = "64,128"
+    return "gemm2_kernel<%s%s>" % (tile, ",pool" if d.get("pool") else "")
 
 
 KERNEL_OF = {"native_fwd": "tgemm_kernel", "native_dgrad": "tgemm_kernel", "native_wgrad": "tgemm_kernel",
@@ -332,6 +344,8 @@ def roofline_of(agg, steps, batch):
     if not fam:
         return fam, None
 
+    # kernels are told apart as rocprofv3 does (one name per template instantiation), so that the committed
+    # --kernel-trace summary can be held against this line kernel by kernel
     # dominant = most GPU resource-time: a furthest-point-sampling launch keeps ONE CU per
     # scene busy (a latency chain running beside the MLPs), every other kernel fills the chip
     def cu_ms(k):

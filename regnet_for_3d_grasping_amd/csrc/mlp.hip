@@ -505,9 +505,16 @@ static int launch_gemm2_tile(G2Args g, bool pool, hipStream_t st) {
 }
 
 static int launch_gemm2(const G2Args& g, bool pool, hipStream_t st) {
-  const long long tiles_big = ((g.P + 255) / 256) * ((g.N + 127) / 128);
-  if (g.N > 128 && tiles_big >= G2_CUS) return launch_gemm2_tile<256, 128, 4, 2, 3, 2>(g, pool, st);
-  return launch_gemm2_tile<128, 128, 2, 2, 3, 3>(g, pool, st);
+  // Measured on the step's layer shapes (scripts/ablate/g2_bench.cpp [medium]): the big tile wants at least one full
+  // round of its 512 slots (or one tile per CU when K is long); below that 128 x 128 wins while it yields 256..512
+  // tiles, and 64 x 128 (4 workgroups per CU) when the problem is smaller still or falls between the two
+  // (P = 40 960, N = 256: 74 / 93 / 105 TFLOP/s for the three tiles; P = 2 048, N = 1 024: 33 / 60 / 95).
+  const long long nt = (g.N + 127) / 128;
+  const long long t256 = ((g.P + 255) / 256) * nt, t128 = ((g.P + 127) / 128) * nt;
+  if (g.N > 128 && (t256 >= 2 * G2_CUS || (t256 >= G2_CUS && g.Kpad >= 1024)))
+    return launch_gemm2_tile<256, 128, 4, 2, 3, 2>(g, pool, st);
+  if ((t128 >= G2_CUS && t128 <= 2 * G2_CUS) || t128 >= 6 * G2_CUS) return launch_gemm2_tile<128, 128, 2, 2, 3, 3>(g, pool, st);
+  return launch_gemm2_tile<64, 128, 1, 4, 3, 4>(g, pool, st);
 }
 
 extern "C" int regnet_mlp_layer_f32(const float* A, int64_t lda, int64_t Ka, const float* W, int64_t Kpad,

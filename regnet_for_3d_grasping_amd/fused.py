@@ -333,7 +333,7 @@ def _flop_meta(P, K, N):
 
 # what bench.py brackets with HIP events: name -> meta(args) (algorithmic flops use the TRUE K)
 TIMED_OPS = {
-    "mlp_layer": lambda A, Ka, layer, P, pool_group=0: _flop_meta(P, layer.K, layer.N),
+    "mlp_layer": lambda A, Ka, layer, P, pool_group=0: _flop_meta(P, layer.K, layer.N) + (" pool%d" % pool_group if pool_group else ""),
     "sa_layer1": lambda feature, xyz, nbr, ctr, layer, B, M, group: _flop_meta(B * M * group, layer.K, layer.N),
     "sa_premul_layer": lambda U, V, nbr, layer, B, Nsrc, M, group, pool_group=0:
         _flop_meta(B * M * group, layer.K, layer.N),
