@@ -43,6 +43,9 @@ def parse():
     ap.add_argument("--points", type=int, default=25600)
     ap.add_argument("--cpu-scenes", type=int, default=4, help="scenes timed for cpu_baseline (0 = skip)")
     ap.add_argument("--score-only", action="store_true", help="configs[1]: ScoreNet forward only")
+    ap.add_argument("--latency-runs", type=int, default=5,
+                    help="batch-1 forwards timed AFTER the timed region for latency_ms_single_scene (0 = skip, e.g. under "
+                         "rocprofv3 so that the trace holds the bench's launches only)")
     ap.add_argument("--time-every", type=int, default=8,
                     help="bracket every n-th call of each native op (per shape) with HIP events; bracketing all calls costs ~2 %")
     ap.add_argument("--train", action="store_true",
@@ -444,7 +447,7 @@ def main():
         exclusive = (timer.summary(), dt1)
 
     latency_ms = None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and args.latency_runs > 0:
         # latency of ONE scene through the whole forward (batch 1, nothing else in flight), outside the timed region:
         # the level-1 furthest-point-sampling chain (5119 dependent rounds on one CU) is most of it
         one = pc[:1].contiguous()
@@ -453,10 +456,10 @@ def main():
             pipeline.forward_scenes(score_net, region_net, one, with_region=not args.score_only)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        for _ in range(5):
+        for _ in range(args.latency_runs):
             pipeline.forward_scenes(score_net, region_net, one, with_region=not args.score_only)
             torch.cuda.synchronize()
-        latency_ms = round((time.perf_counter() - t1) / 5 * 1e3, 3)
+        latency_ms = round((time.perf_counter() - t1) / args.latency_runs * 1e3, 3)
         np.random.set_state(state)
 
     if rank == 0:

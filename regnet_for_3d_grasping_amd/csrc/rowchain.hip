@@ -494,6 +494,19 @@ __global__ __launch_bounds__(RC_THREADS, 2) void sa_premul_chain_kernel(const Sc
 
 static bool rc_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// > 64 KiB of dynamic LDS needs the function attribute, once per (kernel, device) -- one process may drive several GPUs
+static int rc_allow_lds(const void* kernel, size_t bytes) {
+  static unsigned long long done[2] = {0ull, 0ull};   // bit per device id < 64, per kernel
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return (int)hipGetLastError();
+  const int which = kernel == reinterpret_cast<const void*>(fp_head_chain_kernel) ? 0 : 1;
+  if (dev >= 0 && dev < 64 && (done[which] >> dev) & 1ull) return REGNET_OK;
+  hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) return (int)e;
+  if (dev >= 0 && dev < 64) done[which] |= 1ull << dev;
+  return REGNET_OK;
+}
+
 extern "C" int64_t regnet_sa_premul_chain_stream_floats(void) { return 24ll * RC_STAGE_FLOATS; }
 
 extern "C" int regnet_sa_premul_chain_f32(const float* U, int64_t ldu, const float* V, int64_t ldv, const int64_t* nbr,
@@ -515,13 +528,8 @@ extern "C" int regnet_sa_premul_chain_f32(const float* U, int64_t ldu, const flo
   const int cus = 256 * RC_WG_PER_CU;
   const long long wgs = a.n_blocks < cus ? a.n_blocks : cus;
   const size_t lds = (size_t)(RC_STAGES * RC_STAGE_FLOATS + 1536 + RC_WAVES * 512 + 4) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sa_premul_chain_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  int rc_attr = rc_allow_lds(reinterpret_cast<const void*>(sa_premul_chain_kernel), lds);
+  if (rc_attr) return rc_attr;
   hipLaunchKernelGGL(sa_premul_chain_kernel, dim3((unsigned)wgs), dim3(RC_THREADS), lds, as_stream(stream_handle), a);
   REGNET_LAUNCH_CHECK();
   return REGNET_OK;
@@ -548,13 +556,8 @@ extern "C" int regnet_fp_head_chain_f32(const float* X, int64_t ldx, const float
   const int cus = 256 * RC_WG_PER_CU;
   const long long wgs = a.n_blocks < cus ? a.n_blocks : cus;
   const size_t lds = (size_t)(RC_STAGES * RC_STAGE_FLOATS + RC_AFFINE_MAX + 128 + 4) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fp_head_chain_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  int rc_attr = rc_allow_lds(reinterpret_cast<const void*>(fp_head_chain_kernel), lds);
+  if (rc_attr) return rc_attr;
   hipLaunchKernelGGL(fp_head_chain_kernel, dim3((unsigned)wgs), dim3(RC_THREADS), lds, as_stream(stream_handle), a);
   REGNET_LAUNCH_CHECK();
   return REGNET_OK;
