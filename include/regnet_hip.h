@@ -4,8 +4,9 @@
  *
  * Conventions (all entry points):
  *   - plain device pointers + int64 sizes/element-strides, no torch types, no allocation, no
- *     global state; re-entrant; the caller owns every buffer (the Python binding allocates the
- *     outputs exactly like the reference does with at::zeros);
+ *     global state that affects results (the only statics: a per-device "large-LDS attribute set" bit of the two
+ *     row-chain kernels, a debugging environment switch read once); re-entrant; the caller owns every buffer (the
+ *     Python binding allocates the outputs exactly like the reference does with at::zeros);
  *   - `stream` is a hipStream_t passed as void* (NULL = the legacy default stream, which is what
  *     the reference launches on);
  *   - return value: 0 on success, REGNET_ERR_* (<0) for an argument the reference would have
