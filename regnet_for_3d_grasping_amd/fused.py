@@ -20,6 +20,7 @@ ENABLED = True
 CHAIN3 = True   # level-1 set-abstraction block as one register-chained kernel (see sa_features)
 SPLITK_MAX_ROWS = 1024   # at most this many rows: the GEMM is "skinny" and is split along K (see mlp_layer)
 PREMUL = True   # evaluate the first layer of wide set-abstraction blocks per source point (see sa_features)
+PREMUL_CENTRE = __import__("os").environ.get("REGNET_PREMUL_CENTRE", "1") != "0"   # ... on mean-centred coordinates
 
 _check = _lib.check
 _L = _lib.lib
@@ -418,8 +419,16 @@ def sa_features(module, xyz, feature, geo):
         first, N1 = layers[0], xyz.shape[2]
         u_layer, v_layer = _premul_layers(first, Cf)
         width = _round_up(Cf + 3, 4)
-        U = mlp_layer(pack_rows(feature, xyz, width), width, u_layer, B * N1)
-        V = mlp_layer(pack_rows(None, geo["new_xyz"], 4), 4, v_layer, B * M)
+        # U[j] - V[c] = s W [f_j | x_j - x_c] - t only up to fp32 rounding of the two big terms: both sides use the
+        # coordinates RELATIVE TO THE SCENE'S MEAN (the difference is unchanged, the magnitudes -- table-top scenes sit
+        # ~0.75 m from the origin -- and with them the cancellation error of the subtraction shrink)
+        if PREMUL_CENTRE:
+            mu = xyz.mean(dim=2, keepdim=True)
+            src_xyz, ctr_xyz = xyz - mu, geo["new_xyz"] - mu
+        else:
+            src_xyz, ctr_xyz = xyz, geo["new_xyz"]
+        U = mlp_layer(pack_rows(feature, src_xyz, width), width, u_layer, B * N1)
+        V = mlp_layer(pack_rows(None, ctr_xyz, 4), 4, v_layer, B * M)
         if supports_sa_chain(layers) and U.size(1) == 256:
             # layers 2 and 3 + the pooling in one kernel, layer-2 activation in registers (csrc/rowchain.hip)
             pooled = sa_premul_chain(U, V, geo["nbr"], module, layers, B, N1, M)
