@@ -39,6 +39,10 @@ typedef float rc_f32x4 __attribute__((ext_vector_type(4)));
 #define RC_STAGES (RC_WAVES == 8 ? 3 : 2)      // ring depth (two workgroups per CU: 2 x 2 x 32 KiB)
 #endif
 #define RC_PIECES (32 / RC_WAVES)              // 1 KiB LDS-DMA pieces per wave per stage
+#ifndef RC_SPREAD_FETCH
+#define RC_SPREAD_FETCH 0                      // 1: a stage's LDS-DMA pieces are issued between its MFMA steps (measured 2 %
+                                               // SLOWER per kernel, same step time); 0: all right behind the barrier
+#endif
 #define RC_AFFINE_MAX 4096                     // floats of folded BN affine kept in LDS
 
 struct RcArgs {
@@ -75,29 +79,45 @@ struct RcRing {
   unsigned lds_lo, lds_hi; // ... in slot 0 / one past the last slot
   int slot;                // ring slot of the stage to be consumed next
 
+  __device__ __forceinline__ void fetch_piece(int j) {   // j = 0 .. RC_PIECES - 1, in order; the last one advances the ring
+    rc_glds16(src + j * 256, lds_fetch + j * 1024);
+    if (j == RC_PIECES - 1) {
+      src += RC_STAGE_FLOATS;
+      if (++fetch_idx == n_stages) { fetch_idx = 0; src = src_begin; }
+      lds_fetch += RC_STAGE_FLOATS * 4;
+      if (lds_fetch == lds_hi) lds_fetch = lds_lo;
+    }
+  }
   __device__ __forceinline__ void fetch() {
 #pragma unroll
-    for (int j = 0; j < RC_PIECES; ++j) rc_glds16(src + j * 256, lds_fetch + j * 1024);
-    src += RC_STAGE_FLOATS;
-    if (++fetch_idx == n_stages) { fetch_idx = 0; src = src_begin; }
-    lds_fetch += RC_STAGE_FLOATS * 4;
-    if (lds_fetch == lds_hi) lds_fetch = lds_lo;
+    for (int j = 0; j < RC_PIECES; ++j) fetch_piece(j);
   }
   // Make the next stage readable (mine: counted wait; everybody's: barrier -- which also says that nobody reads the
-  // slot consumed last any more) and start the fetch of the stage behind the ones in flight into that slot.
+  // slot consumed last any more, so the stage behind the ones in flight is fetched into it: right here, or -- with
+  // RC_SPREAD_FETCH -- one LDS-DMA piece at a time between the stage's MFMA steps (RC_FETCH_AT)).
   // The counted wait stays correct with other vector memory operations outstanding (activation loads, feature
-  // stores, issued after the newest fetch): loads return in order among loads, so "at most 4 operations outstanding"
-  // implies that at most the 4 newest LOADS are -- every piece of the stage wanted here is older than those; extra
-  // operations only make the wait longer.  DRAIN (vmcnt(0)) is kept as a debugging switch.
+  // stores, issued after the newest fetch): loads return in order among loads, so "at most RC_PIECES operations
+  // outstanding" implies that at most the RC_PIECES newest LOADS are -- every piece of the stage wanted here is older
+  // than those; extra operations only make the wait longer.  DRAIN (vmcnt(0)) is kept as a debugging switch.
   template <bool DRAIN> __device__ __forceinline__ int acquire() {
     if (DRAIN) rc_wait_barrier<0>();
     else rc_wait_barrier<(RC_STAGES - 2) * RC_PIECES>();
+#if !RC_SPREAD_FETCH
     fetch();
+#endif
     const int s = slot;
     slot = (slot + 1 == RC_STAGES) ? 0 : slot + 1;
     return s;
   }
 };
+
+// One LDS-DMA piece of the next fetch behind step STEP_ of a 16-step stage (pieces spread evenly over the steps).
+#if RC_SPREAD_FETCH
+#define RC_FETCH_AT(RING_, STEP_)                                                              \
+  if (((STEP_) + 1) % (16 / RC_PIECES) == 0) (RING_).fetch_piece(((STEP_) + 1) / (16 / RC_PIECES) - 1);
+#else
+#define RC_FETCH_AT(RING_, STEP_)
+#endif
 
 // Per-lane fragment offsets (floats) inside a stage.  A-stages are [32 rows][256 k], B-stages [64 rows][128 k]; in both
 // the logical 16-byte chunk 4 kt + g of row (16 t + j) is stored at physical chunk (4 kt + g) ^ j =
@@ -174,7 +194,7 @@ __device__ __forceinline__ void rc_pair(const rc_f32x4 (&xin)[16], rc_f32x4 (&xo
     for (int u = 0; u < 4; ++u) {
       rc_f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
       const int slot = ring.acquire<false>();
-      if (active) {
+      {   // (waves without rows in the last pass compute on row 0's data: no branch around the MFMA stream)
         const float* st = smem + slot * RC_STAGE_FLOATS;
         rc_f32x4 w0n = *reinterpret_cast<const rc_f32x4*>(st + fo.a[0]);
         rc_f32x4 w1n = *reinterpret_cast<const rc_f32x4*>(st + fo.a[0] + 16 * 256);
@@ -189,6 +209,7 @@ __device__ __forceinline__ void rc_pair(const rc_f32x4 (&xin)[16], rc_f32x4 (&xo
           RC_PIN();
           const rc_f32x4 x = xin[kt];
           RC_MFMA8(w0, w1, x, acc0, acc1)
+          RC_FETCH_AT(ring, kt)
         }
       }
       const float* a = affA + 128 * ob + 32 * u + g4;   // register r of tile t = channel 16 t + 4 g + r
@@ -205,7 +226,7 @@ __device__ __forceinline__ void rc_pair(const rc_f32x4 (&xin)[16], rc_f32x4 (&xo
 #pragma unroll
     for (int v = 0; v < N / 64; ++v) {
       const int slot = ring.acquire<false>();
-      if (active) {
+      {   // (waves without rows in the last pass compute on row 0's data: no branch around the MFMA stream)
         const float* st = smem + slot * RC_STAGE_FLOATS;
         rc_f32x4 w0n = *reinterpret_cast<const rc_f32x4*>(st + fo.b[0]);
         rc_f32x4 w1n = *reinterpret_cast<const rc_f32x4*>(st + fo.b[0] + 16 * 128);
@@ -223,6 +244,7 @@ __device__ __forceinline__ void rc_pair(const rc_f32x4 (&xin)[16], rc_f32x4 (&xo
           RC_PIN();
           const rc_f32x4 x = mid[kt];
           RC_MFMA8(w0, w1, x, xout[4 * v + 2 * tp], xout[4 * v + 2 * tp + 1])
+          RC_FETCH_AT(ring, step)
         }
       }
     }
@@ -412,7 +434,7 @@ __global__ __launch_bounds__(RC_THREADS, 2) void sa_premul_chain_kernel(const Sc
     for (int st8 = 0; st8 < 8; ++st8) {
       rc_f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
       const int slot = ring.acquire<false>();
-      if (active) {
+      {   // (waves without rows in the last pass compute on row 0's data: no branch around the MFMA stream)
         const float* st = smem + slot * RC_STAGE_FLOATS;
         rc_f32x4 w0n = *reinterpret_cast<const rc_f32x4*>(st + fo.a[0]);
         rc_f32x4 w1n = *reinterpret_cast<const rc_f32x4*>(st + fo.a[0] + 16 * 256);
@@ -427,6 +449,7 @@ __global__ __launch_bounds__(RC_THREADS, 2) void sa_premul_chain_kernel(const Sc
           RC_PIN();
           const rc_f32x4 x = x0[kt];
           RC_MFMA8(w0, w1, x, acc0, acc1)
+          RC_FETCH_AT(ring, kt)
         }
       }
       const float* a = aff + 32 * st8 + g4;
@@ -443,7 +466,7 @@ __global__ __launch_bounds__(RC_THREADS, 2) void sa_premul_chain_kernel(const Sc
     for (int s3 = 0; s3 < 16; ++s3) {
       rc_f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
       const int slot = ring.acquire<false>();
-      if (active) {
+      {   // (waves without rows in the last pass compute on row 0's data: no branch around the MFMA stream)
         const float* st = smem + slot * RC_STAGE_FLOATS;
         rc_f32x4 w0n = *reinterpret_cast<const rc_f32x4*>(st + fo.a[0]);
         rc_f32x4 w1n = *reinterpret_cast<const rc_f32x4*>(st + fo.a[0] + 16 * 256);
@@ -458,6 +481,7 @@ __global__ __launch_bounds__(RC_THREADS, 2) void sa_premul_chain_kernel(const Sc
           RC_PIN();
           const rc_f32x4 x = x1[kt];
           RC_MFMA8_T(w0, w1, x, acc0, acc1)
+          RC_FETCH_AT(ring, kt)
         }
         // folded BN affine (+ ReLU) per channel (32 s3 + 16 t + j), max over this wave's 16 points: registers, then lane groups
         const float sc0 = aff[512 + 32 * s3 + j], sc1 = aff[512 + 32 * s3 + 16 + j];
