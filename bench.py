@@ -159,7 +159,7 @@ def _mlp_layer_kernel(d):
     round-1 kernel, everything else gemm2_kernel -- 256 x 128 tiles (pooling or not) or 128 x 128."""
     P, K, N = d.get("P", 0), d.get("K", 0), d.get("N", 0)
     if P <= 1024 or K < 17:
-        return "mlp_gemm_kernel"
+        return "mlp_gemm_kernel<0>"
     nt = (N + 127) // 128
     t256, t128, kpad = ((P + 255) // 256) * nt, ((P + 127) // 128) * nt, (K + 15) // 16 * 16
     if N > 128 and (t256 >= 512 or (t256 >= 256 and kpad >= 1024)):
@@ -173,7 +173,7 @@ def _mlp_layer_kernel(d):
 
 KERNEL_OF = {"native_fwd": "tgemm_kernel", "native_dgrad": "tgemm_kernel", "native_wgrad": "tgemm_kernel",
              "mlp_layer": _mlp_layer_kernel, "sa_layer1": "mlp_gemm_kernel", "sa_layer12": "mlp_gemm_kernel",
-             "sa_premul_layer": "mlp_gemm_kernel", "sa_chain3": "sa_chain_kernel", "fp_head_chain": "fp_head_chain_kernel", "sa_premul_chain": "sa_premul_chain_kernel",
+             "sa_premul_layer": "mlp_gemm_kernel<3>", "sa_chain3": "sa_chain_kernel", "fp_head_chain": "fp_head_chain_kernel", "sa_premul_chain": "sa_premul_chain_kernel",
              "farthest_point_sample": "fps_kernel", "ball_query": "ball_query_kernel",
              "point_search": "three_nn_kernel", "radius_candidates": "radius_group_kernel",
              "box_candidates": "box_crop_kernel", "gather_max": "gather_max_kernel"}
@@ -352,7 +352,11 @@ def roofline_of(agg, steps, batch):
     # dominant = most GPU resource-time: a furthest-point-sampling launch keeps ONE CU per
     # scene busy (a latency chain running beside the MLPs), every other kernel fills the chip
     def cu_ms(k):
-        return fam[k]["ms"] * (min(1.0, batch / 256.0) if k == "fps_kernel" else 1.0)
+        if k == "fps_kernel":
+            return fam[k]["ms"] * min(1.0, batch / 256.0)
+        if k == "mlp_gemm_kernel<0>":   # the skinny split-K launches of the region heads: at most 256 of the chip's 1024
+            return fam[k]["ms"] * 0.25  # workgroup slots, on the region stream (their event time is mostly queueing)
+        return fam[k]["ms"]
     dom = max(fam, key=cu_ms)
     f = fam[dom]
     avg_s = f["ms"] / f["launches"] / 1e3

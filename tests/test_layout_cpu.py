@@ -100,8 +100,8 @@ def test_bench_kernel_names_follow_the_tile_table():
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
     k = bench._mlp_layer_kernel
-    assert k({"P": 512, "K": 1024, "N": 256}) == "mlp_gemm_kernel"             # skinny: split-K heads
-    assert k({"P": 8192, "K": 3, "N": 256}) == "mlp_gemm_kernel"                # Kpad < 32
+    assert k({"P": 512, "K": 1024, "N": 256}) == "mlp_gemm_kernel<0>"          # skinny: split-K heads
+    assert k({"P": 8192, "K": 3, "N": 256}) == "mlp_gemm_kernel<0>"             # Kpad < 32
     assert k({"P": 131072, "K": 512, "N": 1024, "pool": 64}) == "gemm2_kernel<256,128,pool>"
     assert k({"P": 40960, "K": 512, "N": 512}) == "gemm2_kernel<256,128>"
     assert k({"P": 8192, "K": 1024, "N": 1024}) == "gemm2_kernel<256,128>"      # one tile per CU, long K
