@@ -383,6 +383,9 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
+        # one process per GPU on one host: keep each rank's CPU-side helpers (torch intra-op pool, OpenMP) to its share
+        # of the cores, so that N ranks' region-stage host threads do not fight over them
+        torch.set_num_threads(max(1, (os.cpu_count() or world) // (2 * world)))
         sharding.init("nccl", dev)   # RCCL; used only for the barrier + max-over-ranks of the contract
     if args.train:
         run_train(args, rank, world, dev)
