@@ -39,6 +39,10 @@ typedef float rc_f32x4 __attribute__((ext_vector_type(4)));
 #define RC_STAGES (RC_WAVES == 8 ? 3 : 2)      // ring depth (two workgroups per CU: 2 x 2 x 32 KiB)
 #endif
 #define RC_PIECES (32 / RC_WAVES)              // 1 KiB LDS-DMA pieces per wave per stage
+#ifndef RC_TAIL_HALF
+#define RC_TAIL_HALF 0                         // 1: the last 128 blocks of a launch are handed out as half blocks (waves 0-3;
+                                               // measured SLOWER inside the pipeline: 1.74-1.83 vs 1.65-1.67 ms, A/B on one box)
+#endif
 #ifndef RC_SPREAD_FETCH
 #define RC_SPREAD_FETCH 0                      // 1: a stage's LDS-DMA pieces are issued between its MFMA steps (measured 2 %
                                                // SLOWER per kernel, same step time); 0: all right behind the barrier
@@ -57,7 +61,8 @@ struct RcArgs {
   const float* wscore;                         // conv_score weight (128)
   float score_bias, score_bn_scale, score_bn_shift;
   int* ticket;                                 // work queue head (zeroed by the caller before the launch)
-  long long n_blocks;                          // 128-row blocks = passes to hand out
+  long long n_blocks;                          // tickets to hand out: n_full whole blocks (8 waves) + half blocks (waves 0-3)
+  long long n_full;                            // tickets < n_full are whole blocks; ticket t >= n_full: half block t - n_full
 };
 
 __device__ __forceinline__ void rc_glds16(const float* gsrc, unsigned lds_dst) {
@@ -304,8 +309,11 @@ __global__ __launch_bounds__(RC_THREADS, 2) void fp_head_chain_kernel(const RcAr
       for (int d = 0; d < RC_STAGES - 1; ++d) ring.fetch();
       primed = true;
     }
-    const long long unit = blk * RC_WAVES + wave;
-    const bool active = unit < units_total;                    // wave-uniform
+    // whole block: 8 waves x 16 rows; half block (the last round's worth of rows, so that the launch's tail is made of
+    // half-length passes): waves 0-3 only -- one wave per SIMD, which then has the matrix pipe to itself
+    const bool half = blk >= p.n_full;
+    const long long unit = half ? p.n_full * RC_WAVES + (blk - p.n_full) * (RC_WAVES / 2) + wave : blk * RC_WAVES + wave;
+    const bool active = unit < units_total && !(half && wave >= RC_WAVES / 2);   // wave-uniform
     long long row = unit * 16 + j;
     const bool row_ok = active && row < p.P;
     if (!row_ok) row = 0;
@@ -367,7 +375,7 @@ struct ScArgs {
   const float* affine; int affine_floats;        // [scale2(256) | shift2(256) | scale3(512) | shift3(512)]
   int relu3;
   float* out; long long ldo;                     // (groups, 512)
-  int* ticket; long long n_blocks;
+  int* ticket; long long n_blocks, n_full;     // as RcArgs: whole blocks first, then half blocks
 };
 
 __global__ __launch_bounds__(RC_THREADS, 2) void sa_premul_chain_kernel(const ScArgs p) {
@@ -403,8 +411,10 @@ __global__ __launch_bounds__(RC_THREADS, 2) void sa_premul_chain_kernel(const Sc
       for (int d = 0; d < RC_STAGES - 1; ++d) ring.fetch();
       primed = true;
     }
-    const long long grp = blk * (RC_WAVES / 4) + (wave >> 2);  // this wave's neighbourhood
-    const bool active = grp < p.groups;                        // wave-uniform
+    const bool half = blk >= p.n_full;                         // half block: one neighbourhood on waves 0-3
+    const long long grp0 = half ? p.n_full * (RC_WAVES / 4) + (blk - p.n_full) * (RC_WAVES / 8) : blk * (RC_WAVES / 4);
+    const long long grp = grp0 + (wave >> 2);                  // this wave's neighbourhood
+    const bool active = grp < p.groups && !(half && wave >= RC_WAVES / 2);   // wave-uniform
     const long long gs = active ? grp : 0;
     // ---- layer-1 rows of this wave's 16 points
     rc_f32x4 x0[16];
@@ -505,8 +515,8 @@ __global__ __launch_bounds__(RC_THREADS, 2) void sa_premul_chain_kernel(const Sc
     __syncthreads();
 #pragma unroll
     for (int n = 0; n < RC_WAVES / 4; ++n) {
-      const long long gn = blk * (RC_WAVES / 4) + n;
-      if (gn < p.groups)
+      const long long gn = grp0 + n;
+      if (gn < p.groups && !(half && n >= RC_WAVES / 8))
         for (int c = tid; c < 512; c += RC_THREADS) {
           const float* q = pool + (4 * n) * 512 + c;
           p.out[gn * p.ldo + c] = fmaxf(fmaxf(q[0], q[512]), fmaxf(q[1024], q[1536]));
@@ -548,7 +558,14 @@ extern "C" int regnet_sa_premul_chain_f32(const float* U, int64_t ldu, const flo
   a.U = U; a.ldu = ldu; a.scene_stride = Nsrc * ldu; a.V = V; a.ldv = ldv; a.nbr = (const long long*)nbr;
   a.groups = groups; a.groups_per_scene = M; a.stream = stream; a.n_stages = (int)n_stages;
   a.affine = affine; a.affine_floats = (int)affine_floats; a.relu3 = relu3; a.out = out; a.ldo = ldo;
-  a.ticket = ticket; a.n_blocks = (groups + RC_WAVES / 4 - 1) / (RC_WAVES / 4);
+  {   // the last ~half round of blocks is handed out as half blocks (see the kernel)
+    const long long gpb = RC_WAVES / 4, blocks = (groups + gpb - 1) / gpb;
+    const long long split = (RC_WAVES == 8 && RC_TAIL_HALF) ? (blocks < 128 ? blocks : 128) : 0;
+    a.n_full = blocks - split;
+    const long long rest = groups - a.n_full * gpb;            // neighbourhoods left for half blocks (one each)
+    a.n_blocks = a.n_full + (rest > 0 ? rest : 0);
+  }
+  a.ticket = ticket;
   const int cus = 256 * RC_WG_PER_CU;
   const long long wgs = a.n_blocks < cus ? a.n_blocks : cus;
   const size_t lds = (size_t)(RC_STAGES * RC_STAGE_FLOATS + 1536 + RC_WAVES * 512 + 4) * sizeof(float);
@@ -576,7 +593,13 @@ extern "C" int regnet_fp_head_chain_f32(const float* X, int64_t ldx, const float
   a.stream = stream; a.n_stages = (int)n_stages; a.affine = affine; a.affine_floats = (int)affine_floats;
   a.wscore = wscore; a.score_bias = score_bias; a.score_bn_scale = score_bn_scale; a.score_bn_shift = score_bn_shift;
   a.ticket = ticket;
-  a.n_blocks = (P + 16 * RC_WAVES - 1) / (16 * RC_WAVES);
+  {
+    const long long units = (P + 15) / 16, blocks = (units + RC_WAVES - 1) / RC_WAVES;
+    const long long split = (RC_WAVES == 8 && RC_TAIL_HALF) ? (blocks < 128 ? blocks : 128) : 0;
+    a.n_full = blocks - split;
+    const long long rest = units - a.n_full * RC_WAVES;        // 16-row units left for half blocks (4 each)
+    a.n_blocks = a.n_full + (rest > 0 ? (rest + RC_WAVES / 2 - 1) / (RC_WAVES / 2) : 0);
+  }
   const int cus = 256 * RC_WG_PER_CU;
   const long long wgs = a.n_blocks < cus ? a.n_blocks : cus;
   const size_t lds = (size_t)(RC_STAGES * RC_STAGE_FLOATS + RC_AFFINE_MAX + 128 + 4) * sizeof(float);
