@@ -241,6 +241,21 @@ int regnet_grasp_antipodal_stats_f32(const float* points, int64_t pn, int64_t pc
                                      const float* x_hi_per_grasp, float half_thickness, float half_width, float half_space,
                                      float back_x, float neighbour_depth, float* stats, int32_t* side_counts, void* stream);
 
+/* regnet_estimate_normals_f32: surface normals of a scene cloud for validation records that carry no scene_normal --
+ * dataset_utils/eval_score/eval_utils/torch_scene_point_cloud.py:17-19 -> eval_utils/pointcloud.py:27-43, i.e. open3d's
+ * estimate_normals(KDTreeSearchParamHybrid(radius = NORMAL_RADIUS, max_nn = NORMAL_MAX_NN)), normalize_normals and
+ * orient_normals_towards_camera_location (configs/config.py:16-17).  open3d is a dependency outside the reference tree
+ * (absent from this image: parity unpinned, see oracle/collision_oracle.py); the algorithm restated is its published one:
+ * neighbours of point i = the max_nn nearest points (itself included) with squared distance -- double,
+ * ((dx*dx)+(dy*dy))+(dz*dz) -- strictly below float(radius*radius), ties ranked by index; fewer than 3 neighbours ->
+ * (0,0,1); otherwise the eigenvector of the smallest eigenvalue of the neighbours' covariance (second moments / n -
+ * mean products, double), a zero vector replaced by (0,0,1); normalised; negated when it points away from the camera
+ * (normal . (camera - point) < 0).  xyz (N,3) contiguous float32, normals (N,3) float32, count (N) int32 = neighbours
+ * used (may be NULL).  workspace: regnet_normals_workspace_bytes(N) bytes, 16-byte aligned.  max_nn <= 64.             */
+int64_t regnet_normals_workspace_bytes(int64_t N);
+int regnet_estimate_normals_f32(const float* xyz, int64_t N, double radius, int64_t max_nn, double cam_x, double cam_y,
+                                double cam_z, float* normals, int32_t* count, void* workspace, void* stream);
+
 /* regnet_bn_relu_train_fwd_f32 / _bwd_f32: TRAINING-mode BatchNorm (+ ReLU, + max over the K neighbours) of a shared-MLP
  * block -- nn/modules/conv.py:30-36, :70-76 (bn then relu after the bias-free 1x1 convolution) and the set-abstraction
  * reduction torch.max(new_feature, 3) of modules.py:245 -- as two HBM passes each way instead of torch's 13-18.

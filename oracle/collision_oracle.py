@@ -11,7 +11,15 @@ Constants: eval_score/configs/config.py.  Citations are relative to /root/refere
 
 The VIEW cloud's estimated normals (open3d, :77-80 / :261-262), the kd-trees (:260, torch_scene_point_cloud.py:24) and
 the table-corner tests (:172-186 / :374-386, results unused) do not influence anything these functions return and are
-not restated; the SCENE cloud's normals are taken from the record (``scene_normal``, torch_scene_point_cloud.py:13-16).
+not restated; the SCENE cloud's normals are taken from the record (``scene_normal``, torch_scene_point_cloud.py:13-16)
+or, for records without them, estimated by ``estimate_normals`` (torch_scene_point_cloud.py:17-19 ->
+eval_utils/pointcloud.py:27-43).  That function calls open3d (``estimate_normals`` with ``KDTreeSearchParamHybrid``,
+``normalize_normals``, ``orient_normals_towards_camera_location``), a dependency that is NOT in the reference tree and
+not in this image (the reference pins no version; the method-style API it calls exists from open3d 0.8): PARITY UNPINNED
+for ``estimate_normals`` -- it restates open3d's published algorithm (FLANN radius search with the squared radius
+passed as a float and capped at max_nn nearest, covariance from the raw second moments in double, smallest-eigenvalue
+eigenvector of a self-adjoint solver, (0,0,1) for fewer than three neighbours or a zero vector, flip towards the
+camera) and is anchored only by known-answer surfaces (planes, spheres, isolated points) in tests/.
 
 Canonical arithmetic of the point transform, shared with csrc/region.hip:grasp_collision_kernel: individually rounded
 binary32 operations in source order, ``x = ((t00*px + t01*py) + t02*pz) + t03`` (the reference's 4xN torch.matmul goes
@@ -193,3 +201,50 @@ def eval_validate(data, predicted_grasp, view_num, table_height, depth, width, g
         score[ok] = antipodal_scores(scene_pts, np.asarray(data["scene_normal"], dtype=np.float32), Tv[ok], dvo, width)
     grasp_view = grasp[torch.from_numpy(keep_view)]
     return int(ok.sum()), float(torch.from_numpy(score).sum().item()), len(keep_view), grasp_view, grasp_view[torch.from_numpy(np.nonzero(ok)[0])]
+
+
+NORMAL_RADIUS = 0.01           # eval_score/configs/config.py:16-17
+NORMAL_MAX_NN = 30
+
+
+def estimate_normals(points, camera_pos=(0.0, 0.0, 0.0), radius=NORMAL_RADIUS, max_nn=NORMAL_MAX_NN, chunk=512,
+                     return_gap=False):
+    """eval_utils/pointcloud.py:27-43 (see the header: open3d's algorithm restated, parity unpinned).
+    points (N,3) -> (normals (N,3) float64 unit vectors facing the camera, neighbour counts (N,)).
+    Brute force: every point against every point, squared distances in double in the order ((dx*dx)+(dy*dy))+(dz*dz),
+    neighbours = those strictly below float(radius*radius), nearest ``max_nn`` ranked by (distance, index).
+    ``return_gap`` adds (lambda_1 - lambda_0) / lambda_2 per point (0 where the normal is not an eigenvector): how well
+    the smallest-eigenvalue direction is determined."""
+    p = np.asarray(points, dtype=np.float32).astype(np.float64)     # the product path holds float32 coordinates
+    N = p.shape[0]
+    r2 = float(np.float32(float(radius) * float(radius)))
+    cam = np.asarray(camera_pos, dtype=np.float64)
+    normals = np.zeros((N, 3))
+    counts = np.zeros((N,), dtype=np.int64)
+    gap = np.zeros((N,))
+    for beg in range(0, N, chunk):
+        q = p[beg:beg + chunk]
+        dx = p[None, :, 0] - q[:, None, 0]
+        dy = p[None, :, 1] - q[:, None, 1]
+        dz = p[None, :, 2] - q[:, None, 2]
+        d2 = ((dx * dx) + (dy * dy)) + (dz * dz)
+        for r in range(q.shape[0]):
+            idx = np.nonzero(d2[r] < r2)[0]
+            if idx.size > max_nn:
+                idx = idx[np.lexsort((idx, d2[r, idx]))[:max_nn]]
+            counts[beg + r] = idx.size
+            n = np.array([0.0, 0.0, 1.0])
+            if idx.size >= 3:
+                nb = p[idx]
+                mean = nb.mean(axis=0)
+                cov = nb.T @ nb / idx.size - np.outer(mean, mean)      # raw second moments minus mean products
+                w, v = np.linalg.eigh(cov)
+                n = v[:, 0].copy()
+                gap[beg + r] = (w[1] - w[0]) / w[2] if w[2] > 0 else 0.0
+                if not n.any():
+                    n = np.array([0.0, 0.0, 1.0])
+            n = n / np.linalg.norm(n)
+            if n @ (cam - q[r]) < 0:
+                n = -n
+            normals[beg + r] = n
+    return (normals, counts, gap) if return_gap else (normals, counts)

@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("REGNET_HIP_LIB") or os.path.join(_HERE, "csrc", "libregnet_hip.so")   # override: A/B builds only
 
-_i64, _f32, _vp, _int = ctypes.c_int64, ctypes.c_float, ctypes.c_void_p, ctypes.c_int
+_i64, _f32, _f64, _vp, _int = ctypes.c_int64, ctypes.c_float, ctypes.c_double, ctypes.c_void_p, ctypes.c_int
 
 # name -> (restype, argtypes); mirrors include/regnet_hip.h one to one.
 SIGNATURES = {
@@ -52,6 +52,8 @@ SIGNATURES = {
                                                  _vp, _vp]),
     "regnet_grasp_antipodal_stats_f32": (_int, [_vp, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _i64, _f32, _f32, _vp, _f32,
                                                 _f32, _f32, _f32, _f32, _vp, _vp, _vp]),
+    "regnet_normals_workspace_bytes": (_i64, [_i64]),
+    "regnet_estimate_normals_f32": (_int, [_vp, _i64, _f64, _i64, _f64, _f64, _f64, _vp, _vp, _vp, _vp]),
     "regnet_bn_workspace_bytes": (_i64, [_i64]),
     "regnet_bn_relu_train_fwd_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _f32, _f32, _vp, _vp, _int, _i64, _vp, _vp, _vp,
                                             _vp, _vp, _vp]),

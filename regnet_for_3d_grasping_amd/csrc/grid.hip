@@ -356,6 +356,200 @@ __global__ __launch_bounds__(256) void ball_query_grid_kernel(const float* __res
   if (lane == 0) count[(int64_t)b * N2 + c] = cnt;
 }
 
+// ---- surface normals over the grid ----------------------------------------------------------------------
+// Reference: dataset_utils/eval_score/eval_utils/pointcloud.py:27-43 -- open3d's estimate_normals with
+// KDTreeSearchParamHybrid(radius, max_nn), normalize_normals, orient_normals_towards_camera_location.  open3d is not
+// part of the reference tree; the restated algorithm is its documented one: neighbours = the max_nn nearest points
+// with squared distance (double, ((dx*dx)+(dy*dy))+(dz*dz)) < float(radius*radius), the query point included;
+// fewer than 3 -> normal (0,0,1); else the eigenvector of the neighbours' covariance with the smallest eigenvalue;
+// a zero vector becomes (0,0,1); the result is normalised and flipped to face the camera.
+//
+// normal_cov_kernel: a wave owns one point, visits the cells overlapping its ball, keeps the 64 nearest
+// (distance, index) pairs with the same 128-wide bitonic merge as the ball query (pairs instead of bare indices) and
+// reduces the second moments of the first max_nn of them, taken relative to the query point, in double.
+// normal_eigen_kernel: a thread per point diagonalises the 3x3 covariance with cyclic Jacobi rotations in double.
+struct NnKey {
+  unsigned long long d;   // bit pattern of the non-negative double squared distance (orders like the value)
+  unsigned j;             // original index: ties rank by index, so the selection does not depend on the cell order
+};
+__device__ __forceinline__ bool nn_less(const NnKey& a, const NnKey& b) { return a.d < b.d || (a.d == b.d && a.j < b.j); }
+__device__ __forceinline__ NnKey nn_shfl_xor(const NnKey& a, int m) {
+  NnKey r;
+  r.d = __shfl_xor(a.d, m, 64);
+  r.j = __shfl_xor(a.j, m, 64);
+  return r;
+}
+__device__ __forceinline__ void nn_bitonic128_keep64(NnKey& best, NnKey& pend, int lane) {
+#pragma unroll
+  for (int k = 2; k <= 128; k <<= 1) {
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      if (j == 64) {
+        if (nn_less(pend, best)) { const NnKey t = best; best = pend; pend = t; }
+      } else {
+        const NnKey ob = nn_shfl_xor(best, j), op = nn_shfl_xor(pend, j);
+        const bool lower = (lane & j) == 0;
+        const bool up_b = (lane & k) == 0;
+        const bool up_p = ((64 + lane) & k) == 0;
+        const bool take_min_b = lower == up_b, take_min_p = lower == up_p;
+        if (take_min_b ? nn_less(ob, best) : nn_less(best, ob)) best = ob;
+        if (take_min_p ? nn_less(op, pend) : nn_less(pend, op)) pend = op;
+      }
+    }
+  }
+}
+
+#define NN_EMPTY 0xffffffffffffffffull
+
+__global__ __launch_bounds__(256) void normal_cov_kernel(const float* __restrict__ xyz, int N, double r2, float radius,
+                                                         int max_nn, const char* __restrict__ ws,
+                                                         double* __restrict__ cov, int* __restrict__ count) {
+  __shared__ NnKey pendbuf[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = blockIdx.x * 4 + wave;
+  if (i >= N) return;   // wave-uniform
+  const GridHeader H = *reinterpret_cast<const GridHeader*>(ws);
+  const int* cell_start = grid_cell_start(const_cast<char*>(ws));
+  const float4* sorted = grid_sorted(const_cast<char*>(ws));
+  const float qx = xyz[(int64_t)i * 3], qy = xyz[(int64_t)i * 3 + 1], qz = xyz[(int64_t)i * 3 + 2];
+  const float pad = radius * 1.0001f + H.eps + 4e-6f * fmaxf(fmaxf(fabsf(qx), fabsf(qy)), fabsf(qz));
+  const int x0 = cell_coord(qx - pad, H.lo[0], H.inv_h, H.dim[0]), x1 = cell_coord(qx + pad, H.lo[0], H.inv_h, H.dim[0]);
+  const int y0 = cell_coord(qy - pad, H.lo[1], H.inv_h, H.dim[1]), y1 = cell_coord(qy + pad, H.lo[1], H.inv_h, H.dim[1]);
+  const int z0 = cell_coord(qz - pad, H.lo[2], H.inv_h, H.dim[2]), z1 = cell_coord(qz + pad, H.lo[2], H.inv_h, H.dim[2]);
+  NnKey best;
+  best.d = NN_EMPTY; best.j = 0xffffffffu;
+  int npend = 0, total = 0;
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  NnKey* row_buf = pendbuf[wave];
+  for (int z = z0; z <= z1; ++z)
+    for (int y = y0; y <= y1; ++y) {
+      const int row = (z * H.dim[1] + y) * H.dim[0];
+      const int beg = cell_start[row + x0], end = cell_start[row + x1 + 1];
+      for (int k0 = beg; k0 < end; k0 += 64) {
+        const int k = k0 + lane;
+        bool hit = false;
+        NnKey key;
+        key.d = NN_EMPTY; key.j = 0xffffffffu;
+        if (k < end) {
+          const float4 p = sorted[k];
+          const double dx = (double)p.x - (double)qx, dy = (double)p.y - (double)qy, dz = (double)p.z - (double)qz;
+          const double d2 = ((dx * dx) + (dy * dy)) + (dz * dz);
+          hit = d2 < r2;
+          key.d = (unsigned long long)__double_as_longlong(d2);
+          key.j = (unsigned)__float_as_int(p.w);
+        }
+        const unsigned long long mask = __ballot(hit);
+        if (mask == 0ull) continue;
+        const int nh = (int)__popcll(mask);
+        const int rank = (int)__popcll(mask & lt_mask);
+        const int room = 64 - npend;
+        if (hit && rank < room) row_buf[npend + rank] = key;
+        if (nh >= room) {
+          NnKey pend = row_buf[lane];
+          nn_bitonic128_keep64(best, pend, lane);
+          if (hit && rank >= room) row_buf[rank - room] = key;
+          npend = nh - room;
+        } else {
+          npend += nh;
+        }
+        total += nh;
+      }
+    }
+  if (npend > 0) {
+    NnKey pend;
+    pend.d = NN_EMPTY; pend.j = 0xffffffffu;
+    if (lane < npend) pend = row_buf[lane];
+    nn_bitonic128_keep64(best, pend, lane);
+  }
+  // lane l holds the l-th nearest neighbour; the first `cnt` lanes contribute
+  const int cnt = min(total, max_nn);
+  double s[9] = {0., 0., 0., 0., 0., 0., 0., 0., 0.};
+  if (lane < cnt) {
+    const int64_t j = (int64_t)best.j;
+    const double dx = (double)xyz[j * 3] - (double)qx, dy = (double)xyz[j * 3 + 1] - (double)qy,
+                 dz = (double)xyz[j * 3 + 2] - (double)qz;
+    s[0] = dx; s[1] = dy; s[2] = dz;
+    s[3] = dx * dx; s[4] = dx * dy; s[5] = dx * dz; s[6] = dy * dy; s[7] = dy * dz; s[8] = dz * dz;
+  }
+#pragma unroll
+  for (int a = 0; a < 9; ++a) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s[a] += __shfl_xor(s[a], off, 64);
+  }
+  if (lane == 0) {
+    count[i] = cnt;
+    double* c = cov + (int64_t)i * 6;
+    if (cnt > 0) {
+      const double inv = 1.0 / (double)cnt;
+      const double mx = s[0] * inv, my = s[1] * inv, mz = s[2] * inv;
+      c[0] = s[3] * inv - mx * mx; c[1] = s[4] * inv - mx * my; c[2] = s[5] * inv - mx * mz;
+      c[3] = s[6] * inv - my * my; c[4] = s[7] * inv - my * mz; c[5] = s[8] * inv - mz * mz;
+    } else {
+      c[0] = c[1] = c[2] = c[3] = c[4] = c[5] = 0.;
+    }
+  }
+}
+
+// Eigenvector of the smallest eigenvalue of the symmetric matrix [[a0,a1,a2],[a1,a3,a4],[a2,a4,a5]]: cyclic Jacobi.
+// A zero matrix returns (1,0,0) (the first column of the identity, what a QR-based solver leaves untouched).
+__device__ inline void sym3_min_eigenvector(const double* a, double* n) {
+  double A[3][3] = {{a[0], a[1], a[2]}, {a[1], a[3], a[4]}, {a[2], a[4], a[5]}};
+  double V[3][3] = {{1., 0., 0.}, {0., 1., 0.}, {0., 0., 1.}};
+  for (int sweep = 0; sweep < 12; ++sweep) {
+    const double off = fabs(A[0][1]) + fabs(A[0][2]) + fabs(A[1][2]);
+    const double diag = fabs(A[0][0]) + fabs(A[1][1]) + fabs(A[2][2]);
+    if (off == 0. || off <= 1e-300 + 1e-22 * diag) break;
+#pragma unroll
+    for (int pq = 0; pq < 3; ++pq) {
+      const int p = pq == 2 ? 1 : 0, q = pq == 0 ? 1 : 2;
+      const double apq = A[p][q];
+      if (apq == 0.) continue;
+      const double theta = (A[q][q] - A[p][p]) / (2. * apq);
+      const double t = (theta >= 0. ? 1. : -1.) / (fabs(theta) + sqrt(theta * theta + 1.));
+      const double c = 1. / sqrt(t * t + 1.), sn = t * c;
+      const int r = 3 - p - q;
+      const double app = A[p][p], aqq = A[q][q], arp = A[r][p], arq = A[r][q];
+      A[p][p] = app - t * apq;
+      A[q][q] = aqq + t * apq;
+      A[p][q] = A[q][p] = 0.;
+      A[r][p] = A[p][r] = c * arp - sn * arq;
+      A[r][q] = A[q][r] = sn * arp + c * arq;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const double vkp = V[k][p], vkq = V[k][q];
+        V[k][p] = c * vkp - sn * vkq;
+        V[k][q] = sn * vkp + c * vkq;
+      }
+    }
+  }
+  int m = 0;
+  if (A[1][1] < A[m][m]) m = 1;
+  if (A[2][2] < A[m][m]) m = 2;
+  n[0] = m == 0 ? V[0][0] : (m == 1 ? V[0][1] : V[0][2]);
+  n[1] = m == 0 ? V[1][0] : (m == 1 ? V[1][1] : V[1][2]);
+  n[2] = m == 0 ? V[2][0] : (m == 1 ? V[2][1] : V[2][2]);
+}
+
+__global__ __launch_bounds__(256) void normal_eigen_kernel(const float* __restrict__ xyz, int N,
+                                                           const double* __restrict__ cov, const int* __restrict__ count,
+                                                           double cx, double cy, double cz, float* __restrict__ normals) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  double n[3] = {0., 0., 1.};
+  if (count[i] >= 3) {
+    sym3_min_eigenvector(cov + (int64_t)i * 6, n);
+    if (n[0] == 0. && n[1] == 0. && n[2] == 0.) { n[2] = 1.; }
+  }
+  double len = sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+  if (len > 0.) { n[0] /= len; n[1] /= len; n[2] /= len; }
+  const double rx = cx - (double)xyz[(int64_t)i * 3], ry = cy - (double)xyz[(int64_t)i * 3 + 1],
+               rz = cz - (double)xyz[(int64_t)i * 3 + 2];
+  if (n[0] * rx + n[1] * ry + n[2] * rz < 0.) { n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; }
+  normals[(int64_t)i * 3] = (float)n[0];
+  normals[(int64_t)i * 3 + 1] = (float)n[1];
+  normals[(int64_t)i * 3 + 2] = (float)n[2];
+}
+
 // ---- C ABI ------------------------------------------------------------------------------------------
 extern "C" int64_t regnet_grid_workspace_bytes(int64_t B, int64_t N) { return B * grid_slab_bytes(N); }
 
@@ -404,6 +598,33 @@ extern "C" int regnet_ball_query_grid_f32(const float* xyz, int64_t sb, int64_t 
   dim3 grid((unsigned)((N2 + 3) / 4), (unsigned)B);
   hipLaunchKernelGGL(ball_query_grid_kernel, grid, dim3(256), 0, st, centroids, cb, cc, cn, (int)N2, r2, radius, (int)K,
                      (const char*)workspace, grid_slab_bytes(N1), index, count);
+  REGNET_LAUNCH_CHECK();
+  return REGNET_OK;
+}
+
+extern "C" int64_t regnet_normals_workspace_bytes(int64_t N) {
+  const long long grid = (grid_slab_bytes(N) + 15) / 16 * 16;
+  return grid + N * 6 * 8ll + N * 4ll;
+}
+
+extern "C" int regnet_estimate_normals_f32(const float* xyz, int64_t N, double radius, int64_t max_nn, double cam_x,
+                                           double cam_y, double cam_z, float* normals, int32_t* count, void* workspace,
+                                           void* stream) {
+  if (N < 0 || max_nn <= 0) return REGNET_ERR_SHAPE;
+  if (max_nn > 64 || !(radius > 0.) || N >= (int64_t)1 << 31) return REGNET_ERR_UNSUPPORTED;
+  if (N == 0) return REGNET_OK;
+  if (!xyz || !normals || !workspace) return REGNET_ERR_NULL;
+  hipStream_t st = as_stream(stream);
+  int rc = build_grid(xyz, 0, 1, 3, 1, N, (float)radius, workspace, st);
+  if (rc) return rc;
+  const long long grid = (grid_slab_bytes(N) + 15) / 16 * 16;
+  double* cov = reinterpret_cast<double*>((char*)workspace + grid);
+  int* cnt = count ? count : reinterpret_cast<int*>((char*)workspace + grid + N * 6 * 8ll);
+  const double r2 = (double)(float)(radius * radius);   // the search takes the squared radius as a float
+  hipLaunchKernelGGL(normal_cov_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, st, xyz, (int)N, r2, (float)radius,
+                     (int)max_nn, (const char*)workspace, cov, cnt);
+  hipLaunchKernelGGL(normal_eigen_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, xyz, (int)N, cov, cnt, cam_x,
+                     cam_y, cam_z, normals);
   REGNET_LAUNCH_CHECK();
   return REGNET_OK;
 }

@@ -11,8 +11,9 @@ The reference loops over the grasps in Python (a 4xN matmul, five or six masks a
 for validation); here the grasp frames are computed batched with the reference's torch expressions and each pass is ONE
 kernel launch over all grasps (csrc/region.hip: grasp_collision_kernel, grasp_antipodal_kernel) followed by the
 reference's thresholds as tensor ops.  GPU only (the reference's ``gpu=-1`` CPU mode is not offered: there is no CPU
-fallback in this package).  Scene normals are taken from the record (``scene_normal``); estimating them (open3d in the
-reference, torch_scene_point_cloud.py:17-19) is outside this package.
+fallback in this package).  Scene normals are taken from the record (``scene_normal``); records without them get
+``estimate_normals`` (open3d's hybrid-search PCA normals in the reference, torch_scene_point_cloud.py:17-19 ->
+pointcloud.py:27-43; here a uniform-grid neighbour search + 3x3 eigen solve on the GPU, csrc/grid.hip).
 """
 import torch
 
@@ -32,6 +33,8 @@ BOTTOM_LENGTH = 0.06
 CLOSE_REGION_MIN_POINTS = 16
 NEIGHBOR_DEPTH = 0.005
 TABLE_MARGIN = 0.005   # evaluation_data_generator.py:195 (+, test flavour) and :428 (-, validation flavour)
+NORMAL_RADIUS = 0.01   # configs/config.py:16-17
+NORMAL_MAX_NN = 30
 
 
 def _unit_or(v, fallback):
@@ -154,15 +157,34 @@ def eval_test(points, predicted_grasp, view_num, table_height, depth, width, gpu
     return grasp[no_collision_mask(pts, grasp, table_height, depth, width)]
 
 
+def estimate_normals(points, camera_pos=(0.0, 0.0, 0.0), radius=NORMAL_RADIUS, max_nn=NORMAL_MAX_NN, return_count=False):
+    """PointCloud.estimate_normals (pointcloud.py:27-43): unit normals (N,3) float32 of the cloud ``points`` (N,3) on the
+    GPU -- for every point the eigenvector of the smallest eigenvalue of the covariance of its ``max_nn`` nearest
+    neighbours within ``radius`` (itself included; (0,0,1) when fewer than 3), facing ``camera_pos``."""
+    if not points.is_cuda:
+        raise RuntimeError("estimate_normals: points must be on the GPU (no CPU fallback)")
+    pts = points.float().contiguous()
+    if pts.dim() != 2 or pts.shape[1] != 3:
+        raise ValueError("estimate_normals: points must be (N,3)")
+    N = pts.shape[0]
+    cam = [float(c) for c in camera_pos]
+    with torch.cuda.device(pts.device):
+        normals = torch.empty((N, 3), dtype=torch.float32, device=pts.device)
+        count = torch.empty((N,), dtype=torch.int32, device=pts.device)
+        ws = torch.empty((max(int(_L.regnet_normals_workspace_bytes(N)), 16),), dtype=torch.uint8, device=pts.device)
+        _check(_L.regnet_estimate_normals_f32(pts.data_ptr(), N, float(radius), int(max_nn), cam[0], cam[1], cam[2],
+                                              normals.data_ptr(), count.data_ptr(), ws.data_ptr(),
+                                              torch.cuda.current_stream(pts.device).cuda_stream), "estimate_normals")
+    return (normals, count) if return_count else normals
+
+
 def eval_validate(formal_dict, predicted_grasp, view_num, table_height, depth, width, gpu=0):
     """eval.py:14-24 / EvalDataValidate.run_collision (:352-366).  ``formal_dict``: a validation record with
-    ``view_cloud`` (N1,3), ``scene_cloud`` (N2,3) and ``scene_normal`` (N2,3); ``predicted_grasp`` (B,8) rows or (B,4,4)
-    frames.  -> (vgr, antipodal score sum, grasps without view collision (count), those grasps, the ones that also clear
+    ``view_cloud`` (N1,3), ``scene_cloud`` (N2,3) and optionally ``scene_normal`` (N2,3) (estimated from the scene
+    cloud when absent, torch_scene_point_cloud.py:13-19); ``predicted_grasp`` (B,8) rows or (B,4,4) frames.  -> (vgr, antipodal score sum, grasps without view collision (count), those grasps, the ones that also clear
     the scene cloud)."""
     if gpu == -1:
         raise RuntimeError("eval_validate: this package has no CPU mode (gpu=-1)")
-    if "scene_normal" not in formal_dict:
-        raise RuntimeError("eval_validate needs the record's scene_normal (normal estimation is outside this package)")
     dev = torch.device("cuda", int(gpu))
     grasp = torch.as_tensor(predicted_grasp).float().to(dev)
     if grasp.dim() == 3:                                                    # (B,4,4) frames (:273-275)
@@ -184,6 +206,10 @@ def eval_validate(formal_dict, predicted_grasp, view_num, table_height, depth, w
     dv = dep[keep_view] if isinstance(dep, torch.Tensor) else dep
     scene = torch.as_tensor(formal_dict["scene_cloud"]).float().to(dev)
     ok = _passes(collision_counts(scene, Tv, dv, width), True)
-    score = antipodal_scores(scene, torch.as_tensor(formal_dict["scene_normal"]).float().to(dev), Tv, dv, width)
+    if "scene_normal" in formal_dict:
+        normal = torch.as_tensor(formal_dict["scene_normal"]).float().to(dev)
+    else:
+        normal = estimate_normals(scene)
+    score = antipodal_scores(scene, normal, Tv, dv, width)
     score = torch.where(ok, score, torch.zeros_like(score))
     return int(ok.sum()), float(score.sum().item()), int(keep_view.numel()), grasp_view, grasp_view[torch.nonzero(ok).view(-1)]

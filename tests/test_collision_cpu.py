@@ -97,3 +97,42 @@ def test_antipodal_score_known_answer():
     s = co.antipodal_scores(pts, nrm, T, 0.06, 0.08)
     assert abs(float(s[0]) - 0.75 * 0.5) < 1e-6
     assert np.isnan(co.antipodal_scores(pts[-1:], nrm[-1:], T, 0.06, 0.08)[0])      # empty region
+
+
+# ---- normal estimation (eval_utils/pointcloud.py:27-43; open3d restated, parity unpinned: known answers only) -----------
+def _plane_cloud(rng, n, normal, offset, extent=0.04):
+    normal = np.asarray(normal, dtype=np.float64) / np.linalg.norm(normal)
+    a = np.cross(normal, [1.0, 0.3, -0.2]); a /= np.linalg.norm(a)
+    b = np.cross(normal, a)
+    uv = rng.uniform(-extent, extent, (n, 2))
+    return (offset * normal + uv[:, :1] * a + uv[:, 1:] * b).astype(np.float32)
+
+
+def test_normals_oracle_known_answers():
+    rng = np.random.default_rng(7)
+    # a tilted plane 0.6 m in front of the camera: every point with >= 3 neighbours gets the plane normal facing the origin
+    nrm = np.array([0.2, -0.3, 1.0]); nrm /= np.linalg.norm(nrm)
+    pts = _plane_cloud(rng, 1500, nrm, 0.6)
+    n, cnt = co.estimate_normals(pts)
+    ok = cnt >= 3
+    assert ok.sum() > 1400 and cnt.max() == 30                     # capped at max_nn
+    assert np.all(np.abs(n[ok] @ nrm + 1.0) < 1e-6)                # float32 coordinates: the plane is flat to ~1e-8 m
+    assert np.all(np.einsum("ij,ij->i", n, -pts.astype(np.float64)) >= 0)
+    # fewer than three neighbours: (0,0,1), flipped when the camera is below the point
+    lone = np.array([[0.0, 0.0, 0.5], [0.3, 0.0, -0.5], [0.3, 0.005, -0.5]], dtype=np.float32)
+    n, cnt = co.estimate_normals(lone)
+    assert cnt.tolist() == [1, 2, 2]
+    assert np.array_equal(n, [[0, 0, -1], [0, 0, 1], [0, 0, 1]])
+    # a sphere of radius 5 cm seen from outside: radial normals (neighbourhood of 1 cm -> a few degrees of curvature)
+    v = rng.normal(size=(6000, 3)); v /= np.linalg.norm(v, axis=1, keepdims=True)
+    centre = np.array([0.0, 0.0, 0.7])
+    sph = (centre + 0.05 * v).astype(np.float32)
+    n, cnt = co.estimate_normals(sph, camera_pos=centre + 10 * (sph[0] - centre))
+    ok = cnt >= 6
+    cosang = np.abs(np.einsum("ij,ij->i", n[ok], v[ok]))
+    assert ok.sum() > 5000 and np.percentile(cosang, 5) > 0.995
+    # duplicates only: zero covariance -> the solver's first basis vector, still a unit vector facing the camera
+    dup = np.repeat(np.array([[0.1, 0.1, 0.6]], dtype=np.float32), 5, axis=0)
+    n, cnt = co.estimate_normals(dup)
+    assert cnt.tolist() == [5] * 5 and np.allclose(np.linalg.norm(n, axis=1), 1.0)
+    assert np.all(n @ -dup[0].astype(np.float64) >= 0)

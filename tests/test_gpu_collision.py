@@ -101,3 +101,78 @@ def test_eval_validate_matches_reference_fixture_and_oracle(case):
     d2 = torch.linspace(0.03, 0.07, len(g))
     assert np.array_equal(ec.collision_counts(scene, T.to(DEV), d2, c["width"]).cpu().numpy(),
                           co.collision_counts(data["scene_cloud"], T.numpy(), d2.numpy(), c["width"]))
+
+
+# ---- normal estimation (eval_utils/pointcloud.py:27-43) ------------------------------------------------------------------
+def _check_normals(pts, camera=(0.0, 0.0, 0.0), radius=0.01, max_nn=30, min_well=0.5):
+    from regnet_for_3d_grasping_amd import eval_collision as ec
+    want, cnt_want, gap = co.estimate_normals(pts, camera, radius, max_nn, return_gap=True)
+    got, cnt = ec.estimate_normals(torch.from_numpy(pts).to(DEV), camera, radius, max_nn, return_count=True)
+    got, cnt = got.cpu().numpy().astype(np.float64), cnt.cpu().numpy()
+    assert np.array_equal(cnt, cnt_want)                                      # same neighbourhoods (exact arithmetic)
+    assert np.allclose(np.linalg.norm(got, axis=1), 1.0, atol=1e-6)
+    assert np.all(np.einsum("ij,ij->i", got, np.asarray(camera)[None] - pts.astype(np.float64)) >= -1e-7)
+    dot = np.einsum("ij,ij->i", got, want)
+    # the eigenvector is determined up to (rounding of the covariance) / (relative eigenvalue gap): the oracle forms the
+    # covariance from raw second moments of absolute coordinates like open3d (~1e-11 relative), the kernel from
+    # coordinates relative to the query point
+    well = gap > 1e-3
+    assert well.mean() >= min_well
+    assert np.all(dot[well] > 1 - 1e-6), float(dot[well].min())
+    fixed = cnt_want < 3
+    assert np.array_equal(got[fixed], want[fixed])
+    return cnt_want
+
+
+def test_normals_match_oracle_on_scene():
+    from regnet_for_3d_grasping_amd import synthetic
+    scene = synthetic.make_scene(4400, 6000)[:, :3].astype(np.float32)
+    cnt = _check_normals(scene, radius=0.02)
+    assert cnt.max() == 30 and cnt.min() < 30                                 # both the capped and the uncapped branch
+    _check_normals(scene[:3000], camera=(0.1, -0.2, 2.0), radius=0.03, max_nn=64)
+    _check_normals(scene[:2500], min_well=0.0)                                      # the reference's radius: sparse, many lone points
+
+
+def test_normals_known_answers_and_edges():
+    from regnet_for_3d_grasping_amd import eval_collision as ec
+    rng = np.random.default_rng(11)
+    nrm = np.array([0.2, -0.3, 1.0]); nrm /= np.linalg.norm(nrm)
+    a = np.cross(nrm, [1.0, 0.3, -0.2]); a /= np.linalg.norm(a)
+    b = np.cross(nrm, a)
+    uv = rng.uniform(-0.04, 0.04, (4000, 2))
+    plane = (0.6 * nrm + uv[:, :1] * a + uv[:, 1:] * b).astype(np.float32)
+    n, cnt = ec.estimate_normals(torch.from_numpy(plane).to(DEV), return_count=True)
+    n, cnt = n.cpu().numpy().astype(np.float64), cnt.cpu().numpy()
+    assert cnt.max() == 30 and np.all(np.abs(n[cnt >= 3] @ nrm + 1.0) < 1e-5)
+    # a regular lattice: ties in distance everywhere -> the (distance, index) ranking must still match the oracle
+    g = np.stack(np.meshgrid(np.arange(40), np.arange(40), indexing="ij"), -1).reshape(-1, 2) * 0.004
+    lattice = np.concatenate([g, np.full((len(g), 1), 0.7)], 1).astype(np.float32)
+    _check_normals(lattice, radius=0.015)
+    # lone points, duplicates, empty and single-point clouds
+    lone = np.array([[0.0, 0.0, 0.5], [0.3, 0.0, -0.5], [0.3, 0.005, -0.5]], dtype=np.float32)
+    assert np.array_equal(ec.estimate_normals(torch.from_numpy(lone).to(DEV)).cpu().numpy(), [[0, 0, -1], [0, 0, 1], [0, 0, 1]])
+    dup = np.repeat(np.array([[0.1, 0.1, 0.6]], dtype=np.float32), 70, axis=0)
+    _check_normals(dup, min_well=0.0)
+    assert np.array_equal(ec.estimate_normals(torch.from_numpy(dup).to(DEV)).cpu().numpy(), co.estimate_normals(dup)[0])
+    assert ec.estimate_normals(torch.zeros((0, 3), device=DEV)).shape == (0, 3)
+    with pytest.raises(RuntimeError):
+        ec.estimate_normals(torch.zeros((4, 3)))                                # CPU tensors are refused, no fallback
+
+
+def test_eval_validate_estimates_missing_scene_normals():
+    """A validation record without scene_normal (torch_scene_point_cloud.py:17-19): the result equals the one obtained
+    with the estimated normals passed in, and the score equals the oracle's on its own estimated normals."""
+    from regnet_for_3d_grasping_amd import eval_collision as ec
+    c = golden_util.VALIDATE_CASES[0]
+    data, g = golden_util.validate_case(0)
+    data = {k: (v[:6000] if k.startswith("scene") else v) for k, v in data.items()}
+    bare = {k: v for k, v in data.items() if k != "scene_normal"}
+    est = ec.estimate_normals(torch.from_numpy(bare["scene_cloud"]).to(DEV))
+    a = ec.eval_validate(bare, g, c["view_num"], c["table_height"], c["depth"], c["width"], 0)
+    b = ec.eval_validate(dict(bare, scene_normal=est.cpu().numpy()), g, c["view_num"], c["table_height"], c["depth"], c["width"], 0)
+    assert a[0] == b[0] and a[2] == b[2] and abs(a[1] - b[1]) <= 1e-6 * max(1.0, abs(b[1])) and torch.equal(a[4], b[4])
+    n_or, _ = co.estimate_normals(bare["scene_cloud"])
+    want = co.eval_validate(dict(bare, scene_normal=n_or.astype(np.float32)), torch.from_numpy(g), c["view_num"], c["table_height"],
+                            c["depth"], c["width"])
+    assert a[0] == want[0] and a[2] == want[2]
+    assert abs(a[1] - want[1]) <= 1e-4 * max(1.0, abs(want[1]))
