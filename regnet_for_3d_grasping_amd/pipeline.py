@@ -2,6 +2,7 @@
 (the step of test.py:134-141 / train.py:358-367 without losses), as one callable used by
 bench.py, smoke() and the tests."""
 import contextlib
+import os
 import io
 
 import torch
@@ -46,6 +47,11 @@ def forward_scenes(score_net, region_net, pc, with_region=True):
     out.update(center_pc_index=center_idx, pc_group_index=g_idx, pc_group_more_index=gm_idx, next_grasp=res[0],
                select_grasp_class=res[6], select_grasp_score=res[7], final_mask=res[11])
     return out
+
+
+# Timing experiments only (scripts/, never set by the package): "fps" reuses the first batch's level-1 sampling, "plan" its
+# whole geometry, for every later batch -- the results are then WRONG; it measures what those stages cost the others.
+_DEBUG_REUSE = os.environ.get("REGNET_DEBUG_REUSE_GEOMETRY", "")
 
 
 class ForwardPipeline:
@@ -97,7 +103,12 @@ class ForwardPipeline:
         stream = self.s_fps[self._n_sampled % len(self.s_fps)]
         self._n_sampled += 1
         with torch.cuda.stream(stream), torch.no_grad():
-            ctr = self.score_net.sample_level1(pc)
+            if _DEBUG_REUSE and getattr(self, "_dbg_ctr", None) is not None:
+                ctr = self._dbg_ctr
+            else:
+                ctr = self.score_net.sample_level1(pc)
+                if _DEBUG_REUSE:
+                    self._dbg_ctr = ctr
             done = torch.cuda.Event()
             done.record(stream)
         ctr.record_stream(self.s_geo)
@@ -109,7 +120,12 @@ class ForwardPipeline:
         from . import fused
         with torch.cuda.stream(self.s_geo), torch.no_grad():
             self.s_geo.wait_event(item["fps_done"])
-            plan = self.score_net.plan(item["pc"], item["ctr"])
+            if _DEBUG_REUSE == "plan" and getattr(self, "_dbg_plan", None) is not None:
+                plan = self._dbg_plan
+            else:
+                plan = self.score_net.plan(item["pc"], item["ctr"])
+                if _DEBUG_REUSE == "plan":
+                    self._dbg_plan = plan
             done = torch.cuda.Event()
             done.record(self.s_geo)
         for t in fused.plan_tensors(plan):
