@@ -241,6 +241,15 @@ int regnet_grasp_antipodal_stats_f32(const float* points, int64_t pn, int64_t pc
                                      const float* x_hi_per_grasp, float half_thickness, float half_width, float half_space,
                                      float back_x, float neighbour_depth, float* stats, int32_t* side_counts, void* stream);
 
+/* regnet_resample_groups_f32: the gather half of get_regiondataset.py:331-352 (_get_group_pc).  cand (B,Nc,cap) int32: the
+ * ascending member lists of regnet_radius_group_f32; pos (B,Nc,G) int64: positions into them drawn on the host with numpy's
+ * RNG stream (-1 in every slot of a centre without candidates); pc (B,N,C) rows with element strides (pb, pn), channels
+ * contiguous.  index[b,c,g] = cand[b,c,pos[b,c,g]] and points[b,c,g,:] = pc[b,index,:], or -1 / -1.0f where pos < 0 (the
+ * reference fills empty groups with -1, :346-350).  Replaces seven tensor ops per pass.                                  */
+int regnet_resample_groups_f32(const float* pc, int64_t pb, int64_t pn, int64_t C, const int32_t* cand, int64_t cap,
+                               const int64_t* pos, int64_t B, int64_t Nc, int64_t G, int64_t* index, float* points,
+                               void* stream);
+
 /* regnet_estimate_normals_f32: surface normals of a scene cloud for validation records that carry no scene_normal --
  * dataset_utils/eval_score/eval_utils/torch_scene_point_cloud.py:17-19 -> eval_utils/pointcloud.py:27-43, i.e. open3d's
  * estimate_normals(KDTreeSearchParamHybrid(radius = NORMAL_RADIUS, max_nn = NORMAL_MAX_NN)), normalize_normals and

@@ -70,6 +70,20 @@ def box_candidates(group_points, centre, rot, xlim, ylim, zlim):
     return torch.from_numpy(cand), torch.from_numpy(count)
 
 
+def resample_groups(pc, cand, pos):
+    """get_regiondataset.py:331-352 after the draws: pc (B,N,C), cand (B,Nc,cap) candidate lists, pos (B,Nc,G) int64
+    positions into them (-1 = the centre has no candidate) -> index (B,Nc,G) int64, points (B,Nc,G,C); -1 where pos < 0
+    (the reference leaves empty groups at their -1 initialisation, :346-350)."""
+    B, Nc, G = pos.shape
+    C = pc.shape[2]
+    index = torch.gather(cand.long(), 2, pos.clamp(min=0))
+    points = torch.gather(pc, 1, index.view(B, Nc * G, 1).expand(B, Nc * G, C)).view(B, Nc, G, C).clone()
+    empty = pos < 0
+    index[empty] = -1
+    points[empty] = -1.0
+    return index, points
+
+
 def gather_max(feature_rows, rows):
     """gripper_region_network.py:388-395 + utils/pointnet2.py:167: gather rows then max over the group."""
     R, G = rows.shape

@@ -408,3 +408,42 @@ extern "C" int regnet_gather_max_f32(const float* feat, int64_t num_rows, int64_
   REGNET_LAUNCH_CHECK();
   return REGNET_OK;
 }
+
+// ---- resampled groups ---------------------------------------------------------------------------------------------------
+// get_regiondataset.py:331-352: every (scene, centre) candidate list is resampled to exactly G entries at positions drawn
+// on the host (numpy's RNG), then the member indices and their points are gathered; a centre without candidates gets -1
+// everywhere.  One thread per (scene, centre, slot): replaces clamp + gather + cast + 2 x where + gather + where.
+__global__ __launch_bounds__(256) void resample_groups_kernel(const float* __restrict__ pc, int64_t pb, int64_t pn, int C,
+                                                              const int* __restrict__ cand, int64_t cap,
+                                                              const int64_t* __restrict__ pos, long long total, int G,
+                                                              int64_t groups_per_scene, int64_t* __restrict__ index,
+                                                              float* __restrict__ points) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= total) return;
+  const long long grp = t / G;               // scene * groups_per_scene + centre
+  const int64_t p = pos[t];
+  float* o = points + t * C;
+  if (p < 0) {
+    index[t] = -1;
+    for (int c = 0; c < C; ++c) o[c] = -1.0f;
+    return;
+  }
+  const int64_t j = (int64_t)cand[grp * cap + p];
+  index[t] = j;
+  const float* src = pc + (grp / groups_per_scene) * pb + j * pn;
+  for (int c = 0; c < C; ++c) o[c] = src[c];
+}
+
+extern "C" int regnet_resample_groups_f32(const float* pc, int64_t pb, int64_t pn, int64_t C, const int32_t* cand,
+                                          int64_t cap, const int64_t* pos, int64_t B, int64_t Nc, int64_t G,
+                                          int64_t* index, float* points, void* stream) {
+  if (B < 0 || Nc < 0 || G < 0 || C <= 0 || cap < 0) return REGNET_ERR_SHAPE;
+  const long long total = (long long)B * Nc * G;
+  if (total >= (1ll << 40) || G >= (int64_t)1 << 31 || C > 64) return REGNET_ERR_UNSUPPORTED;
+  if (total == 0) return REGNET_OK;
+  if (!pc || !cand || !pos || !index || !points) return REGNET_ERR_NULL;
+  hipLaunchKernelGGL(resample_groups_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), pc, pb,
+                     pn, (int)C, cand, cap, pos, total, (int)G, Nc, index, points);
+  REGNET_LAUNCH_CHECK();
+  return REGNET_OK;
+}

@@ -221,14 +221,6 @@ def _get_group_pc(pc, center_pc, center_pc_index, group_num, width, height, dept
     cand, counts = region_ops.radius_candidates(pc, center_pc, radius)  # (B,Nc,cap) int32, (B,Nc) int32
     counts_np = counts.cpu().numpy()                                    # the one sync of this pass
     pos = torch.from_numpy(_draw_positions(counts_np, group_num)).to(pc.device)
-    has_empty = bool((counts_np == 0).any())
-    pc_group_index = torch.gather(cand, 2, pos.clamp(min=0)).long()
-    if has_empty:  # candidate slots of an empty group were never written: do not gather through them
-        empty = pos[:, :, :1] < 0
-        pc_group_index = torch.where(empty, torch.zeros_like(pc_group_index), pc_group_index)
-    flat = pc_group_index.view(B, Nc * group_num, 1).expand(B, Nc * group_num, C)
-    pc_group = torch.gather(pc, 1, flat).view(B, Nc, group_num, C)
-    if has_empty:
-        pc_group_index = torch.where(empty, torch.full_like(pc_group_index, -1), pc_group_index)
-        pc_group = torch.where(empty.unsqueeze(-1), torch.full_like(pc_group, -1.0), pc_group)
+    # candidate slots of an empty group were never written: the kernel does not read through them
+    pc_group_index, pc_group = region_ops.resample_groups(pc, cand, pos)
     return pc_group_index, pc_group

@@ -68,6 +68,27 @@ def select_positive(pc, score, threshold):
     return index, xyz, count
 
 
+def resample_groups(pc, cand, pos):
+    """pc (B,N,C) float32, cand (B,Nc,cap) int32 candidate lists, pos (B,Nc,G) int64 positions into them (-1 = the centre
+    has no candidate) -> index (B,Nc,G) int64 and points (B,Nc,G,C); -1 / -1.0 where pos < 0."""
+    _need_f32(pc, "pc")
+    _need_i64(pos, "pos")
+    if cand.dtype != torch.int32:
+        raise TypeError("cand must be int32")
+    if pc.stride(2) != 1:
+        pc = pc.contiguous()
+    cand, pos = cand.contiguous(), pos.contiguous()
+    B, Nc, G = pos.shape
+    C = pc.shape[2]
+    with torch.cuda.device(pc.device):
+        index = torch.empty((B, Nc, G), dtype=torch.int64, device=pc.device)
+        points = torch.empty((B, Nc, G, C), dtype=torch.float32, device=pc.device)
+        _check(_L.regnet_resample_groups_f32(pc.data_ptr(), pc.stride(0), pc.stride(1), C, cand.data_ptr(), cand.size(2),
+                                             pos.data_ptr(), B, Nc, G, index.data_ptr(), points.data_ptr(), _stream(pc)),
+               "resample_groups")
+    return index, points
+
+
 def box_candidates(group_points, centre, rot, xlim, ylim, zlim):
     """group_points (n,G,C>=3), centre (n,3), rot (n,3,3), xlim/ylim (n) float32, zlim float ->
     cand (n,G) int32 ascending in-box positions, count (n) int32."""

@@ -306,6 +306,19 @@ def test_region_ops_match_oracle():
             for c in range(64):
                 n = int(wn[b, c])
                 assert torch.equal(gc[b, c, :n].cpu(), wc[b, c, :n])
+        # resampled groups (get_regiondataset.py:331-352): positions into the candidate lists -> member ids + their points,
+        # -1 everywhere for a centre without candidates; against the reference's tensor expressions
+        G = 96
+        pos = torch.stack([torch.stack([torch.from_numpy(rng.integers(0, max(int(wn[b, c]), 1), G)) for c in range(64)]) for b in range(2)])
+        pos[1, 5] = -1
+        pos[0, 63] = -1
+        gi, gp = region_ops.resample_groups(pc.to(DEV), gc, pos.to(DEV))
+        want_i = torch.gather(gc.cpu().long(), 2, pos.clamp(min=0))
+        want_p = torch.gather(pc, 1, want_i.view(2, 64 * G, 1).expand(2, 64 * G, 6)).view(2, 64, G, 6)
+        empty = pos < 0
+        want_i[empty] = -1
+        want_p[empty] = -1.0
+        assert torch.equal(gi.cpu(), want_i) and torch.equal(gp.cpu(), want_p)
     # box crop
     n, G = 40, 1024
     pts = torch.from_numpy(rng.uniform(-0.07, 0.07, (n, G, 6)).astype(np.float32))
