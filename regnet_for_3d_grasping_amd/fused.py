@@ -371,9 +371,11 @@ def sa_group(module, xyz, ctr):
     new_xyz = torch.gather(xyz, 2, ctr[:, None, :].expand(B, 3, M))
     nbr, count = pn2_ext.ball_query(xyz, new_xyz, module.grouper.radius, module.grouper.num_neighbours)
     geo = {"ctr": ctr, "new_xyz": new_xyz, "nbr": nbr}
-    if CHAIN3 and module.grouper.num_neighbours == 64:
-        # for the register-chained block: neighbourhoods with <= 32 members first (they cost half), so that whole
-        # workgroups are of one kind; computed here, in the geometry stage, off the matrix cores' critical path
+    if (CHAIN3 and module.grouper.num_neighbours == 64 and len(module.mlp) == 3
+            and module.mlp[0].conv.in_channels <= 8):
+        # for the register-chained block (narrow gathered input, sa_features): neighbourhoods with <= 32 members first
+        # (they cost half), so that whole workgroups are of one kind; computed here, in the geometry stage, off the
+        # matrix cores' critical path
         geo["count"] = count
         geo["order"] = torch.argsort((count.view(-1) > 32).to(torch.uint8), stable=True)
     return geo
