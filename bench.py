@@ -162,9 +162,9 @@ def _mlp_layer_kernel(d):
         return "mlp_gemm_kernel<0>"
     nt = (N + 127) // 128
     t256, t128, kpad = ((P + 255) // 256) * nt, ((P + 127) // 128) * nt, (K + 15) // 16 * 16
-    if N > 128 and (t256 >= 512 or (t256 >= 256 and kpad >= 1024)):
+    if N > 128 and t256 >= 1024:
         tile = "256,128"
-    elif 256 <= t128 <= 512 or t128 >= 1536:
+    elif t128 >= 1024:
         tile = "128,128"
     else:
         tile = "64,128"

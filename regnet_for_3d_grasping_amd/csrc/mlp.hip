@@ -505,15 +505,19 @@ static int launch_gemm2_tile(G2Args g, bool pool, hipStream_t st) {
 }
 
 static int launch_gemm2(const G2Args& g, bool pool, hipStream_t st) {
-  // Measured on the step's layer shapes (scripts/ablate/g2_bench.cpp [medium]): the big tile wants at least one full
-  // round of its 512 slots (or one tile per CU when K is long); below that 128 x 128 wins while it yields 256..512
-  // tiles, and 64 x 128 (4 workgroups per CU) when the problem is smaller still or falls between the two
-  // (P = 40 960, N = 256: 74 / 93 / 105 TFLOP/s for the three tiles; P = 2 048, N = 1 024: 33 / 60 / 95).
+  // Tile choice, measured on the step's layer shapes BESIDE a level-1 sampling launch (one CU of every XCD held, the
+  // condition these launches run in: scripts/bench_gemm2_layers.py with SIDE_BLOCKS=8, REGNET_G2_TILE=0/1/2): the hardware's
+  // in-order workgroup rotation then loses a round to every tile that does not fit the first one, so a launch wants either
+  // several rounds of its tile (>= 4 x the CUs) or the smallest tile.  (Alone on the chip the big tile wins from one round
+  // up -- 149 vs 177 us at P = 8192, K = N = 1024 -- but beside the sampling it takes 277 vs 205 us.)
+  static const int force_tile = getenv("REGNET_G2_TILE") ? atoi(getenv("REGNET_G2_TILE")) : -1;   // A/B measurements only
+  if (force_tile == 0) return launch_gemm2_tile<256, 128, 4, 2, 3, 2>(g, pool, st);
+  if (force_tile == 1) return launch_gemm2_tile<128, 128, 2, 2, 3, 3>(g, pool, st);
+  if (force_tile == 2) return launch_gemm2_tile<64, 128, 1, 4, 3, 4>(g, pool, st);
   const long long nt = (g.N + 127) / 128;
   const long long t256 = ((g.P + 255) / 256) * nt, t128 = ((g.P + 127) / 128) * nt;
-  if (g.N > 128 && (t256 >= 2 * G2_CUS || (t256 >= G2_CUS && g.Kpad >= 1024)))
-    return launch_gemm2_tile<256, 128, 4, 2, 3, 2>(g, pool, st);
-  if ((t128 >= G2_CUS && t128 <= 2 * G2_CUS) || t128 >= 6 * G2_CUS) return launch_gemm2_tile<128, 128, 2, 2, 3, 3>(g, pool, st);
+  if (g.N > 128 && t256 >= 4 * G2_CUS) return launch_gemm2_tile<256, 128, 4, 2, 3, 2>(g, pool, st);
+  if (t128 >= 4 * G2_CUS) return launch_gemm2_tile<128, 128, 2, 2, 3, 3>(g, pool, st);
   return launch_gemm2_tile<64, 128, 1, 4, 3, 4>(g, pool, st);
 }
 
