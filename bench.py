@@ -57,6 +57,7 @@ def parse():
     ap.add_argument("--mlp-streams", type=int, default=1, help="feature-stage streams (batches whose MFMA kernels may overlap): 2 is ~6 %% faster (875 scenes/s) but "
                          "time-shares the launches, so per-kernel durations stop being a kernel property (DESIGN.md par. 7)")
     ap.add_argument("--fps-streams", type=int, default=2, help="level-1 sampling launches in flight")
+    ap.add_argument("--fps-group", type=int, default=0, help="batches whose level-1 sampling shares one launch (0: 32 scenes' worth)")
     ap.add_argument("--lookahead", type=int, default=3, help="batches whose region stage may be pending (pipeline depth)")
     return ap.parse_args()
 
@@ -70,6 +71,8 @@ class OpTimer:
         self.enabled = False
         self.every = max(1, int(every))   # bracket every n-th call of an op (event records are not free, see --time-every)
         self.calls = {}
+        self.critical_streams = None      # stream handles of the stage that bounds the step (ForwardPipeline's feature stage)
+        self.critical = set()             # (name, shape) keys launched on one of them
 
     def wrap(self, module, name, meta_fn):
         orig = getattr(module, name)
@@ -80,6 +83,8 @@ class OpTimer:
             key = (name, meta_fn(*a, **k))
             n = self.calls.get(key, 0)
             self.calls[key] = n + 1
+            if n == 0 and self.critical_streams is not None and torch.cuda.current_stream().cuda_stream in self.critical_streams:
+                self.critical.add(key)
             if n % self.every:
                 return orig(*a, **k)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -325,8 +330,11 @@ def run_train(args, rank, world, dev):
                        "steps_with_region_losses": region_steps, "last_loss": float(loss)}}))
 
 
-def roofline_of(agg, steps, batch):
-    """OpTimer summary -> (kernel families, roofline object of the dominant one)."""
+def roofline_of(agg, steps, batch, critical=None):
+    """OpTimer summary -> (kernel families, roofline object of the dominant one).  ``critical``: the (name, shape) keys that
+    were launched on the stream of the stage that bounds the step (the pipeline's feature stage, whose queue is busy 98 % of a
+    step: DESIGN.md par. 7); only their families can be the dominant kernel -- the sampling / grouping / region kernels of the
+    other batches run beside it on their own streams and their event time is mostly waiting for a CU."""
     # kernel families: every mlp_layer / sa_layer1 launch is the same device kernel (mlp_gemm_kernel)
     fam = {}
     for (name, meta), (tot, cnt) in agg.items():
@@ -340,7 +348,8 @@ def roofline_of(agg, steps, batch):
                     i += 1
                 d[tok[:i]] = int(tok[i:])
             key = key(d)
-        f = fam.setdefault(key, {"ms": 0.0, "launches": 0, "units": 0, "bound": bound})
+        f = fam.setdefault(key, {"ms": 0.0, "launches": 0, "units": 0, "bound": bound, "critical": critical is None})
+        f["critical"] = f["critical"] or (critical is not None and (name, meta) in critical)
         f["ms"] += tot
         f["launches"] += cnt
         f["units"] += units * cnt
@@ -352,6 +361,8 @@ def roofline_of(agg, steps, batch):
     # dominant = most GPU resource-time: a furthest-point-sampling launch keeps ONE CU per
     # scene busy (a latency chain running beside the MLPs), every other kernel fills the chip
     def cu_ms(k):
+        if not fam[k]["critical"]:
+            return 0.0
         if k == "fps_kernel":
             return fam[k]["ms"] * min(1.0, batch / 256.0)
         if k == "mlp_gemm_kernel<0>":   # the skinny split-K launches of the region heads: at most 256 of the chip's 1024
@@ -409,7 +420,9 @@ def main():
     # and the region stage of the previous one on three HIP streams (all work of the K timed
     # steps happens inside the timed region; the pipeline drains before the closing fence).
     pipe = pipeline.ForwardPipeline(score_net, region_net, with_region=not args.score_only, fps_streams=args.fps_streams,
-                                    mlp_streams=args.mlp_streams)
+                                    mlp_streams=args.mlp_streams, fps_group=args.fps_group)
+
+    timer.critical_streams = {m.cuda_stream for m in pipe.s_mlps}
 
     def run_steps(n):
         last = None
@@ -441,6 +454,7 @@ def main():
         timer.records, timer.calls = [], {}
         pipe1 = pipeline.ForwardPipeline(score_net, region_net, with_region=not args.score_only,
                                          fps_streams=args.fps_streams, mlp_streams=1)
+        timer.critical_streams |= {m.cuda_stream for m in pipe1.s_mlps}
         for _ in pipe1.run((pc for _ in range(4)), max_pending_regions=args.lookahead):
             pass
         torch.cuda.synchronize()
@@ -475,7 +489,7 @@ def main():
         by_time = sorted(agg.items(), key=lambda kv: -kv[1][0])
         kernels = [{"op": k[0], "shape": k[1], "calls": c, "avg_ms": round(tot / c, 4), "total_ms": round(tot, 3)}
                    for k, (tot, c) in by_time]
-        fam, roofline = roofline_of(agg, args.steps, args.batch)
+        fam, roofline = roofline_of(agg, args.steps, args.batch, timer.critical if timer.critical_streams is not None else None)
         if roofline and args.mlp_streams > 1:
             roofline["concurrency"] = ("%d feature-stage streams: launches of this family overlap each other, so the launch "
                                        "duration above (what rocprofv3 shows too) includes time-sharing; roofline_exclusive "
@@ -501,7 +515,7 @@ def main():
             "grasps_last_step": int(out["next_grasp"].shape[0]) if "next_grasp" in out else None,
         }
         if exclusive is not None:
-            _, r1 = roofline_of(exclusive[0], args.exclusive_steps, args.batch)
+            _, r1 = roofline_of(exclusive[0], args.exclusive_steps, args.batch, timer.critical if timer.critical_streams is not None else None)
             if r1:
                 r1["steps"] = args.exclusive_steps
                 r1["scenes_per_s_in_this_mode"] = round(args.batch * args.exclusive_steps / exclusive[1], 1)

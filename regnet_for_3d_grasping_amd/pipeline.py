@@ -63,9 +63,10 @@ class ForwardPipeline:
     CUs and region grouping needs the host for numpy's RNG.  So four stages run concurrently on five
     (or more) HIP streams, each on a different batch:
 
-        s_fps : sample(batch i+2, i+3) level-1 FPS, two batches at a time on two streams: a launch is a
-                                      ~10 ms latency chain on ONE CU per scene, so two of them in
-                                      flight double the sampling throughput at no cost to the MLPs
+        s_fps : sample(batches i+2 ..) level-1 FPS of the NEXT GROUP of batches (up to 64 scenes) in one launch, groups
+                                      alternating between two streams: a launch is a ~10 ms latency chain on ONE CU per
+                                      scene, and what it costs the matrix kernels does not grow with its size up to one or
+                                      two CUs per shader engine (see _sample_group), so it pays to run it rarely
         s_geo : geometry(batch i+1)   FPS levels 2-3, ball query x3, 3-NN x3
         s_mlp : features(batch i)     gather / MFMA shared-MLP / pool / head    (matrix cores; with ``mlp_streams=2``
                                       consecutive batches alternate between two such streams)
@@ -75,10 +76,10 @@ class ForwardPipeline:
     RNG call order: region stages execute in batch order on the host thread).
     """
 
-    def __init__(self, score_net, region_net, with_region=True, fps_streams=2, mlp_streams=1):
+    def __init__(self, score_net, region_net, with_region=True, fps_streams=2, mlp_streams=1, fps_group=0):
         """``fps_streams``: level-1 sampling launches in flight (each ~10 ms on one CU per scene, whatever the batch
-        size): 2 keep up with the matrix cores at 8 scenes per batch.  (Batches of 1-4 scenes are bound by the region
-        stage's ~4.6 ms on its host thread, not by the sampling: more streams measured slower there.)
+        size).  ``fps_group``: consecutive batches whose level-1 sampling shares one launch (0: as many as give 64 scenes,
+        at most 8): +6 % at 8 scenes per batch, +12-15 % at 1 and 4, at the price of reading that many batches ahead.
         ``mlp_streams``: feature stages (consecutive batches) that may overlap.  One batch's ~30 MFMA launches leave the
         chip partly idle at every kernel tail and in the small layers (P <= 40 960 rows); a second stream fills those
         holes with the next batch's kernels: 9.70 -> 9.14 ms per batch of 8 (824 -> 875 scenes/s) with
@@ -86,6 +87,7 @@ class ForwardPipeline:
         a launch's duration (the quantity the roofline accounting and every profile under profiles/ is built on) then
         depends on what the other stream happens to run, and a profiler perturbs exactly that."""
         self.score_net, self.region_net, self.with_region = score_net, region_net, with_region
+        self.fps_group = int(fps_group)   # batches whose level-1 sampling shares one launch; 0 = as many as give 64 scenes (<= 8)
         dev = next(score_net.parameters()).device
         self.device = dev
         # Priorities: FPS and the region stage are chains of small / single-CU kernels (the latter
@@ -99,22 +101,34 @@ class ForwardPipeline:
         self.s_reg = torch.cuda.Stream(dev, priority=-1)
 
     # -- stages -------------------------------------------------------------------------------
-    def _sample(self, pc):
+    def _sample_group(self, pcs):
+        """Level-1 sampling of several consecutive batches in ONE launch -> one item per batch.
+
+        A sampling workgroup owns a whole CU for ~10 ms.  The hardware deals the workgroups of every launch to the XCDs and
+        their shader engines in a fixed rotation, in order, so an engine that has lost a CU paces all the others: 8 held
+        CUs (one per XCD) cost the matrix kernels as much as 32 (one per engine) -- 12.5 %, measured (DESIGN.md par. 10).
+        So the sampling of up to 64 scenes (two per engine) goes into one launch: the same cost while it runs, but it runs
+        an eighth of the time."""
         stream = self.s_fps[self._n_sampled % len(self.s_fps)]
         self._n_sampled += 1
+        B = pcs[0].shape[0]
         with torch.cuda.stream(stream), torch.no_grad():
             if _DEBUG_REUSE and getattr(self, "_dbg_ctr", None) is not None:
-                ctr = self._dbg_ctr
+                ctr = self._dbg_ctr.repeat(len(pcs), 1)
             else:
-                ctr = self.score_net.sample_level1(pc)
+                ctr = self.score_net.sample_level1(pcs[0] if len(pcs) == 1 else torch.cat(pcs, 0))
                 if _DEBUG_REUSE:
-                    self._dbg_ctr = ctr
+                    self._dbg_ctr = ctr[:B].clone()
             done = torch.cuda.Event()
             done.record(stream)
         ctr.record_stream(self.s_geo)
         for m in self.s_mlps:
             ctr.record_stream(m)
-        return {"pc": pc, "ctr": ctr, "fps_done": done}
+        items, at = [], 0
+        for pc in pcs:
+            items.append({"pc": pc, "ctr": ctr[at:at + pc.shape[0]], "fps_done": done})
+            at += pc.shape[0]
+        return items
 
     def _geometry(self, item):
         from . import fused
@@ -219,25 +233,29 @@ class ForwardPipeline:
 
         try:
             import collections
-            sampled = collections.deque()   # batches whose level-1 FPS is enqueued (up to len(s_fps) of them)
+            sampled = collections.deque()   # batches whose level-1 FPS is enqueued
             st_geo = None                   # batch whose remaining geometry is enqueued
             it = iter(batches)
             exhausted = False
+            group = self.fps_group
             while True:
-                pc = None
-                if not exhausted:
-                    try:
-                        pc = next(it)
-                    except StopIteration:
-                        exhausted = True
-                if pc is None and not sampled and st_geo is None:
+                # keep the sampling ahead: a new group launch when at most one group's worth of sampled batches is left
+                while not exhausted and (group <= 0 or len(sampled) <= group):
+                    pcs = []
+                    while group <= 0 or len(pcs) < group:
+                        try:
+                            pcs.append(next(it))
+                        except StopIteration:
+                            exhausted = True
+                            break
+                        if group <= 0:
+                            group = max(1, min(8, 64 // max(1, pcs[0].shape[0])))
+                    if pcs:
+                        sampled.extend(self._sample_group(pcs))
+                if not sampled and st_geo is None:
                     break
                 # enqueue the asynchronous stages, deepest look-ahead first
-                if pc is not None:
-                    sampled.append(self._sample(pc))
-                new_geo = None
-                if len(sampled) > len(self.s_fps) or (exhausted and sampled):
-                    new_geo = self._geometry(sampled.popleft())
+                new_geo = self._geometry(sampled.popleft()) if sampled else None
                 if st_geo is not None:
                     todo.put(self._features(st_geo))
                     pending += 1

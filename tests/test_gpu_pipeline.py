@@ -1,5 +1,6 @@
-"""ForwardPipeline (six or seven HIP streams, four batches in flight; one or two feature-stage streams) must return exactly what the sequential
-forward returns for the same batches and numpy seed."""
+"""ForwardPipeline (six or seven HIP streams, several batches in flight; one or two feature-stage streams; the level-1 sampling of
+consecutive batches grouped into one launch or not) must return exactly what the sequential forward returns for the same batches
+and numpy seed."""
 import numpy as np
 import pytest
 import torch
@@ -8,17 +9,17 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-@pytest.mark.parametrize("mlp_streams", [1, 2])
-def test_pipeline_equals_sequential(mlp_streams):
+@pytest.mark.parametrize("mlp_streams,fps_group", [(1, 0), (2, 0), (1, 2), (1, 1)])
+def test_pipeline_equals_sequential(mlp_streams, fps_group):
     from regnet_for_3d_grasping_amd import pipeline, synthetic
     score_net, region_net = pipeline.build_models(DEV)
-    batches = [synthetic.make_batch(3000 + 10 * i, 2, 6144, device=DEV) for i in range(4)]
+    batches = [synthetic.make_batch(3000 + 10 * i, 2, 6144, device=DEV) for i in range(5)]   # 5: the last sampling group is partial
     synthetic.calibrate_score_head(score_net, batches[0])
     np.random.seed(77)
     want = [pipeline.forward_scenes(score_net, region_net, pc) for pc in batches]
     torch.cuda.synchronize()
     np.random.seed(77)
-    pipe = pipeline.ForwardPipeline(score_net, region_net, mlp_streams=mlp_streams)
+    pipe = pipeline.ForwardPipeline(score_net, region_net, mlp_streams=mlp_streams, fps_group=fps_group)
     got = list(pipe.run(iter(batches)))
     torch.cuda.synchronize()
     assert len(got) == len(want)
