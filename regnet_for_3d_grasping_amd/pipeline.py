@@ -52,6 +52,7 @@ def forward_scenes(score_net, region_net, pc, with_region=True):
 # Timing experiments only (scripts/, never set by the package): "fps" reuses the first batch's level-1 sampling, "plan" its
 # whole geometry, for every later batch -- the results are then WRONG; it measures what those stages cost the others.
 _DEBUG_REUSE = os.environ.get("REGNET_DEBUG_REUSE_GEOMETRY", "")
+_SAMPLE_ALL_LEVELS = os.environ.get("REGNET_PIPE_SAMPLE_LEVELS", "all") != "1"   # "1": only level 1 in the grouped launch (A/B)
 
 
 class ForwardPipeline:
@@ -114,19 +115,22 @@ class ForwardPipeline:
         B = pcs[0].shape[0]
         with torch.cuda.stream(stream), torch.no_grad():
             if _DEBUG_REUSE and getattr(self, "_dbg_ctr", None) is not None:
-                ctr = self._dbg_ctr.repeat(len(pcs), 1)
+                ctr = [c.repeat(len(pcs), 1) for c in self._dbg_ctr]
             else:
-                ctr = self.score_net.sample_level1(pcs[0] if len(pcs) == 1 else torch.cat(pcs, 0))
+                # all three sampling levels: the level-2 / level-3 launches hold a CU per scene too (1.3 + 0.5 ms)
+                big = pcs[0] if len(pcs) == 1 else torch.cat(pcs, 0)
+                ctr = self.score_net.sample_levels(big) if _SAMPLE_ALL_LEVELS else [self.score_net.sample_level1(big)]
                 if _DEBUG_REUSE:
-                    self._dbg_ctr = ctr[:B].clone()
+                    self._dbg_ctr = [c[:B].clone() for c in ctr]
             done = torch.cuda.Event()
             done.record(stream)
-        ctr.record_stream(self.s_geo)
-        for m in self.s_mlps:
-            ctr.record_stream(m)
+        for c in ctr:
+            c.record_stream(self.s_geo)
+            for m in self.s_mlps:
+                c.record_stream(m)
         items, at = [], 0
         for pc in pcs:
-            items.append({"pc": pc, "ctr": ctr[at:at + pc.shape[0]], "fps_done": done})
+            items.append({"pc": pc, "ctr": [c[at:at + pc.shape[0]] for c in ctr], "fps_done": done})
             at += pc.shape[0]
         return items
 

@@ -62,8 +62,25 @@ class PointNet2Seg(nn.Module):
         with torch.no_grad():
             return fused.sa_sample(self.sa_modules[0], xyz)
 
+    def sample_levels(self, points):
+        """Furthest point sampling of ALL set-abstraction levels (each level samples the previous level's centroids): the
+        part of the geometry whose launches hold whole CUs, separable so that a pipeline can run it for many batches in
+        one launch per level.  -> list of (B, M_level) index tensors; pass it to ``plan`` as ``level1_ctr``."""
+        from . import fused
+        xyz = points[:, :3, :]
+        if not (fused.ENABLED and xyz.is_cuda):
+            raise RuntimeError("PointNet2Seg.sample_levels needs GPU tensors")
+        ctrs = []
+        with torch.no_grad():
+            for sa in self.sa_modules:
+                ctr = fused.sa_sample(sa, xyz)
+                ctrs.append(ctr)
+                xyz = torch.gather(xyz, 2, ctr[:, None, :].expand(xyz.shape[0], 3, ctr.shape[1]))
+        return ctrs
+
     def plan(self, points, level1_ctr=None):
-        """Geometry of a forward pass -- FPS / ball-query / 3-NN indices of every level.  Depends on
+        """Geometry of a forward pass -- FPS / ball-query / 3-NN indices of every level (``level1_ctr``: the level-1
+        sampling from ``sample_level1``, or the list of all levels' from ``sample_levels``, when already computed).  Depends on
         xyz only, so it can be computed ahead of (and concurrently with) the feature pass; hand the
         result to ``forward(points, plan=...)`` -- the fused inference path or the operator-granular training path.
         GPU only; always computed without autograd (the reference's geometry ops return no gradients)."""
@@ -77,8 +94,9 @@ class PointNet2Seg(nn.Module):
     def _plan(self, xyz, level1_ctr):
         from . import fused
         levels, sa_geo = [xyz], []
+        ctrs = list(level1_ctr) if isinstance(level1_ctr, (list, tuple)) else [level1_ctr]
         for i, sa in enumerate(self.sa_modules):
-            geo = fused.sa_geometry(sa, levels[-1], level1_ctr if i == 0 else None)
+            geo = fused.sa_geometry(sa, levels[-1], ctrs[i] if i < len(ctrs) else None)
             sa_geo.append(geo)
             levels.append(geo["new_xyz"])
         fp_geo, sparse = [], levels[-1]

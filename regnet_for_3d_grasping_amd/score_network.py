@@ -23,6 +23,10 @@ class ScoreNetwork(nn.Module):
         """Level-1 FPS indices for ``pc``; see PointNet2Seg.sample_level1."""
         return self.extrat_featurePN2.sample_level1(pc[:, :, :6].permute(0, 2, 1))
 
+    def sample_levels(self, pc):
+        """FPS indices of every set-abstraction level for ``pc``; see PointNet2Seg.sample_levels."""
+        return self.extrat_featurePN2.sample_levels(pc[:, :, :6].permute(0, 2, 1))
+
     def plan(self, pc, level1_ctr=None):
         """Geometry plan (sampling / grouping / 3-NN indices) for ``pc``; see PointNet2Seg.plan."""
         return self.extrat_featurePN2.plan(pc[:, :, :6].permute(0, 2, 1), level1_ctr)
