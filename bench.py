@@ -504,6 +504,7 @@ def main():
                                    ", %d-pt synthetic scenes, batch=%d per GPU, eval" % (args.points, args.batch),
                        "points": args.points, "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                        "parallelism": "scene-sharded x%d (no data-path collective)" % world,
+                       "sampling_group_batches": args.fps_group or max(1, min(8, 64 // max(1, args.batch))),
                        "scorenet_gflop_per_scene": SCORENET_GFLOP_PER_SCENE.get(args.points),
                        "executed_gflop_per_scene": round(sum(f["units"] for f in fam.values() if f["bound"] == "mfma")
                                                          / 1e9 / max(args.steps * args.batch, 1), 2)},
