@@ -100,6 +100,12 @@ class ForwardPipeline:
         self.s_mlp = self.s_mlps[0]
         self._n_featured = 0
         self.s_reg = torch.cuda.Stream(dev, priority=-1)
+        # The HIP runtime binds a stream to a hardware queue when its handle is first used, in order of first use, and the
+        # binding matters: with the feature stream bound FIRST (e.g. a caller reading ``s_mlp.cuda_stream`` before the first
+        # ``run``) a step takes 9.1 ms instead of 8.4 (scripts/stream_order_probe.py).  Bind them here, in the order the
+        # first ``run`` would: sampling, features, geometry, region.
+        for s in tuple(self.s_fps) + tuple(self.s_mlps) + (self.s_geo, self.s_reg):
+            _ = s.cuda_stream
 
     # -- stages -------------------------------------------------------------------------------
     def _sample_group(self, pcs):

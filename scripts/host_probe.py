@@ -12,8 +12,8 @@ pc = synthetic.make_batch(1000, 8, 25600)
 synthetic.calibrate_score_head(score_net, pc.to(dev))
 pc = pc.to(dev)
 pipe = pipeline.ForwardPipeline(score_net, region_net)
-log = {"late": 0, "n": 0, "t": {"sample": 0.0, "geometry": 0.0, "features": 0.0}, "prev": None}
-for name in ("_sample", "_geometry", "_features"):
+log = {"late": 0, "n": 0, "t": {"sample_group": 0.0, "geometry": 0.0, "features": 0.0}, "prev": None}
+for name in ("_sample_group", "_geometry", "_features"):
     fn = getattr(pipe, name)
     def timed(item, fn=fn, name=name):
         t0 = time.perf_counter()
