@@ -248,11 +248,15 @@ class ForwardPipeline:
             it = iter(batches)
             exhausted = False
             group = self.fps_group
+            first_launch = True
             while True:
                 # keep the sampling ahead: a new group launch when at most one group's worth of sampled batches is left
                 while not exhausted and (group <= 0 or len(sampled) <= group):
                     pcs = []
-                    while group <= 0 or len(pcs) < group:
+                    # the very first launch finds the chip idle (nothing can run before its result): it takes up to a
+                    # CU's worth of scenes per CU, i.e. four groups
+                    want = 4 * group if first_launch else group
+                    while group <= 0 or len(pcs) < want:
                         try:
                             pcs.append(next(it))
                         except StopIteration:
@@ -260,8 +264,10 @@ class ForwardPipeline:
                             break
                         if group <= 0:
                             group = max(1, min(8, 64 // max(1, pcs[0].shape[0])))
+                            want = 4 * group if first_launch else group
                     if pcs:
                         sampled.extend(self._sample_group(pcs))
+                        first_launch = False
                 if not sampled and st_geo is None:
                     break
                 # enqueue the asynchronous stages, deepest look-ahead first
