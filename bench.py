@@ -491,6 +491,16 @@ def main():
         kernels = [{"op": k[0], "shape": k[1], "calls": c, "avg_ms": round(tot / c, 4), "total_ms": round(tot, 3)}
                    for k, (tot, c) in by_time]
         fam, roofline = roofline_of(agg, args.steps, args.batch, timer.critical if timer.critical_streams is not None else None)
+        if roofline and roofline["kernel"] == "sa_chain_kernel":
+            # the level-1 chain skips the second point tile of neighbourhoods with <= 32 members (their slots 32..63 repeat
+            # slot 0): "achieved" counts the ALGORITHMIC flops (all 64 slots, what the reference multiplies); say how much of
+            # it the matrix pipe really executes on these scenes (layers 2-3 are 49152 / 49920 of the block's flops)
+            with torch.no_grad():
+                count = score_net.plan(pc)["sa"][0].get("count")
+            if count is not None:
+                small = float((count <= 32).float().mean())
+                roofline["executed_share_of_algorithmic_flops"] = round(1.0 - 0.5 * small * 49152.0 / 49920.0, 4)
+                roofline["frac_executed"] = round(roofline["frac"] * roofline["executed_share_of_algorithmic_flops"], 4)
         if roofline and args.mlp_streams > 1:
             roofline["concurrency"] = ("%d feature-stage streams: launches of this family overlap each other, so the launch "
                                        "duration above (what rocprofv3 shows too) includes time-sharing; roofline_exclusive "
