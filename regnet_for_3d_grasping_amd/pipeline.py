@@ -248,23 +248,29 @@ class ForwardPipeline:
             it = iter(batches)
             exhausted = False
             group = self.fps_group
-            first_launch = True
+            first_launch, first_want = True, 0
             while True:
                 # keep the sampling ahead: a new group launch when at most one group's worth of sampled batches is left
-                while not exhausted and (group <= 0 or len(sampled) <= group):
+                while not exhausted and (first_want <= 0 or len(sampled) <= group):
                     pcs = []
                     # the very first launch finds the chip idle (nothing can run before its result): it takes up to a
                     # CU's worth of scenes per CU, i.e. four groups
-                    want = 4 * group if first_launch else group
-                    while group <= 0 or len(pcs) < want:
+                    want = first_want if first_launch else group
+                    while first_want <= 0 or len(pcs) < want:
                         try:
                             pcs.append(next(it))
                         except StopIteration:
                             exhausted = True
                             break
-                        if group <= 0:
-                            group = max(1, min(8, 64 // max(1, pcs[0].shape[0])))
-                            want = 4 * group if first_launch else group
+                        if first_want <= 0:
+                            # scenes one launch may hold: a scene beyond 25 600 points samples on 2-4 cooperating
+                            # workgroups (csrc/geometry.hip: fps_multi_kernel), and all of a launch's must be resident
+                            B0, N0 = max(1, pcs[0].shape[0]), pcs[0].shape[1]
+                            cap = max(B0, 256 // max(1, -(-N0 // 25600)))
+                            if group <= 0:
+                                group = max(1, min(8, min(64, cap) // B0))
+                            first_want = max(group, min(4 * group, cap // B0))
+                            want = first_want if first_launch else group
                     if pcs:
                         sampled.extend(self._sample_group(pcs))
                         first_launch = False
