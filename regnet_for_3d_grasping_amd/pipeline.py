@@ -45,7 +45,8 @@ def forward_scenes(score_net, region_net, pc, with_region=True):
         with contextlib.redirect_stdout(io.StringIO()):
             res = region_net(g, gm, g_idx, gm_idx, center_pc, center_idx, pc, all_feature, GRIPPER_PARAMS, None, [])
     out.update(center_pc_index=center_idx, pc_group_index=g_idx, pc_group_more_index=gm_idx, next_grasp=res[0],
-               select_grasp_class=res[6], select_grasp_score=res[7], final_mask=res[11])
+               keep_per_scene=res[1], true_mask=res[2], select_grasp_class=res[6], select_grasp_score=res[7],
+               final_mask=res[11])
     return out
 
 
@@ -184,8 +185,8 @@ class ForwardPipeline:
                     res = self.region_net(g, gm, g_idx, gm_idx, center_pc, center_idx, pc, all_feature,
                                           GRIPPER_PARAMS, None, [])
                 out.update(center_pc_index=center_idx, pc_group_index=g_idx, pc_group_more_index=gm_idx,
-                           next_grasp=res[0], select_grasp_class=res[6], select_grasp_score=res[7],
-                           final_mask=res[11])
+                           next_grasp=res[0], keep_per_scene=res[1], true_mask=res[2], select_grasp_class=res[6],
+                           select_grasp_score=res[7], final_mask=res[11])
             done = torch.cuda.Event()
             done.record(self.s_reg)
         if not self.with_region:

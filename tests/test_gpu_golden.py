@@ -11,7 +11,10 @@ from . import golden_util as gu
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-TOL = dict(rtol=1e-4, atol=1e-4)
+# north_star's bound is ABSOLUTE: outputs (scores, grasp tuples, class-1 grasps) within 1e-4 of the reference, no relative
+# slack.  The 256-channel feature map is an intermediate with magnitudes up to ~10: it keeps a bound relative to its size.
+TOL = dict(rtol=0.0, atol=1e-4)
+TOL_FEATURE = dict(rtol=1e-4, atol=1e-4)
 
 
 def test_s1_scorenet_on_gpu(monkeypatch):
@@ -26,7 +29,7 @@ def test_s1_scorenet_on_gpu(monkeypatch):
     if rec.log:  # op-granular path: every index tensor must match the reference bit for bit
         rec.check_against(m["s1_ops"])
     np.testing.assert_allclose(score.cpu().numpy(), exp["score"], **TOL)
-    np.testing.assert_allclose(all_feature[:, ::64, :].cpu().numpy(), exp["feature_sample"], **TOL)
+    np.testing.assert_allclose(all_feature[:, ::64, :].cpu().numpy(), exp["feature_sample"], **TOL_FEATURE)
 
 
 def test_s1_scorenet_unfused_ops_on_gpu(monkeypatch):
@@ -42,7 +45,7 @@ def test_s1_scorenet_unfused_ops_on_gpu(monkeypatch):
         all_feature, score, _ = net(gu.scenes(m["cfg"], DEV))
     rec.check_against(m["s1_ops"])
     np.testing.assert_allclose(score.cpu().numpy(), exp["score"], **TOL)
-    np.testing.assert_allclose(all_feature[:, ::64, :].cpu().numpy(), exp["feature_sample"], **TOL)
+    np.testing.assert_allclose(all_feature[:, ::64, :].cpu().numpy(), exp["feature_sample"], **TOL_FEATURE)
 
 
 def _s2(m, pc):
@@ -145,4 +148,4 @@ def test_scorenet_dense_scene_51200_points():
         feat, score, _ = gpu_net(pc.to(DEV))
     assert tuple(feat.shape) == (1, 51200, 256)
     np.testing.assert_allclose(score.cpu().numpy(), score_ref.numpy(), **TOL)
-    np.testing.assert_allclose(feat[:, ::97, :].cpu().numpy(), feat_ref[:, ::97, :].numpy(), **TOL)
+    np.testing.assert_allclose(feat[:, ::97, :].cpu().numpy(), feat_ref[:, ::97, :].numpy(), **TOL_FEATURE)

@@ -12,7 +12,10 @@ from . import golden_util as gu
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-TOL = dict(rtol=1e-4, atol=1e-4)
+# north_star's bound is ABSOLUTE: outputs (scores, grasp tuples, class-1 grasps) within 1e-4 of the reference, no relative
+# slack.  The 256-channel feature map is an intermediate with magnitudes up to ~10: it keeps a bound relative to its size.
+TOL = dict(rtol=0.0, atol=1e-4)
+TOL_FEATURE = dict(rtol=1e-4, atol=1e-4)
 
 
 def _scenes_a(m):
@@ -33,7 +36,7 @@ def test_s7a_scorenet_batch4_25600_fused(monkeypatch):
     err = float(np.abs(score.cpu().numpy() - exp["score"]).max())
     print("s7a score max abs err vs reference: %.3e" % err)
     np.testing.assert_allclose(score.cpu().numpy(), exp["score"], **TOL)
-    np.testing.assert_allclose(all_feature[:, ::m["cfg"]["feature_stride_a"], :].cpu().numpy(), exp["feature_sample"], **TOL)
+    np.testing.assert_allclose(all_feature[:, ::m["cfg"]["feature_stride_a"], :].cpu().numpy(), exp["feature_sample"], **TOL_FEATURE)
 
 
 def test_s7a_single_scene_batch1(monkeypatch):
@@ -68,7 +71,7 @@ def test_s7a_config1_score_only_pipeline():
     stride = m["cfg"]["feature_stride_a"]
     for o, out in zip(order, outs):
         np.testing.assert_allclose(out["score"].cpu().numpy(), exp["score"][o], **TOL)
-        np.testing.assert_allclose(out["all_feature"][:, ::stride, :].cpu().numpy(), exp["feature_sample"][o], **TOL)
+        np.testing.assert_allclose(out["all_feature"][:, ::stride, :].cpu().numpy(), exp["feature_sample"][o], **TOL_FEATURE)
 
 
 def test_s7b_scorenet_51200(monkeypatch):
@@ -83,7 +86,7 @@ def test_s7b_scorenet_51200(monkeypatch):
         all_feature, score, _ = net(synthetic.make_batch(b["scene_seed"], b["B"], b["N"]).to(DEV))
     gu.check_ops_per_scene(rec.log, m["s7b_ops"], [0])
     np.testing.assert_allclose(score.cpu().numpy(), exp["score"], **TOL)
-    np.testing.assert_allclose(all_feature[:, ::m["cfg"]["feature_stride_b"], :].cpu().numpy(), exp["feature_sample"], **TOL)
+    np.testing.assert_allclose(all_feature[:, ::m["cfg"]["feature_stride_b"], :].cpu().numpy(), exp["feature_sample"], **TOL_FEATURE)
 
 
 def test_s7c_region_stage_25600():
