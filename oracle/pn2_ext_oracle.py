@@ -26,9 +26,10 @@ def build(force=False):
     return _SO
 
 
-def _load():
-    build()
-    lib = ctypes.CDLL(_SO)
+def _load(path=None):
+    if path is None:
+        build()
+    lib = ctypes.CDLL(path or _SO)
     i64, f32, vp = ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
     lib.oracle_fps.argtypes = [vp, i64, i64, i64, vp]
     lib.oracle_ball_query.argtypes = [vp, vp, i64, i64, i64, f32, i64, vp, vp]
@@ -45,6 +46,22 @@ def _load():
 
 
 _lib = _load()
+
+
+@__import__("contextlib").contextmanager
+def fma_contracted():
+    """Measurement only (scripts/fma_sensitivity.py): inside the block the FPS / ball-query / 3-NN distances are
+    evaluated with nvcc-style FMA contraction (pn2_oracle.c: sqdist_cuda, -DORACLE_FMA_CONTRACT)."""
+    global _lib
+    so = os.path.join(_HERE, "_build", "libpn2_oracle_fma.so")
+    src = os.path.join(_HERE, "pn2_oracle.c")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "_build/libpn2_oracle_fma.so"])
+    saved, _lib = _lib, _load(so)
+    try:
+        yield
+    finally:
+        _lib = saved
 
 
 def _check(rc, what):

@@ -44,6 +44,25 @@ static inline float sqdist(float ax, float ay, float az, float bx, float by, flo
 }
 
 /*
+ * The distance expression of the three CUDA kernels (sampling_kernel.cu:82, ball_query_kernel.cu:60,
+ * interpolate_kernel.cu:56):  dx*dx + dy*dy + dz*dz.  Canonical build: identical to sqdist().
+ * -DORACLE_FMA_CONTRACT (second, test-only build: _build/libpn2_oracle_fma.so) evaluates it the way nvcc's default
+ * -fmad=true contracts that source line -- one rounded product, then two fused multiply-adds,
+ *     d = fma(dz, dz, fma(dy, dy, dx*dx))
+ * -- which this container cannot observe (no nvcc, no CUDA device).  It exists ONLY to measure how many of the
+ * discrete outputs the other convention moves (scripts/fma_sensitivity.py -> DESIGN.md par. 3); no test, no product
+ * path and no fixture uses it.
+ */
+static inline float sqdist_cuda(float ax, float ay, float az, float bx, float by, float bz) {
+#ifdef ORACLE_FMA_CONTRACT
+  float dx = ax - bx, dy = ay - by, dz = az - bz;
+  return fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+#else
+  return sqdist(ax, ay, az, bx, by, bz);
+#endif
+}
+
+/*
  * Furthest point sampling.  csrc/sampling_kernel.cu:47-117 (kernel), :126-170 (host).
  * points (B,N,3) contiguous, index (B,M).  The reference launches `block` threads per
  * scene (block = ref_block(N), min 16 through the switch at :148-165); thread t scans
@@ -71,7 +90,7 @@ int oracle_fps(const float* points, int64_t B, int64_t N, int64_t M, int64_t* in
         float max_dist = 0.0f;
         int32_t max_ind = cur;
         for (int64_t j = t; j < N; j += block) {
-          float d = sqdist(p[j * 3 + 0], p[j * 3 + 1], p[j * 3 + 2], x1, y1, z1);
+          float d = sqdist_cuda(p[j * 3 + 0], p[j * 3 + 1], p[j * 3 + 2], x1, y1, z1);
           float last = temp[j];
           if (last > d || last < 0) temp[j] = d; else d = last; /* :84-88 */
           if (d > max_dist) { max_dist = d; max_ind = (int32_t)j; }
@@ -111,7 +130,7 @@ int oracle_ball_query(const float* points, const float* centroids, int64_t B, in
       int64_t cnt = 0;
       for (int64_t j = 0; j < N1 && cnt < K; ++j) {
         /* reference computes (x2-x1): point minus centroid */
-        float d = sqdist(p[j * 3 + 0], p[j * 3 + 1], p[j * 3 + 2], x1, y1, z1);
+        float d = sqdist_cuda(p[j * 3 + 0], p[j * 3 + 1], p[j * 3 + 2], x1, y1, z1);
         if (d < r2) {
           if (cnt == 0) { for (int64_t k = 0; k < K; ++k) out[k] = j; }
           else out[cnt] = j;
@@ -144,7 +163,7 @@ int oracle_three_nn(const float* query, const float* key, int64_t B, int64_t N1,
       int32_t mi[3] = {-1, 0, 0};
       for (int64_t j = 0; j < N2; ++j) {
         /* reference computes (x1-x2): query minus key */
-        float d = sqdist(x1, y1, z1, kx[j * 3 + 0], kx[j * 3 + 1], kx[j * 3 + 2]);
+        float d = sqdist_cuda(x1, y1, z1, kx[j * 3 + 0], kx[j * 3 + 1], kx[j * 3 + 2]);
         for (int k = 0; k < 3; ++k) {
           if (d < md[k]) {
             for (int l = 2; l > k; --l) { md[l] = md[l - 1]; mi[l] = mi[l - 1]; }
