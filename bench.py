@@ -57,7 +57,13 @@ def parse():
     ap.add_argument("--mlp-streams", type=int, default=1, help="feature-stage streams (batches whose MFMA kernels may overlap): 2 is ~6 %% faster (875 scenes/s) but "
                          "time-shares the launches, so per-kernel durations stop being a kernel property (DESIGN.md par. 7)")
     ap.add_argument("--fps-streams", type=int, default=2, help="level-1 sampling launches in flight")
-    ap.add_argument("--fps-group", type=int, default=0, help="batches whose level-1 sampling shares one launch (0: 32 scenes' worth)")
+    ap.add_argument("--fps-group", type=int, default=0, help="batches whose level-1..3 sampling shares one launch (0: 64 scenes' worth, at most 8 batches)")
+    ap.add_argument("--first-launch-groups", type=int, default=4,
+                    help="sampling groups the FIRST sampling launch of a run takes (it finds the chip idle); the line reports "
+                         "the resulting look-ahead (config.sampling_lookahead_batches) and value_no_lookahead beside the headline")
+    ap.add_argument("--no-lookahead-steps", type=int, default=20,
+                    help="steps of the extra pass AFTER the timed region with one sampling launch per batch and no enlarged "
+                         "first launch (value_no_lookahead); 0 = skip")
     ap.add_argument("--lookahead", type=int, default=3, help="batches whose region stage may be pending (pipeline depth)")
     return ap.parse_args()
 
@@ -420,7 +426,8 @@ def main():
     # and the region stage of the previous one on three HIP streams (all work of the K timed
     # steps happens inside the timed region; the pipeline drains before the closing fence).
     pipe = pipeline.ForwardPipeline(score_net, region_net, with_region=not args.score_only, fps_streams=args.fps_streams,
-                                    mlp_streams=args.mlp_streams, fps_group=args.fps_group)
+                                    mlp_streams=args.mlp_streams, fps_group=args.fps_group,
+                                    first_launch_groups=args.first_launch_groups)
 
     def run_steps(n):
         last = None
@@ -447,6 +454,24 @@ def main():
     timer.enabled = False
     main_summary = timer.summary() if rank == 0 else None
     dt = sharding.max_over_ranks(dt, dev)
+    first_launch_batches = pipe.first_launch_batches
+
+    no_lookahead = None
+    if world == 1 and args.no_lookahead_steps > 0:
+        # the same steps with ONE sampling launch per batch and a first launch like every other (the pipeline then reads
+        # 3-4 batches ahead instead of up to 32): what the grouped sampling + enlarged first launch are worth, same
+        # process, same scenes, outside the timed region
+        pipe0 = pipeline.ForwardPipeline(score_net, region_net, with_region=not args.score_only,
+                                         fps_streams=args.fps_streams, mlp_streams=args.mlp_streams, fps_group=1,
+                                         first_launch_groups=1)
+        for _ in pipe0.run((pc for _ in range(max(2, args.warmup))), max_pending_regions=args.lookahead):
+            pass
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in pipe0.run((pc for _ in range(args.no_lookahead_steps)), max_pending_regions=args.lookahead):
+            pass
+        torch.cuda.synchronize()
+        no_lookahead = args.batch * args.no_lookahead_steps / (time.perf_counter() - t1)
 
     exclusive = None
     if args.mlp_streams > 1 and world == 1 and args.exclusive_steps > 0:
@@ -516,12 +541,19 @@ def main():
                        "points": args.points, "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                        "parallelism": "scene-sharded x%d (no data-path collective)" % world,
                        "sampling_group_batches": args.fps_group or max(1, min(8, 64 // max(1, args.batch))),
+                       # batches the pipeline pulled from its input before the first result could exist (the first sampling
+                       # launch of the timed run); steady state: up to 2 x sampling_group_batches
+                       "sampling_lookahead_batches": first_launch_batches,
                        "scorenet_gflop_per_scene": SCORENET_GFLOP_PER_SCENE.get(args.points),
                        "executed_gflop_per_scene": round(sum(f["units"] for f in fam.values() if f["bound"] == "mfma")
                                                          / 1e9 / max(args.steps * args.batch, 1), 2)},
             "roofline": roofline,
             "roofline_exclusive": None,
             "latency_ms_single_scene": latency_ms,
+            "value_no_lookahead": None if no_lookahead is None else round(no_lookahead, 3),
+            "value_no_lookahead_note": None if no_lookahead is None else (
+                "%d steps after the timed region, --fps-group 1 --first-launch-groups 1 (one sampling launch per batch, "
+                "look-ahead 3-4 batches)" % args.no_lookahead_steps),
             "mlp_tflops": round(SCORENET_GFLOP_PER_SCENE.get(args.points, 0.0) * total_scenes / world / dt / 1e3, 3),
             "kernels": kernels[:40],
             "grasps_last_step": int(out["next_grasp"].shape[0]) if "next_grasp" in out else None,

@@ -2,7 +2,6 @@
 (the step of test.py:134-141 / train.py:358-367 without losses), as one callable used by
 bench.py, smoke() and the tests."""
 import contextlib
-import os
 import io
 
 import torch
@@ -50,10 +49,14 @@ def forward_scenes(score_net, region_net, pc, with_region=True):
     return out
 
 
-# Timing experiments only (scripts/, never set by the package): "fps" reuses the first batch's level-1 sampling, "plan" its
-# whole geometry, for every later batch -- the results are then WRONG; it measures what those stages cost the others.
-_DEBUG_REUSE = os.environ.get("REGNET_DEBUG_REUSE_GEOMETRY", "")
-_SAMPLE_ALL_LEVELS = os.environ.get("REGNET_PIPE_SAMPLE_LEVELS", "all") != "1"   # "1": only level 1 in the grouped launch (A/B)
+SINGLE_CU_POINTS = 25600   # largest scene whose furthest point sampling runs on ONE workgroup (csrc/geometry.hip)
+NUM_CUS = 256              # MI355X
+
+
+def sampling_workgroups_per_scene(num_points):
+    """Workgroups (= whole CUs) one scene's level-1 sampling holds: 1 up to 25 600 points, else 2-4 COOPERATING workgroups
+    (fps_multi_kernel) that exchange a word per round and therefore must all be resident at the same time."""
+    return max(1, -(-int(num_points) // SINGLE_CU_POINTS))
 
 
 class ForwardPipeline:
@@ -78,10 +81,16 @@ class ForwardPipeline:
     RNG call order: region stages execute in batch order on the host thread).
     """
 
-    def __init__(self, score_net, region_net, with_region=True, fps_streams=2, mlp_streams=1, fps_group=0):
+    def __init__(self, score_net, region_net, with_region=True, fps_streams=2, mlp_streams=1, fps_group=0,
+                 first_launch_groups=1):
         """``fps_streams``: level-1 sampling launches in flight (each ~10 ms on one CU per scene, whatever the batch
         size).  ``fps_group``: consecutive batches whose level-1 sampling shares one launch (0: as many as give 64 scenes,
         at most 8): +6 % at 8 scenes per batch, +12-15 % at 1 and 4, at the price of reading that many batches ahead.
+        ``first_launch_groups``: the FIRST sampling launch of a ``run`` finds the chip idle (nothing can start before its
+        result) and may take this many groups at once (bench.py passes 4: all of a short run's batches are then sampled in
+        one launch); the library default is 1.  INPUT-LATENCY CONTRACT: ``run`` pulls up to
+        ``first_launch_groups x group`` batches from its iterator before it yields the first result and stays up to
+        ``2 x group`` batches ahead afterwards -- with a live source (camera, data loader) use ``fps_group=1``.
         ``mlp_streams``: feature stages (consecutive batches) that may overlap.  One batch's ~30 MFMA launches leave the
         chip partly idle at every kernel tail and in the small layers (P <= 40 960 rows); a second stream fills those
         holes with the next batch's kernels: 9.70 -> 9.14 ms per batch of 8 (824 -> 875 scenes/s) with
@@ -90,6 +99,9 @@ class ForwardPipeline:
         depends on what the other stream happens to run, and a profiler perturbs exactly that."""
         self.score_net, self.region_net, self.with_region = score_net, region_net, with_region
         self.fps_group = int(fps_group)   # batches whose level-1 sampling shares one launch; 0 = as many as give 64 scenes (<= 8)
+        self.first_launch_groups = max(1, int(first_launch_groups))
+        self.first_launch_batches = None  # what the first sampling launch of the last ``run`` really took (bench.py reports it)
+        self._one_sampling_stream = False
         dev = next(score_net.parameters()).device
         self.device = dev
         # Priorities: FPS and the region stage are chains of small / single-CU kernels (the latter
@@ -117,18 +129,14 @@ class ForwardPipeline:
         CUs (one per XCD) cost the matrix kernels as much as 32 (one per engine) -- 12.5 %, measured (DESIGN.md par. 10).
         So the sampling of up to 64 scenes (two per engine) goes into one launch: the same cost while it runs, but it runs
         an eighth of the time."""
-        stream = self.s_fps[self._n_sampled % len(self.s_fps)]
+        # scenes beyond one CU's register file sample on cooperating workgroups that must ALL be resident: such launches
+        # stay on ONE stream (stream order = never two of them in flight), see ``run``
+        stream = self.s_fps[0 if self._one_sampling_stream else self._n_sampled % len(self.s_fps)]
         self._n_sampled += 1
-        B = pcs[0].shape[0]
         with torch.cuda.stream(stream), torch.no_grad():
-            if _DEBUG_REUSE and getattr(self, "_dbg_ctr", None) is not None:
-                ctr = [c.repeat(len(pcs), 1) for c in self._dbg_ctr]
-            else:
-                # all three sampling levels: the level-2 / level-3 launches hold a CU per scene too (1.3 + 0.5 ms)
-                big = pcs[0] if len(pcs) == 1 else torch.cat(pcs, 0)
-                ctr = self.score_net.sample_levels(big) if _SAMPLE_ALL_LEVELS else [self.score_net.sample_level1(big)]
-                if _DEBUG_REUSE:
-                    self._dbg_ctr = [c[:B].clone() for c in ctr]
+            # all three sampling levels: the level-2 / level-3 launches hold a CU per scene too (1.3 + 0.5 ms)
+            big = pcs[0] if len(pcs) == 1 else torch.cat(pcs, 0)
+            ctr = self._sample(big)
             done = torch.cuda.Event()
             done.record(stream)
         for c in ctr:
@@ -141,16 +149,19 @@ class ForwardPipeline:
             at += pc.shape[0]
         return items
 
+    def _sample(self, big):
+        """Sampled centroid indices of every level for the concatenated scenes (overridden by timing harnesses under
+        scripts/ only)."""
+        return self.score_net.sample_levels(big)
+
+    def _plan(self, pc, ctr):
+        return self.score_net.plan(pc, ctr)
+
     def _geometry(self, item):
         from . import fused
         with torch.cuda.stream(self.s_geo), torch.no_grad():
             self.s_geo.wait_event(item["fps_done"])
-            if _DEBUG_REUSE == "plan" and getattr(self, "_dbg_plan", None) is not None:
-                plan = self._dbg_plan
-            else:
-                plan = self.score_net.plan(item["pc"], item["ctr"])
-                if _DEBUG_REUSE == "plan":
-                    self._dbg_plan = plan
+            plan = self._plan(item["pc"], item["ctr"])
             done = torch.cuda.Event()
             done.record(self.s_geo)
         for t in fused.plan_tensors(plan):
@@ -250,12 +261,14 @@ class ForwardPipeline:
             exhausted = False
             group = self.fps_group
             first_launch, first_want = True, 0
+            self.first_launch_batches = None
             while True:
-                # keep the sampling ahead: a new group launch when at most one group's worth of sampled batches is left
-                while not exhausted and (first_want <= 0 or len(sampled) <= group):
+                # keep the sampling ahead: a new group launch when less than one group's worth of sampled batches is left
+                # (strictly less: the first launch is never followed by a second one straight away)
+                while not exhausted and (first_want <= 0 or len(sampled) < group):
                     pcs = []
-                    # the very first launch finds the chip idle (nothing can run before its result): it takes up to a
-                    # CU's worth of scenes per CU, i.e. four groups
+                    # the very first launch finds the chip idle (nothing can run before its result): it may take
+                    # ``first_launch_groups`` groups
                     want = first_want if first_launch else group
                     while first_want <= 0 or len(pcs) < want:
                         try:
@@ -264,15 +277,25 @@ class ForwardPipeline:
                             exhausted = True
                             break
                         if first_want <= 0:
-                            # scenes one launch may hold: a scene beyond 25 600 points samples on 2-4 cooperating
-                            # workgroups (csrc/geometry.hip: fps_multi_kernel), and all of a launch's must be resident
+                            # scenes one launch may hold.  A scene beyond 25 600 points samples on G = 2-4 COOPERATING
+                            # workgroups (csrc/geometry.hip: fps_multi_kernel) that spin on each other's words: every
+                            # workgroup of every such launch IN FLIGHT must be resident, or two half-resident launches
+                            # wait for each other's CUs for ever.  So with G > 1: one sampling stream (launches are
+                            # serialised by stream order) and a launch leaves room for the only other cooperative
+                            # launch that can run beside it -- the region stage's centre picker over the positives of
+                            # ONE batch (at most B0 x G workgroups on its own stream).
                             B0, N0 = max(1, pcs[0].shape[0]), pcs[0].shape[1]
-                            cap = max(B0, 256 // max(1, -(-N0 // 25600)))
+                            G = sampling_workgroups_per_scene(N0)
+                            self._one_sampling_stream = G > 1
+                            cap = NUM_CUS if G == 1 else max(B0, (NUM_CUS - B0 * G) // G)
                             if group <= 0:
                                 group = max(1, min(8, min(64, cap) // B0))
-                            first_want = max(group, min(4 * group, cap // B0))
+                            group = max(1, min(group, max(1, cap // B0)))
+                            first_want = max(group, min(self.first_launch_groups * group, cap // B0))
                             want = first_want if first_launch else group
                     if pcs:
+                        if first_launch:
+                            self.first_launch_batches = len(pcs)
                         sampled.extend(self._sample_group(pcs))
                         first_launch = False
                 if not sampled and st_geo is None:

@@ -11,7 +11,7 @@ python scripts/side_load_micro.py 2>&1 | grep -v amdgpu > $out/${tag}_dispatch_m
 python scripts/queue_state_probe.py 2>&1 | grep -v amdgpu > $out/${tag}_dispatch_queue_state.txt
 python scripts/clock_under_load.py 2>&1 | grep -v amdgpu > $out/${tag}_dispatch_clock.txt
 { echo "== alone"; python scripts/bench_gemm2_layers.py 2>&1 | grep -v amdgpu; echo "== 8 CUs held (one per XCD)"; SIDE_BLOCKS=8 python scripts/bench_gemm2_layers.py 2>&1 | grep -v amdgpu; } > $out/${tag}_dispatch_gemm2_layers.txt
-for v in none fps plan; do REGNET_DEBUG_REUSE_GEOMETRY=$( [ $v = none ] || echo $v ) python bench.py --cpu-scenes 0 --latency-runs 0 2>/dev/null | python -c "
+for v in none fps plan; do { if [ $v = none ]; then python bench.py --cpu-scenes 0 --latency-runs 0; else python scripts/reuse_geometry_bench.py $v --cpu-scenes 0 --latency-runs 0; fi; } 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']
 print('geometry reuse = $v: %.3f ms per step, %s frac %.3f (%.3f ms per launch)' % (d['ms_per_step'], r['kernel'], r['frac'], r['avg_launch_ms']))"; done > $out/${tag}_dispatch_pipeline_without_sampling.txt

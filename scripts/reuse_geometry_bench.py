@@ -1,0 +1,42 @@
+#!/usr/bin/env python
+"""TIMING EXPERIMENT ONLY -- the results of this run are WRONG on purpose.  bench.py with a pipeline whose batches after
+the first reuse the first batch's level-1..3 sampling ("fps") or its whole geometry plan ("plan"): measures what those
+stages cost the feature stage (DESIGN.md par. 10).  The product package has no such switch; this harness subclasses it.
+
+    python scripts/reuse_geometry_bench.py fps|plan [bench.py arguments]
+"""
+import os
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+mode = sys.argv.pop(1)
+assert mode in ("fps", "plan")
+
+from regnet_for_3d_grasping_amd import pipeline  # noqa: E402
+
+
+class ReusePipeline(pipeline.ForwardPipeline):
+    _ctr = None
+    _first_plan = None
+
+    def _sample(self, big):
+        if self._ctr is None:
+            self._ctr = [c[:self._b0].clone() for c in super()._sample(big)]
+        return [c.repeat(big.shape[0] // self._b0, 1) for c in self._ctr]
+
+    def _sample_group(self, pcs):
+        self._b0 = pcs[0].shape[0]
+        return super()._sample_group(pcs)
+
+    def _plan(self, pc, ctr):
+        if mode != "plan":
+            return super()._plan(pc, ctr)
+        if self._first_plan is None:
+            self._first_plan = super()._plan(pc, ctr)
+        return self._first_plan
+
+
+pipeline.ForwardPipeline = ReusePipeline
+import bench  # noqa: E402
+bench.main()

@@ -52,7 +52,7 @@ class _Recorder:
                 self.cursor[key] = at + outs[0].shape[0]
                 rows = self.seen.setdefault(key, [])
                 for i in range(outs[0].shape[0]):
-                    aux = gu.sha(outs[1][i]) if name == "ball_query" else None
+                    aux = gu.sha(outs[1][i]) if len(outs) > 1 else None   # ball-query counts / 3-NN squared distances
                     rows.append((self.flat[at + i], gu.sha(outs[0][i]), aux))
             return out
         return wrapped
