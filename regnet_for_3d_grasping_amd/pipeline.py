@@ -263,9 +263,10 @@ class ForwardPipeline:
             first_launch, first_want = True, 0
             self.first_launch_batches = None
             while True:
-                # keep the sampling ahead: a new group launch when less than one group's worth of sampled batches is left
-                # (strictly less: the first launch is never followed by a second one straight away)
-                while not exhausted and (first_want <= 0 or len(sampled) < group):
+                # keep the sampling ahead: a new group launch when at most one group's worth of sampled batches is left (a
+                # launch is a ~10 ms latency chain, longer than a step: with one batch per launch two must be in flight).
+                # Cooperative launches (scenes beyond 25 600 points) share one stream, so two of THEM never overlap.
+                while not exhausted and (first_want <= 0 or len(sampled) <= group):
                     pcs = []
                     # the very first launch finds the chip idle (nothing can run before its result): it may take
                     # ``first_launch_groups`` groups
