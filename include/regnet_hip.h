@@ -399,6 +399,19 @@ int regnet_conv1x1_wgrad_f32(const float* dY, const float* X, float* dW, int64_t
 int regnet_np_choice_rows(uint32_t* mt_key, int32_t* mt_pos, const int32_t* counts, int64_t rows,
                           int64_t size, int mode, int64_t* out, uint8_t* valid);
 
+/* ---- the same draws ON THE DEVICE (round 3): numpy's generator state lives in device memory ------
+ * d_mt_key[624] (raw MT19937 words) / d_mt_pos[1] are np.random.get_state()[1:3] in device memory, updated in
+ * place by kernels on `stream`; d_counts (rows) int32 device; d_out (rows,size) int64 device; d_valid (rows) u8 device
+ * or NULL; semantics, row order and stream consumption exactly as regnet_np_choice_rows.  max_count bounds every
+ * count (it sizes the workspace: regnet_np_choice_rows_dev_workspace_ints(rows, max_count) int32 words; the last
+ * word is a status flag the caller may read back after the stream has drained: non-zero = a count exceeded
+ * max_count and the results are invalid).  No host synchronisation.  Replaces the same reference loops
+ * (dataset_utils/get_regiondataset.py:331-337, multi_model/gripper_region_network.py:532-544).            */
+int64_t regnet_np_choice_rows_dev_workspace_ints(int64_t rows, int64_t max_count);
+int regnet_np_choice_rows_dev(uint32_t* d_mt_key, int32_t* d_mt_pos, const int32_t* d_counts, int64_t rows,
+                              int64_t size, int64_t max_count, int mode, int64_t* d_out, uint8_t* d_valid,
+                              int32_t* d_workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

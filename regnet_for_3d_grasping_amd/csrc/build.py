@@ -26,6 +26,7 @@ SOURCES = [
     ("tgemm.hip", []),
     ("bn_train.hip", []),
     ("np_random.hip", []),
+    ("np_random_dev.hip", []),
 ]
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
           "-fno-gpu-rdc"]

@@ -1,0 +1,268 @@
+// np_random_dev.hip -- numpy's legacy MT19937 stream consumed ON THE DEVICE (gfx950).
+//
+// The reference resamples every centre's candidate list and every grasp's in-box points with np.random.choice from
+// Python loops (dataset_utils/get_regiondataset.py:331-337, multi_model/gripper_region_network.py:532-544).  Round 1-2
+// moved those draws into native HOST code (np_random.hip) -- which still cost a device->host copy of the counts, 2.6 ms
+// of host work and a host->device copy of the positions per batch, with the GPU's region stream idle meanwhile.  Here
+// the generator state lives in device memory and the draws are made by kernels, bit for bit the stream numpy would
+// produce (same algorithms as np_random.hip, which tests/test_np_random.py pins against numpy itself):
+//   choice(n, size, replace=True)  -> randint(0, n, size): per value, next_uint32 & mask until <= n - 1
+//   choice(n, size, replace=False) -> permutation(n)[:size]: Fisher-Yates from the top, j = random_interval(i)
+//                                     (next_uint32 & mask_for(i) until <= i), swap(a[i], a[j])
+// The stream is inherently serial -- a row's first word is wherever the previous row stopped, and rejection sampling
+// makes that data dependent -- so ONE workgroup walks it; what is parallel is everything inside a step:
+//   np_choice_scan_kernel (2 waves): wave 1 twists + tempers MT block b+1 (624 words, three dependent sweeps) while
+//     wave 0 scans block b, 64 words per step: acceptance flags by ballot, ranks by mbcnt, the accepted values stored
+//     by their lanes.  With replacement the flags do not depend on the state; for the shuffle they do (i shrinks by
+//     one per accepted word and the mask with it), which a fixpoint over the ballot resolves: lane p's decision only
+//     depends on the lanes before it, so iterating "flags from the previous flags' prefix counts" reaches the serial
+//     answer (lane p is final after p + 1 rounds; typically 2-3 rounds).  Shuffle rows only record their j's here;
+//   np_shuffle_rows_kernel (one wave per shuffle row, rows in parallel): plays the swaps in LDS and writes a[:size].
+// State in / out: 624 raw words + position, numpy's own layout (np.random.get_state()[1:3]).
+#include "common.h"
+
+namespace {
+constexpr int MT_N = 624;
+constexpr int MT_M = 397;
+
+__device__ __forceinline__ unsigned mt_mix(unsigned a, unsigned b) {
+  const unsigned y = (a & 0x80000000u) | (b & 0x7fffffffu);
+  return (y >> 1) ^ ((0u - (y & 1u)) & 0x9908b0dfu);
+}
+__device__ __forceinline__ unsigned mt_temper(unsigned y) {
+  y ^= (y >> 11);
+  y ^= (y << 7) & 0x9d2c5680u;
+  y ^= (y << 15) & 0xefc60000u;
+  y ^= (y >> 18);
+  return y;
+}
+__device__ __forceinline__ unsigned mask_for(unsigned m) { return m ? (0xffffffffu >> __clz(m)) : 0u; }   // 2^k - 1 >= m
+__device__ __forceinline__ int rank_below(unsigned long long bits) {   // set bits of `bits` in the lanes below mine
+  return __builtin_amdgcn_mbcnt_hi((unsigned)(bits >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bits, 0u));
+}
+__device__ __forceinline__ void wave_sync() {   // one wave: LDS executes its instructions in order; keep the compiler from reordering
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+struct ScanArgs {
+  unsigned* key; int* pos;                  // generator state, device memory, updated
+  const int* counts; long long rows; int size; int mode;
+  long long* out; unsigned char* valid;     // (rows, size) positions; (rows) or null
+  int* jbuf; long long jcap;                // the shuffle rows' accepted draws, row after row
+  int* row_joff;                            // (rows): offset of the row's draws in jbuf, -1 = not a shuffle row
+  int* status;                              // bit 0: jbuf too small (results of shuffle rows invalid)
+};
+
+enum { ROW_NONE = 0, ROW_REPLACE = 1, ROW_SHUFFLE = 2 };
+
+__global__ __launch_bounds__(128) void np_choice_scan_kernel(const ScanArgs p) {
+  __shared__ unsigned raw[2][MT_N];
+  __shared__ unsigned tmp[2][MT_N];
+  __shared__ int s_done;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int i = tid; i < MT_N; i += 128) {
+    const unsigned k = p.key[i];
+    raw[0][i] = k;
+    tmp[0][i] = mt_temper(k);
+  }
+  if (tid == 0) s_done = 0;
+  __syncthreads();
+
+  int cur = 0;
+  int pos = __builtin_amdgcn_readfirstlane(*p.pos);
+  // ---- scanner state (wave 0; everything wave-uniform)
+  long long r = 0;                 // current row
+  long long rbase = -64;           // rows [rbase, rbase + 64) are prefetched in cnt_reg
+  int cnt_reg = 0;
+  int kind = ROW_NONE, need = 0;   // accepted words the current row still wants
+  unsigned rng = 0, mask = 0;      // replace rows: n - 1 and its mask
+  int icur = 0;                    // shuffle rows: current i (n - 1 down to 1)
+  long long wr = 0;                // where the next accepted value goes (out index / jbuf index)
+  long long joff = 0;              // jbuf fill
+  const long long size = p.size;
+
+  for (;;) {
+    if (wave == 1) {
+      // ---- generator: block cur -> block cur ^ 1 (mt19937_gen of numpy's randomkit, out of place)
+      const unsigned* o = raw[cur];
+      unsigned* nw = raw[cur ^ 1];
+      for (int i = lane; i < MT_N - MT_M; i += 64) nw[i] = o[i + MT_M] ^ mt_mix(o[i], o[i + 1]);
+      wave_sync();
+      for (int i = (MT_N - MT_M) + lane; i < 2 * (MT_N - MT_M); i += 64) nw[i] = nw[i - (MT_N - MT_M)] ^ mt_mix(o[i], o[i + 1]);
+      wave_sync();
+      for (int i = 2 * (MT_N - MT_M) + lane; i < MT_N - 1; i += 64) nw[i] = nw[i - (MT_N - MT_M)] ^ mt_mix(o[i], o[i + 1]);
+      wave_sync();
+      if (lane == 0) nw[MT_N - 1] = nw[MT_M - 1] ^ mt_mix(o[MT_N - 1], nw[0]);
+      wave_sync();
+      unsigned* t = tmp[cur ^ 1];
+      for (int i = lane; i < MT_N; i += 64) t[i] = mt_temper(nw[i]);
+    } else {
+      // ---- scanner: rows consume tmp[cur][pos ..]
+      const unsigned* words = tmp[cur];
+      for (;;) {
+        while (need == 0) {          // open the next row (rows that draw nothing are finished right here)
+          if (r == p.rows) break;
+          if (r - rbase >= 64) {
+            rbase = r;
+            cnt_reg = (rbase + lane < p.rows) ? p.counts[rbase + lane] : 0;
+          }
+          const int n = __builtin_amdgcn_readlane(cnt_reg, (int)(r - rbase));
+          bool ok = true;
+          long long fill = 0;
+          kind = ROW_NONE;
+          if (p.mode == 0) {         // radius groups (get_regiondataset.py:333-337)
+            if (n >= size && n > 0) kind = ROW_SHUFFLE;
+            else if (n > 0) kind = ROW_REPLACE;
+            else { fill = -1; ok = false; }
+          } else {                   // gripper crops (gripper_region_network.py:533-544); :538 re-tests the RESAMPLED length
+            if (n > size) { kind = ROW_SHUFFLE; ok = size > 5; }
+            else if (n > 5) kind = ROW_REPLACE;
+            else ok = false;
+          }
+          if (lane == 0 && p.valid) p.valid[r] = ok ? 1 : 0;
+          int row_off = -1;
+          if (kind == ROW_SHUFFLE) {
+            if (n >= 2) {
+              need = n - 1; icur = n - 1; wr = joff; row_off = (int)joff; joff += n - 1;
+              if (joff > p.jcap) {   // cannot happen with the capacity the binding allocates; never write out of bounds
+                if (lane == 0) atomicOr(p.status, 1);
+                kind = ROW_NONE; need = 0; row_off = -1; joff -= n - 1;
+              }
+            } else {                 // permutation(1) = [0]: nothing drawn (size is 1 here)
+              kind = ROW_NONE;
+            }
+          } else if (kind == ROW_REPLACE) {
+            rng = (unsigned)(n - 1);
+            if (rng == 0) kind = ROW_NONE;          // randint(0, 1): zeros, no variates consumed
+            else { mask = mask_for(rng); need = (int)size; wr = r * size; }
+          }
+          if (lane == 0) p.row_joff[r] = row_off;
+          if (need == 0) {           // constant row
+            for (long long k = lane; k < size; k += 64) p.out[r * size + k] = fill;
+            ++r;
+          }
+        }
+        if (need == 0) break;        // all rows done
+        if (pos >= MT_N) break;      // block exhausted
+        const int idx = pos + lane;
+        const bool in = idx < MT_N;
+        const unsigned w = in ? words[idx] : 0u;
+        unsigned v;
+        bool ok;
+        unsigned long long acc;
+        if (kind == ROW_REPLACE) {
+          v = w & mask;
+          ok = in && v <= rng;
+          acc = __ballot(ok);
+        } else {
+          // i falls by one per accepted word (and the mask with it): iterate to the serial answer
+          unsigned long long prev = 0ull;
+          for (;;) {
+            const int ip = icur - rank_below(prev);
+            v = w & mask_for(ip > 0 ? (unsigned)ip : 0u);
+            ok = in && ip >= 1 && v <= (unsigned)ip;
+            acc = __ballot(ok);
+            if (acc == prev) break;
+            prev = acc;
+          }
+        }
+        int cnt = __popcll(acc);
+        int used = MT_N - pos < 64 ? MT_N - pos : 64;       // words this step consumes
+        const int rk = rank_below(acc);
+        if (cnt >= need) {                                   // the row ends inside this step: at its need-th accepted word
+          const unsigned long long last = __ballot(ok && rk == need - 1);
+          const int e = __builtin_ctzll(last);
+          acc &= (e == 63) ? ~0ull : ((1ull << (e + 1)) - 1ull);
+          cnt = need;
+          used = e + 1;
+        }
+        if ((acc >> lane) & 1ull) {
+          if (kind == ROW_REPLACE) p.out[wr + rk] = (long long)v;
+          else p.jbuf[wr + rk] = (int)v;
+        }
+        wr += cnt; need -= cnt; icur -= cnt; pos += used;
+        if (need == 0) ++r;
+      }
+      if (need == 0 && r == p.rows && lane == 0) s_done = 1;
+    }
+    __syncthreads();
+    if (s_done) break;
+    cur ^= 1;
+    pos = 0;
+  }
+  for (int i = tid; i < MT_N; i += 128) p.key[i] = raw[cur][i];
+  if (tid == 0) *p.pos = pos;
+}
+
+// One wave per row; rows that are not shuffle rows leave at once.  a[] lives in LDS (lds_cap ints) or, for longer
+// candidate lists, in the row's slice of `scratch` (global memory, slow, rare).
+__global__ __launch_bounds__(64) void np_shuffle_rows_kernel(const int* __restrict__ counts, const int* __restrict__ row_joff,
+                                                             const int* __restrict__ jbuf, int size,
+                                                             long long* __restrict__ out, int lds_cap,
+                                                             int* __restrict__ scratch) {
+  extern __shared__ int a_lds[];
+  const long long r = blockIdx.x;
+  const int joff = row_joff[r];
+  if (joff < 0) return;
+  const int n = counts[r], lane = threadIdx.x;
+  int* a_glb = scratch + (long long)joff + r;   // n ints (the row's n - 1 draws start at joff; r rows before it)
+  const bool in_lds = n <= lds_cap;
+  if (in_lds) { for (int k = lane; k < n; k += 64) a_lds[k] = k; }
+  else { for (int k = lane; k < n; k += 64) a_glb[k] = k; __threadfence_block(); }
+  wave_sync();
+  const int steps = n - 1;
+  for (int t0 = 0; t0 < steps; t0 += 64) {
+    const int jl = (t0 + lane < steps) ? jbuf[joff + t0 + lane] : 0;
+    const int m = steps - t0 < 64 ? steps - t0 : 64;
+    for (int q = 0; q < m; ++q) {
+      const int j = __builtin_amdgcn_readlane(jl, q);
+      const int i = n - 1 - (t0 + q);
+      if (lane == 0) {
+        if (in_lds) { const int ai = a_lds[i], aj = a_lds[j]; a_lds[j] = ai; a_lds[i] = aj; }
+        else {
+          volatile int* g = a_glb;
+          const int ai = g[i], aj = g[j]; g[j] = ai; g[i] = aj;
+        }
+      }
+    }
+  }
+  wave_sync();
+  if (!in_lds) __threadfence_block();
+  for (int k = lane; k < size; k += 64) out[r * (long long)size + k] = in_lds ? a_lds[k] : ((volatile int*)a_glb)[k];
+}
+
+}  // namespace
+
+extern "C" int64_t regnet_np_choice_rows_dev_workspace_ints(int64_t rows, int64_t max_count) {
+  // row_joff (rows) | jbuf (rows * max_count) | scratch (rows * max_count + rows) | status (1)
+  if (rows < 0 || max_count < 0) return -1;
+  return rows + rows * max_count + (rows * max_count + rows) + 1;
+}
+
+extern "C" int regnet_np_choice_rows_dev(uint32_t* d_mt_key, int32_t* d_mt_pos, const int32_t* d_counts, int64_t rows,
+                                         int64_t size, int64_t max_count, int mode, int64_t* d_out, uint8_t* d_valid,
+                                         int32_t* d_workspace, void* stream) {
+  if (rows < 0 || size < 0 || max_count < 0 || (mode != 0 && mode != 1)) return REGNET_ERR_SHAPE;
+  if (size >= (1ll << 31) || max_count >= (1ll << 31) || rows * (max_count + 1) >= (1ll << 31)) return REGNET_ERR_UNSUPPORTED;
+  if (rows == 0) return REGNET_OK;
+  if (!d_mt_key || !d_mt_pos || !d_counts || !d_out || !d_workspace) return REGNET_ERR_NULL;
+  ScanArgs a = {};
+  a.key = d_mt_key; a.pos = d_mt_pos; a.counts = d_counts; a.rows = rows; a.size = (int)size; a.mode = mode;
+  a.out = (long long*)d_out; a.valid = d_valid;
+  a.row_joff = d_workspace;
+  a.jbuf = d_workspace + rows; a.jcap = rows * max_count;
+  int* scratch = a.jbuf + rows * max_count;
+  a.status = scratch + rows * max_count + rows;
+  hipStream_t s = as_stream(stream);
+  if (hipMemsetAsync(a.status, 0, sizeof(int), s) != hipSuccess) return (int)hipGetLastError();
+  hipLaunchKernelGGL(np_choice_scan_kernel, dim3(1), dim3(128), 0, s, a);
+  REGNET_LAUNCH_CHECK();
+  const int lds_cap = 12288;   // 48 KiB: three shuffle rows per CU side by side
+  hipLaunchKernelGGL(np_shuffle_rows_kernel, dim3((unsigned)rows), dim3(64), lds_cap * sizeof(int), s, d_counts,
+                     a.row_joff, a.jbuf, (int)size, (long long*)d_out, lds_cap, scratch);
+  REGNET_LAUNCH_CHECK();
+  return REGNET_OK;
+}

@@ -36,6 +36,7 @@ def get_grasp_allobj(pc, predict_score, params, data_paths, use_theta=True):
     grasp_labels = None
     if len(data_paths) > 0:
         grasp_labels = _get_center_grasp(center_pc_index, center_pc, data_paths, depth, use_theta)
+    np_random.flush_unless_deferred()   # numpy's generator gets the state the device draws left (pipeline: once per run)
     return center_pc, center_pc_index, pc_group_index, pc_group, pc_group_more_index, pc_group_more, grasp_labels
 
 
@@ -184,10 +185,12 @@ def _select_score_center(pc, pre_score, center_num, score_thre):
         if P > center_num:
             index[b] = map_index[_F.farthest_point_sample(sub_xyz[b:b + 1, :, :P], center_num).view(-1)]
         elif P > 0:
+            np_random.flush()    # a host-side draw: numpy's generator must hold the current state
             extra = np.random.choice(P, center_num - P, replace=True)
             local = torch.cat([torch.arange(P), torch.from_numpy(np.asarray(extra, dtype=np.int64))])
             index[b] = map_index[local.to(pc.device)]
         else:
+            np_random.flush()
             picks = np.random.choice(N, center_num, replace=False)
             index[b] = torch.from_numpy(np.asarray(picks, dtype=np.int64)).to(pc.device)
     center_pc = torch.gather(pc, 1, index.unsqueeze(-1).expand(B, center_num, C))
@@ -200,14 +203,21 @@ def group_radius(width, height, depth, r_time):
     return float(np.float32(max(width, height, depth) * r_time))
 
 
-def _draw_positions(counts, group_num):
-    """Host-side resampling of every (scene, centre) candidate list to exactly ``group_num``
-    entries, consuming numpy's global RNG in the reference's order (get_regiondataset.py:331-337:
-    scene-major, then centre; without replacement when ``n >= group_num`` else with).
-    counts: (B,Nc) int array.  Returns positions (B,Nc,group_num) int64 into the ascending
-    candidate lists; rows with no candidate are -1.  The draws run in native host code that is
-    stream-compatible with numpy's legacy generator (np_random.choice_rows)."""
-    return np_random.choice_rows(counts, group_num, 0)[0]
+DEVICE_DRAWS = True   # False: the round-1/2 path (counts to the host, native host draws, positions back up)
+
+
+def _draw_positions(counts, group_num, max_count):
+    """Resampling of every (scene, centre) candidate list to exactly ``group_num`` entries, consuming numpy's
+    global RNG in the reference's order (get_regiondataset.py:331-337: scene-major, then centre; without
+    replacement when ``n >= group_num`` else with).  counts: (B,Nc) int32 tensor.  Returns positions
+    (B,Nc,group_num) int64 into the ascending candidate lists; rows with no candidate are -1.
+    On the GPU the draws are made by kernels from a device-resident copy of numpy's generator state
+    (np_random.choice_rows_device: no synchronisation); ``DEVICE_DRAWS = False`` or CPU tensors (the oracle-backed
+    mirror) take the native host code (np_random.choice_rows) after one device->host copy of the counts."""
+    if DEVICE_DRAWS and counts.is_cuda:
+        return np_random.choice_rows_device(counts.int(), group_num, 0, max_count)[0]
+    np_random.flush()
+    return torch.from_numpy(np_random.choice_rows(counts.cpu().numpy(), group_num, 0)[0]).to(counts.device)
 
 
 def _get_group_pc(pc, center_pc, center_pc_index, group_num, width, height, depth, r_time):
@@ -219,8 +229,7 @@ def _get_group_pc(pc, center_pc, center_pc_index, group_num, width, height, dept
     Nc = center_pc.shape[1]
     radius = group_radius(width, height, depth, r_time)
     cand, counts = region_ops.radius_candidates(pc, center_pc, radius)  # (B,Nc,cap) int32, (B,Nc) int32
-    counts_np = counts.cpu().numpy()                                    # the one sync of this pass
-    pos = torch.from_numpy(_draw_positions(counts_np, group_num)).to(pc.device)
+    pos = _draw_positions(counts, group_num, N)                         # on the GPU: no synchronisation
     # candidate slots of an empty group were never written: the kernel does not read through them
     pc_group_index, pc_group = region_ops.resample_groups(pc, cand, pos)
     return pc_group_index, pc_group

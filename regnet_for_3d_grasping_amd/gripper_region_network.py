@@ -109,6 +109,7 @@ class GripperRegionNetwork(nn.Module):
         counts = [int((ground_8 == a).sum()) for a in range(A)]
         per_class = max(int(min(counts)), 1)
         chosen = []
+        np_random.flush()    # host-side draws below: numpy's generator must hold the state the device draws left
         for a in range(A):
             members = torch.nonzero(ground_8 == a).view(-1)
             if len(members) == 0:
@@ -167,6 +168,7 @@ class GripperRegionNetwork(nn.Module):
         loss = loss_class = l_center = l_axis = l_theta = l_score = zero
         sl1 = nn.functional.smooth_l1_loss
         if num > 0:
+            np_random.flush()
             idx0 = neg[np.random.choice(len(neg), num, replace=False)].view(-1)
             idx1 = pos[np.random.choice(len(pos), num, replace=False)].view(-1)
             index = torch.cat((idx0, idx1), dim=-1)
@@ -248,6 +250,7 @@ class GripperRegionNetwork(nn.Module):
                 keep3, keep3_score = [0] * B, [0] * B
         (select_class, select_score, select_class_stage2, final_mask, final_mask_sthre, loss_refine_tuple,
          correct_refine_tuple, gt) = res
+        np_random.flush_unless_deferred()   # hand numpy's generator the state the crop draws left on the device
         return (next_grasp.detach(), keep2, true_mask, loss_tuple, correct_tuple, next_gt, select_class,
                 select_score, select_class_stage2, keep3, keep3_score, final_mask, final_mask_sthre,
                 loss_refine_tuple, correct_refine_tuple, gt)
@@ -311,12 +314,16 @@ def get_gripper_region_transform(group_points, group_index, grasp, region_num, g
     xlim, ylim = _half_extent(depths, n, dev), _half_extent(widths, n, dev)
     cand, count = region_ops.box_candidates(group_points, center, rot, xlim, ylim, height / 2)
 
-    # one sync for all grasps, then numpy-stream-compatible native draws in grasp order:
+    # numpy-stream-compatible draws in grasp order, on the device (no synchronisation):
     # > region_num candidates: without replacement; 6..region_num: with replacement; <= 5: invalid
-    pos, valid = np_random.choice_rows(count.cpu().numpy(), region_num, 1)
-    pos_t = torch.from_numpy(pos).to(dev)
-    valid_t = torch.from_numpy(valid).to(dev)
-    valid_ids = torch.from_numpy(np.nonzero(valid)[0]).to(dev)
+    from . import get_regiondataset as _grd
+    if _grd.DEVICE_DRAWS and count.is_cuda:
+        pos_t, valid_t = np_random.choice_rows_device(count.int(), region_num, 1, G)
+    else:
+        np_random.flush()
+        pos, valid = np_random.choice_rows(count.cpu().numpy(), region_num, 1)
+        pos_t, valid_t = torch.from_numpy(pos).to(dev), torch.from_numpy(valid).to(dev)
+    valid_ids = torch.nonzero(valid_t).view(-1)     # data-dependent length: the one synchronisation of the crop
 
     # positions inside the group; rows without a valid crop hold unwritten candidate slots -> 0
     index = torch.where(valid_t.view(n, 1), torch.gather(cand, 1, pos_t).long(), torch.zeros_like(pos_t))

@@ -231,17 +231,22 @@ class ForwardPipeline:
 
         todo, done = queue.Queue(), queue.Queue()
 
+        from . import np_random
+
         def region_worker():
             torch.cuda.set_device(self.device)
-            while True:
-                item = todo.get()
-                if item is None:
-                    return
-                try:
-                    done.put(self._region(item))
-                except BaseException as exc:  # surface the failure in the consumer thread
-                    done.put(exc)
-                    return
+            # numpy's generator state stays on the device between the region stages of a run (they are its only users, in
+            # batch order); it is handed back to np.random once, when the worker ends
+            with np_random.deferred():
+                while True:
+                    item = todo.get()
+                    if item is None:
+                        return
+                    try:
+                        done.put(self._region(item))
+                    except BaseException as exc:  # surface the failure in the consumer thread
+                        done.put(exc)
+                        return
 
         worker = threading.Thread(target=region_worker, name="regnet-region-stage", daemon=True)
         worker.start()

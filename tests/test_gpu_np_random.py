@@ -1,0 +1,127 @@
+"""The DEVICE-side numpy stream (csrc/np_random_dev.hip) must consume numpy's global MT19937 stream exactly like the
+reference's per-row np.random.choice loops (get_regiondataset.py:331-337, gripper_region_network.py:532-544): same
+outputs, same generator state afterwards -- checked against numpy itself, as tests/test_np_random.py does for the host
+implementation."""
+import numpy as np
+import pytest
+import torch
+
+from .test_np_random import _reference_crops, _reference_groups
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _dev_counts(counts):
+    return torch.from_numpy(np.asarray(counts, dtype=np.int32)).to(DEV)
+
+
+@pytest.mark.parametrize("size", [1, 64, 256, 1024])
+def test_device_choice_rows_matches_numpy_stream(size):
+    from regnet_for_3d_grasping_amd import np_random
+    rng = np.random.default_rng(0)
+    for seed in (0, 1, 123, 2 ** 31 - 1, 987654321):
+        counts = np.concatenate([rng.integers(0, 3 * size + 5, 40), [0, 1, 2, 5, 6, size - 1, size, size + 1,
+                                                                    2 ** 16, 2 ** 16 + 1, 40000, 12288, 12289]]).astype(np.int64)
+        counts = np.maximum(counts, 0)
+        cap = int(counts.max())
+        np.random.seed(seed)
+        np.random.random(seed % 700)                    # start from an arbitrary position in the block
+        want = _reference_groups(counts, size)
+        after = np.random.randint(0, 2 ** 31 - 1, 5)
+        np.random.seed(seed)
+        np.random.random(seed % 700)
+        got, valid = np_random.choice_rows_device(_dev_counts(counts), size, 0, cap)
+        np_random.flush()
+        assert np.array_equal(got.cpu().numpy(), want), "mode 0, seed %d" % seed
+        assert np.array_equal(valid.cpu().numpy(), counts > 0)
+        assert np.array_equal(np.random.randint(0, 2 ** 31 - 1, 5), after)   # generator left in the same state
+
+        np.random.seed(seed + 1)
+        want, wvalid = _reference_crops(counts, size)
+        after = np.random.randint(0, 2 ** 31 - 1, 5)
+        np.random.seed(seed + 1)
+        got, valid = np_random.choice_rows_device(_dev_counts(counts), size, 1, cap)
+        np_random.flush()
+        assert np.array_equal(got.cpu().numpy(), want), "mode 1, seed %d" % seed
+        assert np.array_equal(valid.cpu().numpy(), wvalid)
+        assert np.array_equal(np.random.randint(0, 2 ** 31 - 1, 5), after)
+
+
+def test_device_stream_chains_calls_and_follows_host_reseeds():
+    """Consecutive device draws continue one stream without a hand-back in between (what the pipeline's region worker
+    does); a host-side re-seed between two calls is honoured; block-boundary positions (0, 623, 624) are handled."""
+    from regnet_for_3d_grasping_amd import np_random
+    counts_a = np.array([700, 3, 0, 64, 65, 2000], dtype=np.int64)
+    counts_b = np.array([[9, 1], [300, 5000]], dtype=np.int64)
+    for skip in (0, 1, 623, 624, 625):
+        np.random.seed(42)
+        if skip:
+            np.random.randint(0, 2 ** 31 - 1, skip)     # one 32-bit word each
+        want_a = _reference_groups(counts_a, 256)
+        want_b, wvalid_b = _reference_crops(counts_b.reshape(-1), 64)
+        after = np.random.randint(0, 2 ** 31 - 1, 3)
+        np.random.seed(42)
+        if skip:
+            np.random.randint(0, 2 ** 31 - 1, skip)
+        with np_random.deferred():
+            got_a, _ = np_random.choice_rows_device(_dev_counts(counts_a), 256, 0, 2000)
+            got_b, valid_b = np_random.choice_rows_device(_dev_counts(counts_b), 64, 1, 5000)
+        assert np.array_equal(got_a.cpu().numpy(), want_a)
+        assert got_b.shape == (2, 2, 64) and np.array_equal(got_b.cpu().numpy().reshape(4, 64), want_b)
+        assert np.array_equal(valid_b.cpu().numpy().reshape(-1), wvalid_b)
+        assert np.array_equal(np.random.randint(0, 2 ** 31 - 1, 3), after)
+    # a re-seed on the host while the device copy is ahead: the next draw starts from the HOST's state
+    np.random.seed(7)
+    want = _reference_groups(counts_a, 64)
+    with np_random.deferred():
+        np.random.seed(1)
+        np_random.choice_rows_device(_dev_counts(counts_a), 64, 0, 2000)     # device now ahead of seed-1's stream
+        np.random.seed(7)
+        got, _ = np_random.choice_rows_device(_dev_counts(counts_a), 64, 0, 2000)
+    assert np.array_equal(got.cpu().numpy(), want)
+
+
+def test_device_draws_leave_gaussian_cache_and_shapes():
+    from regnet_for_3d_grasping_amd import np_random
+    np.random.seed(5)
+    np.random.standard_normal()                 # leaves a cached gaussian in the legacy state
+    state = np.random.get_state()
+    pos, valid = np_random.choice_rows_device(_dev_counts([[3, 0], [700, 64]]), 64, 0, 700)
+    np_random.flush()
+    assert pos.shape == (2, 2, 64) and valid.cpu().tolist() == [[True, False], [True, True]]
+    assert (pos[0, 1] == -1).all() and sorted(pos[1, 1].cpu().tolist()) == list(range(64))
+    assert np.random.get_state()[3] == state[3] and np.random.get_state()[4] == state[4]
+
+
+def test_region_stage_device_draws_equal_host_draws():
+    """get_grasp_allobj + the grasp-region forward with the draws on the device == the round-2 host-draw path
+    (same centres, groups, crops, grasps, numpy stream position)."""
+    import contextlib
+    import io
+    from regnet_for_3d_grasping_amd import get_regiondataset as grd, pipeline, synthetic
+    score_net, region_net = pipeline.build_models(DEV)
+    pc = synthetic.make_batch(1000, 2, 6144, device=DEV)
+    synthetic.calibrate_score_head(score_net, pc)
+    with torch.no_grad():
+        feat, score, _ = score_net(pc)
+    outs = []
+    for dev_draws in (True, False):
+        grd.DEVICE_DRAWS = dev_draws
+        try:
+            np.random.seed(11)
+            with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+                g = grd.get_grasp_allobj(pc, score, pipeline.PARAMS, [])
+                res = region_net(g[3], g[5], g[2], g[4], g[0], g[1], pc, feat, pipeline.GRIPPER_PARAMS, None, [])
+            outs.append((g, res, int(np.random.randint(0, 2 ** 31 - 1))))
+        finally:
+            grd.DEVICE_DRAWS = True
+    (g0, r0, s0), (g1, r1, s1) = outs
+    assert s0 == s1
+    for a, b in zip(g0[:6], g1[:6]):
+        assert torch.equal(a, b)
+    assert torch.equal(r0[0], r1[0]) and torch.equal(r0[2], r1[2])
+    for i in (6, 7, 11):
+        assert (r0[i] is None) == (r1[i] is None)
+        if r0[i] is not None:
+            assert torch.equal(r0[i], r1[i])
