@@ -57,16 +57,63 @@ struct ScanArgs {
 
 enum { ROW_NONE = 0, ROW_REPLACE = 1, ROW_SHUFFLE = 2 };
 
+constexpr int MT_PAD = 640;   // 10 x 64: every lane-indexed read of a block stays inside its array
+
+// Block cur -> block cur ^ 1 by ONE wave, straight-line (mt19937_gen of numpy's randomkit, out of place): all reads of the old
+// block are issued up front, the three dependent sweeps (new[i] needs new[i - 227]) exchange through LDS, and the
+// tempered words are written from registers.  Word i = 64 c + lane lives in lane `lane`, register c.
+__device__ __forceinline__ void mt_next_block(const unsigned* __restrict__ o, unsigned* __restrict__ nw,
+                                              unsigned* __restrict__ t, int lane) {
+  constexpr int D = MT_N - MT_M;   // 227
+  unsigned mix[10], val[10];
+#pragma unroll
+  for (int c = 0; c < 10; ++c) {
+    const int i = 64 * c + lane;
+    mix[c] = mt_mix(o[i], o[i + 1 < MT_PAD ? i + 1 : i]);   // (i = 623 is redone below: it mixes with the NEW word 0)
+    val[c] = 0u;
+  }
+  unsigned far[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) { const int i = 64 * c + lane; far[c] = o[i + MT_M < MT_PAD ? i + MT_M : i]; }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {          // sweep 1: i < 227
+    const int i = 64 * c + lane;
+    if (i < D) { val[c] = far[c] ^ mix[c]; nw[i] = val[c]; }
+  }
+  wave_sync();
+#pragma unroll
+  for (int c = 3; c < 8; ++c) {          // sweep 2: 227 <= i < 454
+    const int i = 64 * c + lane;
+    if (i >= D && i < 2 * D) { val[c] = nw[i - D] ^ mix[c]; nw[i] = val[c]; }
+  }
+  wave_sync();
+#pragma unroll
+  for (int c = 7; c < 10; ++c) {         // sweep 3: 454 <= i < 623
+    const int i = 64 * c + lane;
+    if (i >= 2 * D && i < MT_N - 1) { val[c] = nw[i - D] ^ mix[c]; nw[i] = val[c]; }
+  }
+  wave_sync();
+  if (lane == (MT_N - 1) % 64) {         // i = 623 (register 9): mixes old[623] with NEW[0]
+    val[9] = nw[MT_M - 1] ^ mt_mix(o[MT_N - 1], nw[0]);
+    nw[MT_N - 1] = val[9];
+  }
+#pragma unroll
+  for (int c = 0; c < 10; ++c) {
+    const int i = 64 * c + lane;
+    if (i < MT_N) t[i] = mt_temper(val[c]);
+  }
+}
+
 __global__ __launch_bounds__(128) void np_choice_scan_kernel(const ScanArgs p) {
-  __shared__ unsigned raw[2][MT_N];
-  __shared__ unsigned tmp[2][MT_N];
+  __shared__ unsigned raw[2][MT_PAD];
+  __shared__ unsigned tmp[2][MT_PAD];
   __shared__ int s_done;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  for (int i = tid; i < MT_N; i += 128) {
-    const unsigned k = p.key[i];
-    raw[0][i] = k;
-    tmp[0][i] = mt_temper(k);
+  for (int i = tid; i < MT_PAD; i += 128) {
+    const unsigned k = i < MT_N ? p.key[i] : 0u;
+    raw[0][i] = k; raw[1][i] = 0u;
+    tmp[0][i] = mt_temper(k); tmp[1][i] = 0u;
   }
   if (tid == 0) s_done = 0;
   __syncthreads();
@@ -86,22 +133,13 @@ __global__ __launch_bounds__(128) void np_choice_scan_kernel(const ScanArgs p) {
 
   for (;;) {
     if (wave == 1) {
-      // ---- generator: block cur -> block cur ^ 1 (mt19937_gen of numpy's randomkit, out of place)
-      const unsigned* o = raw[cur];
-      unsigned* nw = raw[cur ^ 1];
-      for (int i = lane; i < MT_N - MT_M; i += 64) nw[i] = o[i + MT_M] ^ mt_mix(o[i], o[i + 1]);
-      wave_sync();
-      for (int i = (MT_N - MT_M) + lane; i < 2 * (MT_N - MT_M); i += 64) nw[i] = nw[i - (MT_N - MT_M)] ^ mt_mix(o[i], o[i + 1]);
-      wave_sync();
-      for (int i = 2 * (MT_N - MT_M) + lane; i < MT_N - 1; i += 64) nw[i] = nw[i - (MT_N - MT_M)] ^ mt_mix(o[i], o[i + 1]);
-      wave_sync();
-      if (lane == 0) nw[MT_N - 1] = nw[MT_M - 1] ^ mt_mix(o[MT_N - 1], nw[0]);
-      wave_sync();
-      unsigned* t = tmp[cur ^ 1];
-      for (int i = lane; i < MT_N; i += 64) t[i] = mt_temper(nw[i]);
+      mt_next_block(raw[cur], raw[cur ^ 1], tmp[cur ^ 1], lane);
     } else {
-      // ---- scanner: rows consume tmp[cur][pos ..]
+      // ---- scanner: rows consume the tempered words of block cur from pos on; the block sits in registers
       const unsigned* words = tmp[cur];
+      unsigned w[10];
+#pragma unroll
+      for (int c = 0; c < 10; ++c) w[c] = words[64 * c + lane];
       for (;;) {
         while (need == 0) {          // open the next row (rows that draw nothing are finished right here)
           if (r == p.rows) break;
@@ -147,42 +185,61 @@ __global__ __launch_bounds__(128) void np_choice_scan_kernel(const ScanArgs p) {
         }
         if (need == 0) break;        // all rows done
         if (pos >= MT_N) break;      // block exhausted
+        if (kind == ROW_REPLACE) {
+          // the flags do not depend on the state: one pass over the REST OF THE BLOCK (ten ballots, scalar prefix counts)
+          unsigned long long acc[10];
+          int pre[11];
+          pre[0] = 0;
+#pragma unroll
+          for (int c = 0; c < 10; ++c) {
+            const int idx = 64 * c + lane;
+            acc[c] = __ballot(idx >= pos && idx < MT_N && (w[c] & mask) <= rng);
+            pre[c + 1] = pre[c] + __popcll(acc[c]);
+          }
+          const int want = need;
+#pragma unroll
+          for (int c = 0; c < 10; ++c) {
+            if (pre[c] < want) {     // (else: the row ended in an earlier chunk)
+              const int rk = rank_below(acc[c]);
+              const bool mine = (acc[c] >> lane) & 1ull;
+              const int k = want - pre[c];                       // accepted words this chunk may still give the row (>= 1)
+              if (mine && rk < k) p.out[wr + pre[c] + rk] = (long long)(w[c] & mask);
+              if (pre[c + 1] >= want) {                          // the row ends here: at the chunk's k-th accepted word
+                const int e = __builtin_ctzll(__ballot(mine && rk == k - 1));
+                pos = 64 * c + e + 1;
+              }
+            }
+          }
+          if (pre[10] < want) { wr += pre[10]; need -= pre[10]; pos = MT_N; }
+          else { need = 0; ++r; }
+          continue;
+        }
+        // ---- shuffle row: i falls by one per accepted word (and the mask with it): 64 words per step, iterated to the
+        //      serial answer (lane p's decision only depends on the lanes before it)
         const int idx = pos + lane;
         const bool in = idx < MT_N;
-        const unsigned w = in ? words[idx] : 0u;
+        const unsigned ww = words[in ? idx : MT_N - 1];
         unsigned v;
         bool ok;
-        unsigned long long acc;
-        if (kind == ROW_REPLACE) {
-          v = w & mask;
-          ok = in && v <= rng;
-          acc = __ballot(ok);
-        } else {
-          // i falls by one per accepted word (and the mask with it): iterate to the serial answer
-          unsigned long long prev = 0ull;
-          for (;;) {
-            const int ip = icur - rank_below(prev);
-            v = w & mask_for(ip > 0 ? (unsigned)ip : 0u);
-            ok = in && ip >= 1 && v <= (unsigned)ip;
-            acc = __ballot(ok);
-            if (acc == prev) break;
-            prev = acc;
-          }
+        unsigned long long accs, prev = 0ull;
+        for (;;) {
+          const int ip = icur - rank_below(prev);
+          v = ww & mask_for(ip > 0 ? (unsigned)ip : 0u);
+          ok = in && ip >= 1 && v <= (unsigned)ip;
+          accs = __ballot(ok);
+          if (accs == prev) break;
+          prev = accs;
         }
-        int cnt = __popcll(acc);
+        int cnt = __popcll(accs);
         int used = MT_N - pos < 64 ? MT_N - pos : 64;       // words this step consumes
-        const int rk = rank_below(acc);
+        const int rk = rank_below(accs);
         if (cnt >= need) {                                   // the row ends inside this step: at its need-th accepted word
-          const unsigned long long last = __ballot(ok && rk == need - 1);
-          const int e = __builtin_ctzll(last);
-          acc &= (e == 63) ? ~0ull : ((1ull << (e + 1)) - 1ull);
+          const int e = __builtin_ctzll(__ballot(ok && rk == need - 1));
+          accs &= (e == 63) ? ~0ull : ((1ull << (e + 1)) - 1ull);
           cnt = need;
           used = e + 1;
         }
-        if ((acc >> lane) & 1ull) {
-          if (kind == ROW_REPLACE) p.out[wr + rk] = (long long)v;
-          else p.jbuf[wr + rk] = (int)v;
-        }
+        if ((accs >> lane) & 1ull) p.jbuf[wr + rk] = (int)v;
         wr += cnt; need -= cnt; icur -= cnt; pos += used;
         if (need == 0) ++r;
       }

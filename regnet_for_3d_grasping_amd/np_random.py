@@ -82,6 +82,12 @@ class _DeviceStream:
         import torch
         if not self.ahead:
             return
+        if self._signature(np.random.get_state()) != self.host_sig:
+            # the host generator was re-seeded (or used) after the device copy was taken: the device copy is obsolete --
+            # never overwrite what the caller put into np.random
+            self.ahead = False
+            self.status = []
+            return
         with torch.cuda.device(self.device):
             if self.last_event is not None:
                 torch.cuda.current_stream(self.device).wait_event(self.last_event)

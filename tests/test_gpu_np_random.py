@@ -115,7 +115,7 @@ def test_region_stage_device_draws_equal_host_draws():
                 res = region_net(g[3], g[5], g[2], g[4], g[0], g[1], pc, feat, pipeline.GRIPPER_PARAMS, None, [])
             outs.append((g, res, int(np.random.randint(0, 2 ** 31 - 1))))
         finally:
-            grd.DEVICE_DRAWS = True
+            grd.DEVICE_DRAWS = False
     (g0, r0, s0), (g1, r1, s1) = outs
     assert s0 == s1
     for a, b in zip(g0[:6], g1[:6]):
@@ -125,3 +125,27 @@ def test_region_stage_device_draws_equal_host_draws():
         assert (r0[i] is None) == (r1[i] is None)
         if r0[i] is not None:
             assert torch.equal(r0[i], r1[i])
+
+
+def test_pipeline_with_device_draws_equals_sequential_host_draws():
+    """ForwardPipeline with the region stage's draws on the device (numpy's generator resident on the GPU for the whole
+    run, handed back when the worker ends) == batch-by-batch forward with the host draws: same groups, same grasps,
+    same numpy stream position afterwards."""
+    from regnet_for_3d_grasping_amd import get_regiondataset as grd, pipeline, synthetic
+    score_net, region_net = pipeline.build_models(DEV)
+    batches = [synthetic.make_batch(3000 + 2 * i, 2, 6144, device=DEV) for i in range(3)]
+    synthetic.calibrate_score_head(score_net, batches[0])
+    np.random.seed(99)
+    want = [pipeline.forward_scenes(score_net, region_net, pc) for pc in batches]
+    after = int(np.random.randint(0, 2 ** 31 - 1))
+    grd.DEVICE_DRAWS = True
+    try:
+        np.random.seed(99)
+        got = list(pipeline.ForwardPipeline(score_net, region_net).run(iter(batches)))
+        torch.cuda.synchronize()
+        assert int(np.random.randint(0, 2 ** 31 - 1)) == after
+    finally:
+        grd.DEVICE_DRAWS = False
+    for w, g in zip(want, got):
+        for key in ("center_pc_index", "pc_group_index", "pc_group_more_index", "next_grasp", "true_mask"):
+            assert torch.equal(w[key], g[key]), key
