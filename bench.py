@@ -184,7 +184,7 @@ def _mlp_layer_kernel(d):
 
 KERNEL_OF = {"native_fwd": "tgemm_kernel", "native_dgrad": "tgemm_kernel", "native_wgrad": "tgemm_kernel",
              "mlp_layer": _mlp_layer_kernel, "sa_layer1": "mlp_gemm_kernel", "sa_layer12": "mlp_gemm_kernel",
-             "sa_premul_layer": "mlp_gemm_kernel<3>", "sa_chain3": "sa_chain_kernel", "fp_head_chain": "fp_head_chain_kernel", "sa_premul_chain": "sa_premul_chain_kernel",
+             "sa_premul_layer": "mlp_gemm_kernel<3>", "sa_chain3": "sa_chain_kernel", "fp_head_chain": "fp_head_chain_kernel", "sa_premul_chain": "sa_premul_chain_kernel", "sa3_premul_chain": "sa3_premul_chain_kernel",
              "farthest_point_sample": "fps_kernel", "ball_query": "ball_query_kernel",
              "point_search": "three_nn_kernel", "radius_candidates": "radius_group_kernel",
              "box_candidates": "box_crop_kernel", "gather_max": "gather_max_kernel"}

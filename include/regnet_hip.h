@@ -346,6 +346,19 @@ int regnet_sa_premul_chain_f32(const float* U, int64_t ldu, const float* V, int6
                                int64_t affine_floats, int relu3, float* out, int64_t ldo, int32_t* ticket,
                                void* stream);
 
+/* regnet_sa3_premul_chain_f32: the same for the level-3 block (utils/pointnet2.py:40-42: 515 -> 512 -> 512 -> 1024 over
+ * 256 x 64 rows per scene): U (B*Nsrc, >=512), V (B*M, >=512) pre-multiplied layer-1 rows as for
+ * regnet_sa_premul_layer_f32; layer 2 (512 -> 512) runs as two K-halves so that its 512-wide activation stays in
+ * registers, layer 3 (512 -> 1024) point-major with the max over the 64 neighbours; out (B*M, 1024).
+ * `stream_w`: regnet_sa3_premul_chain_stream_floats() floats = 96 stages [32 output channels][256 k]: W2 as
+ * (K-half, 16 row blocks), then W3 as (32 row blocks, K-half); `affine` = [scale2 | shift2 | scale3 | shift3]
+ * (3072 floats).  Same values as regnet_sa_premul_layer_f32 + regnet_mlp_layer_f32(pool) up to fp32 summation order. */
+int64_t regnet_sa3_premul_chain_stream_floats(void);
+int regnet_sa3_premul_chain_f32(const float* U, int64_t ldu, const float* V, int64_t ldv, const int64_t* nbr, int64_t B,
+                                int64_t Nsrc, int64_t M, const float* stream_w, int64_t n_stages, const float* affine,
+                                int64_t affine_floats, int relu3, float* out, int64_t ldo, int32_t* ticket,
+                                void* stream);
+
 /* regnet_fp_head_chain_f32: the tail of the last feature-propagation block and the whole segmentation head of
  * PointNet2Seg as ONE kernel (utils/pointnet2.py:64-84 with fp_channels[2] = (256, 256, 256), :116-119 with
  * seg_channels = (512, 256, 256, 128); pn2_utils/modules.py:500-509):

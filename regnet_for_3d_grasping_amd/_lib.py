@@ -73,6 +73,9 @@ SIGNATURES = {
     "regnet_sa_premul_chain_stream_floats": (_i64, []),
     "regnet_sa_premul_chain_f32": (_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _int, _vp, _i64,
                                           _vp, _vp]),
+    "regnet_sa3_premul_chain_stream_floats": (_i64, []),
+    "regnet_sa3_premul_chain_f32": (_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _int, _vp, _i64,
+                                           _vp, _vp]),
     "regnet_fp_head_chain_stream_floats": (_i64, []),
     "regnet_fp_head_chain_f32": (_int, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _f32, _f32, _f32, _vp, _i64, _vp, _i64, _vp,
                                         _vp]),

@@ -526,14 +526,184 @@ __global__ __launch_bounds__(RC_THREADS, 2) void sa_premul_chain_kernel(const Sc
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Level-3 set-abstraction block of PointNet2Seg on pre-multiplied layer-1 rows (pointnet2.py:40-42: 515 -> 512 -> 512 ->
+// 1024 over 256 x 64 rows per scene; pn2_utils/modules.py:39-56, :244-245): layers 2 + 3 + the max over the 64 neighbours
+// in one kernel, like sa_premul_chain_kernel but with 512-wide activations -- 128 registers per 16 points, so layer 1 and
+// layer 2 cannot both be resident.  Layer 2 therefore runs as two K-halves:
+//     for kh in {0, 1}:  x0h = relu(U[b, nbr[p]][256 kh ..] - V[p / 64][256 kh ..])       64 registers, re-gathered per half
+//                        x1 += W2[:, 256 kh ..] . x0h                                      128 accumulator registers (all 512)
+//     x1 = relu(aff2(x1));   y = relu(aff3(x1 . W3^T)) point-major, 32 channels per step, two K-half stages each;  max.
+// The 268 MB (batch of 8) layer-2 activation that regnet_sa_premul_layer_f32 wrote and the pooling GEMM re-read never
+// exists.  96 stages per pass ([32 output channels][256 k] each): W2 as (kh, 16 row blocks), W3 as (32 row blocks, kh).
+struct Sc3Args {
+  const float* U; long long ldu, scene_stride;
+  const float* V; long long ldv;
+  const long long* nbr;
+  long long groups, groups_per_scene;
+  const float* stream; int n_stages;
+  const float* affine; int affine_floats;        // [scale2(512) | shift2(512) | scale3(1024) | shift3(1024)]
+  int relu3;
+  float* out; long long ldo;                     // (groups, 1024)
+  int* ticket; long long n_blocks;
+};
+
+__global__ __launch_bounds__(RC_THREADS, 2) void sa3_premul_chain_kernel(const Sc3Args p) {
+  extern __shared__ __attribute__((aligned(1024))) float smem[];   // ring | affine (3072) | pool (8 x 1024) | ticket
+  float* const aff = smem + RC_STAGES * RC_STAGE_FLOATS;
+  float* const pool = aff + 3072;
+  int* const s_blk = reinterpret_cast<int*>(pool + RC_WAVES * 1024);
+  const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int i = tid; i < p.affine_floats; i += RC_THREADS) aff[i] = p.affine[i];
+  __syncthreads();
+
+  RcRing ring;
+  ring.n_stages = p.n_stages;
+  ring.src_begin = p.stream + (wave * RC_PIECES) * 256 + lane * 4;
+  ring.src = ring.src_begin;
+  ring.fetch_idx = 0;
+  ring.lds_lo = (unsigned)(uintptr_t)smem + (unsigned)(wave * RC_PIECES * 1024);
+  ring.lds_hi = ring.lds_lo + RC_STAGES * RC_STAGE_FLOATS * 4;
+  ring.lds_fetch = ring.lds_lo;
+  ring.slot = 0;
+  const RcFrag fo = rc_frag_offsets();
+  const int g4 = 4 * g;
+
+  bool primed = false;
+  for (;;) {
+    if (tid == 0) *s_blk = atomicAdd(p.ticket, 1);
+    __syncthreads();
+    const long long blk = __builtin_amdgcn_readfirstlane(*s_blk);
+    if (blk >= p.n_blocks) break;
+    if (!primed) {
+#pragma unroll
+      for (int d = 0; d < RC_STAGES - 1; ++d) ring.fetch();
+      primed = true;
+    }
+    const long long grp0 = blk * (RC_WAVES / 4);
+    const long long grp = grp0 + (wave >> 2);                  // this wave's neighbourhood
+    const bool active = grp < p.groups;                        // wave-uniform
+    const long long gs = active ? grp : 0;
+    const long long b = gs / p.groups_per_scene;
+    const long long src = p.nbr[gs * 64 + (wave & 3) * 16 + j];
+    const float* const ur = p.U + b * p.scene_stride + src * p.ldu + g4;
+    const float* const vr = p.V + gs * p.ldv + g4;
+
+    // ---- layer 2 as two K-halves; x1[t] register r, lane (g, j) = channel 16 t + 4 g + r of point j
+    rc_f32x4 x1[32];
+#pragma unroll
+    for (int t = 0; t < 32; ++t) x1[t] = rc_f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kh = 0; kh < 2; ++kh) {
+      rc_f32x4 x0[16];
+      {
+        const float* urh = ur + 256 * kh;
+        const float* vrh = vr + 256 * kh;
+#pragma unroll
+        for (int kq = 0; kq < 4; ++kq) {     // four loads of each kind in flight at a time
+          rc_f32x4 u[4], v[4];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            u[t] = *reinterpret_cast<const rc_f32x4*>(urh + 16 * (4 * kq + t));
+            v[t] = *reinterpret_cast<const rc_f32x4*>(vrh + 16 * (4 * kq + t));
+          }
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x0[4 * kq + t][r] = fmaxf(u[t][r] - v[t][r], 0.f);
+          RC_PIN();
+        }
+      }
+#pragma unroll
+      for (int rg = 0; rg < 16; ++rg) {
+        const int slot = ring.acquire<false>();
+        const float* st = smem + slot * RC_STAGE_FLOATS;
+        rc_f32x4 w0n = *reinterpret_cast<const rc_f32x4*>(st + fo.a[0]);
+        rc_f32x4 w1n = *reinterpret_cast<const rc_f32x4*>(st + fo.a[0] + 16 * 256);
+#pragma unroll
+        for (int kt = 0; kt < 16; ++kt) {
+          const rc_f32x4 w0 = w0n, w1 = w1n;
+          if (kt + 1 < 16) {
+            const float* wp = st + fo.a[(kt + 1) & 3] + 64 * ((kt + 1) >> 2);
+            w0n = *reinterpret_cast<const rc_f32x4*>(wp);
+            w1n = *reinterpret_cast<const rc_f32x4*>(wp + 16 * 256);
+          }
+          RC_PIN();
+          const rc_f32x4 x = x0[kt];
+          RC_MFMA8(w0, w1, x, x1[2 * rg], x1[2 * rg + 1])
+        }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 32; ++t) {
+      const float* a = aff + 16 * t + g4;
+      const rc_f32x4 sc = *reinterpret_cast<const rc_f32x4*>(a), sh = *reinterpret_cast<const rc_f32x4*>(a + 512);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) x1[t][r] = fmaxf(x1[t][r] * sc[r] + sh[r], 0.f);
+    }
+    // ---- layer 3 + max over the points: 32 channels per step, the two K-halves as two stages
+    for (int s3 = 0; s3 < 32; ++s3) {
+      rc_f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh) {
+        const int slot = ring.acquire<false>();
+        const float* st = smem + slot * RC_STAGE_FLOATS;
+        rc_f32x4 w0n = *reinterpret_cast<const rc_f32x4*>(st + fo.a[0]);
+        rc_f32x4 w1n = *reinterpret_cast<const rc_f32x4*>(st + fo.a[0] + 16 * 256);
+#pragma unroll
+        for (int kt = 0; kt < 16; ++kt) {
+          const rc_f32x4 w0 = w0n, w1 = w1n;
+          if (kt + 1 < 16) {
+            const float* wp = st + fo.a[(kt + 1) & 3] + 64 * ((kt + 1) >> 2);
+            w0n = *reinterpret_cast<const rc_f32x4*>(wp);
+            w1n = *reinterpret_cast<const rc_f32x4*>(wp + 16 * 256);
+          }
+          RC_PIN();
+          const rc_f32x4 x = x1[16 * kh + kt];
+          RC_MFMA8_T(w0, w1, x, acc0, acc1)
+        }
+      }
+      // folded BN affine (+ ReLU) per channel (32 s3 + 16 t + j), max over this wave's 16 points: registers, then lane groups
+      const float sc0 = aff[1024 + 32 * s3 + j], sc1 = aff[1024 + 32 * s3 + 16 + j];
+      const float sh0 = aff[2048 + 32 * s3 + j], sh1 = aff[2048 + 32 * s3 + 16 + j];
+      float m0 = -__builtin_inff(), m1 = -__builtin_inff();
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        m0 = fmaxf(m0, acc0[r] * sc0 + sh0);
+        m1 = fmaxf(m1, acc1[r] * sc1 + sh1);
+      }
+      if (p.relu3) { m0 = fmaxf(m0, 0.f); m1 = fmaxf(m1, 0.f); }
+      m0 = fmaxf(m0, __shfl_xor(m0, 16, 64)); m1 = fmaxf(m1, __shfl_xor(m1, 16, 64));
+      m0 = fmaxf(m0, __shfl_xor(m0, 32, 64)); m1 = fmaxf(m1, __shfl_xor(m1, 32, 64));
+      if (g == 0) {
+        pool[wave * 1024 + 32 * s3 + j] = m0;
+        pool[wave * 1024 + 32 * s3 + 16 + j] = m1;
+      }
+    }
+    // ---- max over the 4 waves of each neighbourhood (the ring's next barriers separate this from the next pass's writes)
+    __syncthreads();
+#pragma unroll
+    for (int n = 0; n < RC_WAVES / 4; ++n) {
+      const long long gn = grp0 + n;
+      if (gn < p.groups)
+        for (int c = tid; c < 1024; c += RC_THREADS) {
+          const float* q = pool + (4 * n) * 1024 + c;
+          p.out[gn * p.ldo + c] = fmaxf(fmaxf(q[0], q[1024]), fmaxf(q[2048], q[3072]));
+        }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 static bool rc_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // > 64 KiB of dynamic LDS needs the function attribute, once per (kernel, device) -- one process may drive several GPUs
 static int rc_allow_lds(const void* kernel, size_t bytes) {
-  static unsigned long long done[2] = {0ull, 0ull};   // bit per device id < 64, per kernel
+  static unsigned long long done[3] = {0ull, 0ull, 0ull};   // bit per device id < 64, per kernel
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return (int)hipGetLastError();
-  const int which = kernel == reinterpret_cast<const void*>(fp_head_chain_kernel) ? 0 : 1;
+  const int which = kernel == reinterpret_cast<const void*>(fp_head_chain_kernel) ? 0
+                  : kernel == reinterpret_cast<const void*>(sa_premul_chain_kernel) ? 1 : 2;
   if (dev >= 0 && dev < 64 && (done[which] >> dev) & 1ull) return REGNET_OK;
   hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
   if (e != hipSuccess) return (int)e;
@@ -572,6 +742,34 @@ extern "C" int regnet_sa_premul_chain_f32(const float* U, int64_t ldu, const flo
   int rc_attr = rc_allow_lds(reinterpret_cast<const void*>(sa_premul_chain_kernel), lds);
   if (rc_attr) return rc_attr;
   hipLaunchKernelGGL(sa_premul_chain_kernel, dim3((unsigned)wgs), dim3(RC_THREADS), lds, as_stream(stream_handle), a);
+  REGNET_LAUNCH_CHECK();
+  return REGNET_OK;
+}
+
+extern "C" int64_t regnet_sa3_premul_chain_stream_floats(void) { return 96ll * RC_STAGE_FLOATS; }
+
+extern "C" int regnet_sa3_premul_chain_f32(const float* U, int64_t ldu, const float* V, int64_t ldv, const int64_t* nbr,
+                                           int64_t B, int64_t Nsrc, int64_t M, const float* stream, int64_t n_stages,
+                                           const float* affine, int64_t affine_floats, int relu3, float* out, int64_t ldo,
+                                           int32_t* ticket, void* stream_handle) {
+  if (B < 0 || M < 0 || Nsrc <= 0 || ldu < 512 || ldv < 512 || (ldu & 3) || (ldv & 3) || ldo < 1024 || n_stages != 96 ||
+      affine_floats != 3072 || RC_WAVES != 8)
+    return REGNET_ERR_SHAPE;
+  const long long groups = B * M;
+  if (groups == 0) return REGNET_OK;
+  if (!U || !V || !nbr || !stream || !affine || !out || !ticket) return REGNET_ERR_NULL;
+  if (!rc_aligned16(U) || !rc_aligned16(V) || !rc_aligned16(stream) || !rc_aligned16(affine)) return REGNET_ERR_SHAPE;
+  Sc3Args a = {};
+  a.U = U; a.ldu = ldu; a.scene_stride = Nsrc * ldu; a.V = V; a.ldv = ldv; a.nbr = (const long long*)nbr;
+  a.groups = groups; a.groups_per_scene = M; a.stream = stream; a.n_stages = (int)n_stages;
+  a.affine = affine; a.affine_floats = (int)affine_floats; a.relu3 = relu3; a.out = out; a.ldo = ldo;
+  a.n_blocks = (groups + 1) / 2;
+  a.ticket = ticket;
+  const long long wgs = a.n_blocks < 256 ? a.n_blocks : 256;
+  const size_t lds = (size_t)(RC_STAGES * RC_STAGE_FLOATS + 3072 + RC_WAVES * 1024 + 4) * sizeof(float);
+  int rc_attr = rc_allow_lds(reinterpret_cast<const void*>(sa3_premul_chain_kernel), lds);
+  if (rc_attr) return rc_attr;
+  hipLaunchKernelGGL(sa3_premul_chain_kernel, dim3((unsigned)wgs), dim3(RC_THREADS), lds, as_stream(stream_handle), a);
   REGNET_LAUNCH_CHECK();
   return REGNET_OK;
 }

@@ -343,6 +343,8 @@ TIMED_OPS = {
                                 2 * B * M * group * (l1.K * l1.N + l2.K * l2.N + l3.K * l3.N)),
     "sa_premul_chain": lambda U, V, nbr, module, layers, B, Nsrc, M:
         "P%d K256 N512 flop%d" % (B * M * 64, 2 * B * M * 64 * (256 * 256 + 256 * 512)),
+    "sa3_premul_chain": lambda U, V, nbr, module, layers, B, Nsrc, M:
+        "P%d K512 N1024 flop%d" % (B * M * 64, 2 * B * M * 64 * (512 * 512 + 512 * 1024)),
     "fp_head_chain": lambda h1, seg, fp_layers, P: "P%d K256 N256 flop%d" % (P, 2 * P * 491520),
     "sa_layer12": lambda feature, xyz, nbr, ctr, first, layer, B, M, group, pool_group=0:
         "P%d K%d N%d flop%d" % (B * M * group, layer.K, layer.N,
@@ -431,6 +433,10 @@ def sa_features(module, xyz, feature, geo):
             src_xyz, ctr_xyz = xyz, geo["new_xyz"]
         U = mlp_layer(pack_rows(feature, src_xyz, width), width, u_layer, B * N1)
         V = mlp_layer(pack_rows(None, ctr_xyz, 4), 4, v_layer, B * M)
+        if supports_sa3_chain(layers) and U.size(1) == 512:
+            # level 3: the same with 512-wide activations (layer 2 as two K-halves, csrc/rowchain.hip)
+            pooled = sa3_premul_chain(U, V, geo["nbr"], module, layers, B, N1, M)
+            return geo["new_xyz"], pooled.view(B, M, -1).transpose(1, 2)
         if supports_sa_chain(layers) and U.size(1) == 256:
             # layers 2 and 3 + the pooling in one kernel, layer-2 activation in registers (csrc/rowchain.hip)
             pooled = sa_premul_chain(U, V, geo["nbr"], module, layers, B, N1, M)
@@ -558,8 +564,45 @@ def sa_premul_chain(U, V, nbr, module, layers, B, Nsrc, M):
     return out
 
 
+# ---- level-3 set-abstraction block: layers 2 + 3 + pooling as ONE kernel, 512-wide (csrc/rowchain.hip) ------------------
+def _packed_sa3_chain(module, layers):
+    """Weight stream (96 stages [32 rows][256 k]: W2 as (K-half, 16 row blocks), W3 as (32 row blocks, K-half)) + affine
+    table of sa3_premul_chain."""
+    sig = _signature(module.mlp)
+    cache = getattr(module, "_regnet_sa3_chain", None)
+    if cache is None or cache[0] != sig:
+        l2, l3 = layers[1], layers[2]
+        stages = [_swizzle_stage(l2.W[32 * rg:32 * rg + 32, 256 * kh:256 * kh + 256]) for kh in range(2) for rg in range(16)]
+        stages += [_swizzle_stage(l3.W[32 * s:32 * s + 32, 256 * kh:256 * kh + 256]) for s in range(32) for kh in range(2)]
+        stream = torch.cat(stages).contiguous()
+        affine = torch.cat([l2.scale[:512], l2.shift[:512], l3.scale[:1024], l3.shift[:1024]]).contiguous()
+        assert stream.numel() == _L.regnet_sa3_premul_chain_stream_floats() and affine.numel() == 3072
+        cache = (sig, (stream, affine))
+        module._regnet_sa3_chain = cache
+    return cache[1]
+
+
+def supports_sa3_chain(layers):
+    return (SA3_CHAIN and len(layers) == 3 and layers[0].N == 512 and layers[1].K == 512 and layers[1].N == 512
+            and layers[1].relu and layers[2].K == 512 and layers[2].N == 1024)
+
+
+@_on_tensor_device
+def sa3_premul_chain(U, V, nbr, module, layers, B, Nsrc, M):
+    """relu(U[nbr] - V[centre]) -> 512 -> 1024 -> max over the 64 neighbours, one launch; -> (B*M, 1024)."""
+    stream, affine = _packed_sa3_chain(module, layers)
+    out = torch.empty((B * M, 1024), dtype=torch.float32, device=U.device)
+    ticket = torch.zeros((1,), dtype=torch.int32, device=U.device)
+    _check(_L.regnet_sa3_premul_chain_f32(U.data_ptr(), U.stride(0), V.data_ptr(), V.stride(0), nbr.data_ptr(), B, Nsrc,
+                                          M, stream.data_ptr(), 96, affine.data_ptr(), affine.numel(), layers[2].relu,
+                                          out.data_ptr(), out.stride(0), ticket.data_ptr(), _stream(U)),
+           "sa3_premul_chain")
+    return out
+
+
 # ---- FP3 tail + segmentation head as ONE kernel (csrc/rowchain.hip) --------------------------------------------------
 ROWCHAIN = True   # last FP block's layers 2-3 + the whole head in one register-chained kernel
+SA3_CHAIN = True  # level-3 set-abstraction block's layers 2-3 + pooling in one register-chained kernel
 
 
 def _swizzle_stage(block):
@@ -659,6 +702,8 @@ def prepack(score_net, region_net=None):
             _premul_layers(layers[0], Cf)
             if supports_sa_chain(layers):
                 _packed_sa_chain(sa, layers)
+            if supports_sa3_chain(layers):
+                _packed_sa3_chain(sa, layers)
     sparse = seg.sa_modules[-1].out_channels
     for fp in seg.fp_modules:
         layers = _packed_stack(fp, fp.mlp)

@@ -34,3 +34,33 @@ for name, fn in (("chain", chain), ("layerwise", layerwise), ("chain", chain), (
     torch.cuda.synchronize()
     ms = s.elapsed_time(e) / 10
     print("%-10s %.3f ms  %.1f TFLOP/s" % (name, ms, flop / ms / 1e9))
+
+# ---- level-3 set-abstraction block (8 scenes x 256 neighbourhoods x 64): one chained launch vs the two it replaces
+sa = seg.sa_modules[2]
+Cf = sa.in_channels
+layers = fused._packed_stack(sa, sa.mlp, lambda: torch.cat([torch.arange(3, 3 + Cf), torch.arange(0, 3)]).to(DEV))
+B, M, Nsrc = 8, 256, 1024
+U = torch.randn(B * Nsrc, 512, device=DEV)
+V = torch.randn(B * M, 512, device=DEV) * 0.5
+nbr = torch.randint(0, Nsrc, (B, M, 64), device=DEV)
+
+def sa3_chain():
+    return fused.sa3_premul_chain(U, V, nbr, sa, layers, B, Nsrc, M)
+
+def sa3_layerwise():
+    h = fused.sa_premul_layer(U, V, nbr, layers[1], B, Nsrc, M, 64)
+    return fused.mlp_layer(h, layers[2].K, layers[2], B * M * 64, pool_group=64)
+
+flop3 = 2.0 * B * M * 64 * (512 * 512 + 512 * 1024)
+for name, fn in (("sa3 chain", sa3_chain), ("sa3 layerwise", sa3_layerwise), ("sa3 chain", sa3_chain), ("sa3 layerwise", sa3_layerwise)):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(10):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    ms = s.elapsed_time(e) / 10
+    print("%-14s %.3f ms  %.1f TFLOP/s" % (name, ms, flop3 / ms / 1e9))

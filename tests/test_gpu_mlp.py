@@ -421,3 +421,38 @@ def test_sa_premul_chain_equals_layerwise_kernels(B, M):
         ref = x.squeeze(-1).view(B, 512, M, 64).amax(-1).permute(0, 2, 1).reshape(B * M, 512)
         score_net.float()
     torch.testing.assert_close(got.double(), ref, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("B,M", [(2, 64), (1, 33), (3, 1), (8, 256)])
+def test_sa3_premul_chain_equals_layerwise_kernels(B, M):
+    """csrc/rowchain.hip:sa3_premul_chain_kernel (level-3 SA block: 512-wide layers 2 + 3 + pooling in one kernel, layer 2
+    as two K-halves) against the two launches it replaces and an fp64 reference; odd neighbourhood counts, one
+    neighbourhood, and the bench shape (8 x 256 neighbourhoods = 4 rounds of 256 workgroups)."""
+    from regnet_for_3d_grasping_amd import fused, pipeline
+    torch.manual_seed(10 * B + M)
+    score_net, _ = pipeline.build_models(DEV)
+    sa = score_net.extrat_featurePN2.sa_modules[2]
+    Cf = sa.in_channels
+    layers = fused._packed_stack(sa, sa.mlp, lambda: torch.cat([torch.arange(3, 3 + Cf), torch.arange(0, 3)]).to(DEV))
+    assert fused.supports_sa3_chain(layers)
+    Nsrc = 300
+    U = torch.randn(B * Nsrc, 512, device=DEV)
+    V = torch.randn(B * M, 512, device=DEV) * 0.5
+    nbr = torch.randint(0, Nsrc, (B, M, 64), device=DEV)
+    got = fused.sa3_premul_chain(U, V, nbr, sa, layers, B, Nsrc, M)
+    h = fused.sa_premul_layer(U, V, nbr, layers[1], B, Nsrc, M, 64)
+    want = fused.mlp_layer(h, layers[2].K, layers[2], B * M * 64, pool_group=64)
+    torch.cuda.synchronize()
+    assert got.shape == want.shape == (B * M, 1024) and torch.isfinite(got).all()
+    torch.testing.assert_close(got, want, rtol=2e-5, atol=2e-5)
+    if B * M <= 128:
+        with torch.no_grad():
+            x0 = torch.relu(U.view(B, Nsrc, 512).double().gather(1, nbr.view(B, M * 64, 1).expand(-1, -1, 512))
+                            - V.view(B, M, 1, 512).double().expand(-1, -1, 64, -1).reshape(B, M * 64, 512))
+            x = x0.transpose(1, 2).unsqueeze(-1)                       # (B, 512, M*64, 1)
+            for blk in list(sa.mlp)[1:]:
+                blk = blk.double()
+                x = torch.relu(blk.bn(blk.conv(x)))
+            ref = x.squeeze(-1).view(B, 1024, M, 64).amax(-1).permute(0, 2, 1).reshape(B * M, 1024)
+            score_net.float()
+        torch.testing.assert_close(got.double(), ref, rtol=1e-4, atol=1e-4)
