@@ -61,6 +61,10 @@ def parse():
     ap.add_argument("--first-launch-groups", type=int, default=4,
                     help="sampling groups the FIRST sampling launch of a run takes (it finds the chip idle); the line reports "
                          "the resulting look-ahead (config.sampling_lookahead_batches) and value_no_lookahead beside the headline")
+    ap.add_argument("--train-steps", type=int, default=5,
+                    help="forward bench only: training iterations (configs[3] shapes, batch --train-batch) timed AFTER the timed "
+                         "region for the line's \"train\" object (3 warm-up iterations first); 0 = skip")
+    ap.add_argument("--train-batch", type=int, default=8)
     ap.add_argument("--no-lookahead-steps", type=int, default=20,
                     help="steps of the extra pass AFTER the timed region with one sampling launch per batch and no enlarged "
                          "first launch (value_no_lookahead); 0 = skip")
@@ -271,13 +275,14 @@ def _pts(n):
     return "{:,}".format(int(n)).replace(",", " ")
 
 
-def run_train(args, rank, world, dev):
-    """configs[3-4]: K training iterations of ``train_step.RefineTrainer`` on this rank's scenes (synthetic labels)."""
+def measure_train(args, rank, world, dev, steps, warmup, batch):
+    """configs[3-4]: ``steps`` training iterations of ``train_step.RefineTrainer`` on this rank's scenes (synthetic labels,
+    fresh random-init networks).  Returns the fields of a bench line (rank 0) or None."""
     from regnet_for_3d_grasping_amd import pipeline, sharding, synthetic
     from regnet_for_3d_grasping_amd.gripper_region_network import GripperRegionNetwork
     from regnet_for_3d_grasping_amd.score_network import ScoreNetwork
     from regnet_for_3d_grasping_amd.train_step import RefineTrainer
-    B, N = args.batch, args.points
+    B, N = batch, args.points
     pc_cpu = synthetic.make_batch(1000 + rank * B, B, N)
     records = [synthetic.make_grasp_labels(pc_cpu[b].numpy(), 50 + rank * B + b) for b in range(B)]
     target = torch.from_numpy(np.random.default_rng(2 + rank).uniform(0, 1, (B, N)).astype(np.float32)).to(dev)
@@ -294,6 +299,7 @@ def run_train(args, rank, world, dev):
     # the iteration) on the stream they are launched on, inside the timed region
     from regnet_for_3d_grasping_amd import conv1x1_train
     timer = OpTimer(every=args.time_every)
+    originals = {name: getattr(conv1x1_train, name) for name in conv1x1_train.TIMED_OPS}
     for name, meta in conv1x1_train.TIMED_OPS.items():
         timer.wrap(conv1x1_train, name, meta)
 
@@ -305,7 +311,7 @@ def run_train(args, rank, world, dev):
     # steady state of a training loop: the geometry (FPS / ball query / 3-NN: xyz only) of the NEXT batch is enqueued
     # on a side stream before each iteration, as a data loader with one batch of look-ahead would
     ahead = trainer.prefetch(pc)
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         nxt = trainer.prefetch(pc)
         trainer.step(pc, target, records, plan=ahead)
         ahead = nxt
@@ -313,27 +319,40 @@ def run_train(args, rank, world, dev):
     timer.enabled = True
     t0 = time.perf_counter()
     region_steps = 0
-    for _ in range(args.steps):
+    allreduce_ms = []
+    for _ in range(steps):
         nxt = trainer.prefetch(pc)
         loss, parts = trainer.step(pc, target, records, plan=ahead)
         ahead = nxt
         region_steps += "region_error" not in parts
+        if trainer.bucket is not None and trainer.bucket.last_ms is not None:
+            allreduce_ms.append(trainer.bucket.last_ms)
     fence()
     dt = sharding.max_over_ranks(time.perf_counter() - t0, dev)
     timer.enabled = False
-    if rank == 0:
-        _, roofline = roofline_of(timer.summary(), args.steps, B)
-        grads = sum(p.numel() for net in (score_net, region_net) for p in net.parameters())
-        print(json.dumps({
-            "metric": "train scenes/sec (%s-pt ScoreNet+GRN+Refine training iteration)" % _pts(N), "value": round(B * args.steps * world / dt, 3),
-            "unit": "scenes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+    for name, fn in originals.items():
+        setattr(conv1x1_train, name, fn)
+    if rank != 0:
+        return None
+    _, roofline = roofline_of(timer.summary(), steps, B)
+    grads = sum(p.numel() for net in (score_net, region_net) for p in net.parameters())
+    return {"metric": "train scenes/sec (%s-pt ScoreNet+GRN+Refine training iteration)" % _pts(N),
+            "value": round(B * steps * world / dt, 3), "unit": "scenes/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic", "roofline": roofline,
+            # event-timed duration of the iteration's single flat gradient all-reduce (RCCL, side stream); null at 1 GPU
+            "allreduce_ms": round(sum(allreduce_ms) / len(allreduce_ms), 4) if allreduce_ms else None,
             "config": {"workload": "configs[3]: training iteration (forward with labels, stage-2 + refine losses, backward, "
                                    "two Adam steps), %d-pt synthetic scenes, batch=%d per GPU" % (N, B),
                        "points": N, "batch_per_gpu": B, "global_batch": B * world,
-                       "parallelism": "dp%d: one flat fp32 gradient all-reduce per network (%d elements) over RCCL" % (world, grads),
-                       "steps_with_region_losses": region_steps, "last_loss": float(loss)}}))
+                       "parallelism": "dp%d: ONE flat fp32 gradient all-reduce per iteration (%d elements, both networks) over RCCL" % (world, grads),
+                       "steps_with_region_losses": region_steps, "last_loss": float(loss)}}
+
+
+def run_train(args, rank, world, dev):
+    res = measure_train(args, rank, world, dev, args.steps, args.warmup, args.batch)
+    if rank == 0:
+        print(json.dumps(res))
 
 
 def roofline_of(agg, steps, batch, critical=None):
@@ -509,6 +528,12 @@ def main():
         latency_ms = round((time.perf_counter() - t1) / args.latency_runs * 1e3, 3)
         np.random.set_state(state)
 
+    train_line = None
+    if args.train_steps > 0 and not args.score_only:
+        # configs[3]'s training iteration on the same box, after the timed region (every rank takes part: the gradient
+        # all-reduce is a collective)
+        train_line = measure_train(args, rank, world, dev, args.train_steps, 3, args.train_batch)
+
     if rank == 0:
         total_scenes = args.batch * args.steps * world
         agg = main_summary
@@ -566,6 +591,12 @@ def main():
             res["roofline_exclusive"] = r1
         else:
             res.pop("roofline_exclusive")
+        if train_line is not None:
+            res["train"] = {"scenes_per_s": train_line["value"], "ms_per_step": train_line["ms_per_step"],
+                            "steps": train_line["steps"], "warmup": train_line["warmup"],
+                            "batch_per_gpu": args.train_batch, "roofline": train_line["roofline"],
+                            "allreduce_ms": train_line["allreduce_ms"], "workload": train_line["config"]["workload"],
+                            "note": "measured after the timed region; `python bench.py --train` times it alone"}
         if world == 1 and args.cpu_scenes > 0:
             res["cpu_baseline"] = cpu_baseline(args, args.cpu_scenes, (score_net, region_net))
             res["parity"] = res["cpu_baseline"].pop("parity")

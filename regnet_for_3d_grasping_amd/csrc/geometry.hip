@@ -583,6 +583,9 @@ static int fps_num_cus() {
 // float array of running distances for the streaming kernel.  The callee initialises the workspace.
 extern "C" int64_t regnet_fps_workspace_bytes(int64_t B, int64_t N, int64_t M) {
   (void)M;
+#ifdef FPS_FORCE_MULTI
+  if (N > 8192 && N <= FPS_RESIDENT_MAX) return B * 64;
+#endif
   if (N <= FPS_RESIDENT_MAX) return 0;
   const int64_t stream_bytes = B * N * (int64_t)sizeof(float), slot_bytes = B * 64;
   return stream_bytes > slot_bytes ? stream_bytes : slot_bytes;
@@ -607,6 +610,19 @@ extern "C" int regnet_fps_f32(const float* xyz, int64_t sb, int64_t sc, int64_t 
   // The in-thread scan keeps the first strict maximum in slot order; that equals the reference's
   // order only if all points of a thread share one reference lane (j mod RB), i.e. T % RB == 0 or
   // one point per thread.  Hence T = RB (PPT 1) up to 512 points and T in {512, 1024} above.
+#ifdef FPS_FORCE_MULTI   // measurement builds only (scripts/fps_multi_probe.py): G cooperating workgroups also for N <= 25 600
+  if (N > 8192 && N <= FPS_RESIDENT_MAX && M < 32768 && FPS_FORCE_MULTI * B <= fps_num_cus()) {
+    if (!workspace) return REGNET_ERR_NULL;
+    const int G = FPS_FORCE_MULTI;
+    const int Bpad = (int)((B + 7) / 8 * 8);
+    hipError_t e = hipMemsetAsync(workspace, 0, (size_t)B * 64, st);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL((fps_multi_kernel<25>), dim3((unsigned)(Bpad * G)), dim3(1024), 0, st, xyz, sb, sc, sn, (int)N,
+                       (int)M, rbl, G, (int)B, Bpad, (unsigned long long*)workspace, index);
+    REGNET_LAUNCH_CHECK();
+    return REGNET_OK;
+  }
+#endif
   if (N <= 64) FPS_CASE(64, 1);
   else if (N <= 128) FPS_CASE(128, 1);
   else if (N <= 256) FPS_CASE(256, 1);

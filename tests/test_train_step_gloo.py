@@ -136,13 +136,22 @@ def _refine_worker(rank, world, port, out_dir, fail_rank, no_refine_rank):
             res[13] = res[13][:2]
             return tuple(res)
         region_net.forward = no_refine
+    calls = []
+    orig_all_reduce = td.all_reduce
+
+    def counting_all_reduce(t, *a, **k):
+        calls.append(int(t.numel()))
+        return orig_all_reduce(t, *a, **k)
+    td.all_reduce = counting_all_reduce
     with oracle_backend():
         total, parts = trainer.step(pc, pc_score, records)
+    td.all_reduce = orig_all_reduce
     named = list(score_net.named_parameters()) + [("region." + k, p) for k, p in region_net.named_parameters()]
     torch.save({"start": start, "total": float(total), "region_error": parts.get("region_error"),
                 "stage2": parts["stage2"] is not None, "refine": parts["refine"] is not None,
                 "params": {k: p.detach().clone() for k, p in named},
-                "has_grad": {k: p.grad is not None for k, p in named}},
+                "has_grad": {k: p.grad is not None for k, p in named}, "all_reduce_sizes": calls,
+                "n_params": len(named), "n_grad": sum(p.numel() for _, p in named)},
                os.path.join(out_dir, "refine_rank%d.pt" % rank))
     td.destroy_process_group()
 
@@ -174,6 +183,8 @@ def test_refine_trainer_two_ranks_one_rank_without_region_stage(tmp_path):
         assert r0["has_grad"][k] == r1["has_grad"][k], k
         moved += int(r0["has_grad"][k])
     # rank 1 received the region network's gradients from rank 0; the never-used layer stays grad-less everywhere
+    # ONE collective per iteration, same length on both ranks: every gradient of BOTH networks + one flag per parameter
+    assert r0["all_reduce_sizes"] == r1["all_reduce_sizes"] == [r0["n_grad"] + r0["n_params"]]
     assert r1["has_grad"]["region.extrat_feature_region.conv.weight"]
     assert not r0["has_grad"]["region.extrat_feature_region.linear_cls.weight"]
     assert moved > 80
@@ -182,6 +193,7 @@ def test_refine_trainer_two_ranks_one_rank_without_region_stage(tmp_path):
 def test_refine_trainer_two_ranks_one_rank_without_refine_loss(tmp_path):
     r0, r1 = _run_refine(tmp_path, fail_rank=-1, no_refine_rank=0)
     assert r0["stage2"] and not r0["refine"] and r1["stage2"]
+    assert r0["all_reduce_sizes"] == r1["all_reduce_sizes"] == [r0["n_grad"] + r0["n_params"]]
     for k in r0["params"]:
         assert torch.equal(r0["params"][k], r1["params"][k]), k
         assert r0["has_grad"][k] == r1["has_grad"][k], k
