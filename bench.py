@@ -69,6 +69,9 @@ def parse():
                     help="steps of the extra pass AFTER the timed region with one sampling launch per batch and no enlarged "
                          "first launch (value_no_lookahead); 0 = skip")
     ap.add_argument("--lookahead", type=int, default=3, help="batches whose region stage may be pending (pipeline depth)")
+    ap.add_argument("--set", action="append", default=[], metavar="module.NAME=0|1",
+                    help="A/B measurement only: flip a module-level switch of the package before the run, e.g. "
+                         "--set fused.FP_HEAD_INTERP=0 (reported in config.switches)")
     return ap.parse_args()
 
 
@@ -188,7 +191,7 @@ def _mlp_layer_kernel(d):
 
 KERNEL_OF = {"native_fwd": "tgemm_kernel", "native_dgrad": "tgemm_kernel", "native_wgrad": "tgemm_kernel",
              "mlp_layer": _mlp_layer_kernel, "sa_layer1": "mlp_gemm_kernel", "sa_layer12": "mlp_gemm_kernel",
-             "sa_premul_layer": "mlp_gemm_kernel<3>", "sa_chain3": "sa_chain_kernel", "fp_head_chain": "fp_head_chain_kernel", "sa_premul_chain": "sa_premul_chain_kernel", "sa3_premul_chain": "sa3_premul_chain_kernel",
+             "sa_premul_layer": "mlp_gemm_kernel<3>", "sa_chain3": "sa_chain_kernel", "fp_head_chain": "fp_head_chain_kernel", "fp_head_chain_interp": "fp_head_chain_kernel", "sa_premul_chain": "sa_premul_chain_kernel", "sa3_premul_chain": "sa3_premul_chain_kernel",
              "farthest_point_sample": "fps_kernel", "ball_query": "ball_query_kernel",
              "point_search": "three_nn_kernel", "radius_candidates": "radius_group_kernel",
              "box_candidates": "box_crop_kernel", "gather_max": "gather_max_kernel"}
@@ -430,6 +433,13 @@ def main():
         return
 
     from regnet_for_3d_grasping_amd import pipeline, synthetic
+    import importlib
+    for item in args.set:
+        target, value = item.split("=")
+        mod, name = target.rsplit(".", 1)
+        module = importlib.import_module("regnet_for_3d_grasping_amd." + mod)
+        assert isinstance(getattr(module, name), bool), target
+        setattr(module, name, value not in ("0", "false", "False"))
     timer = OpTimer(args.time_every)
     install_timers(timer)
 
@@ -569,6 +579,7 @@ def main():
                        # batches the pipeline pulled from its input before the first result could exist (the first sampling
                        # launch of the timed run); steady state: up to 2 x sampling_group_batches
                        "sampling_lookahead_batches": first_launch_batches,
+                       "switches": args.set or None,
                        "scorenet_gflop_per_scene": SCORENET_GFLOP_PER_SCENE.get(args.points),
                        "executed_gflop_per_scene": round(sum(f["units"] for f in fam.values() if f["bound"] == "mfma")
                                                          / 1e9 / max(args.steps * args.batch, 1), 2)},

@@ -376,6 +376,17 @@ int regnet_sa3_premul_chain_f32(const float* U, int64_t ldu, const float* V, int
  * `ticket`: one int32 in device memory, ZERO when the kernel starts (the caller clears it on the same stream): the
  * work queue through which the resident workgroups draw their 128-row blocks.                                          */
 int64_t regnet_fp_head_chain_stream_floats(void);
+/* regnet_fp_head_chain_interp_f32: the same chain with the block's FIRST layer in its prologue -- 3-NN interpolation of
+ * the pre-multiplied sparse rows + the narrow skip input + folded BN + ReLU, i.e. regnet_interp_affine_f32's arithmetic
+ * (pn2_utils/modules.py:104-131, :500-509) -- so that the (P x 256) first-layer activation is never written:
+ * Ys (B, Ns, 256) with element strides ys_sb / ys_sn; idx / dist2 (B*Nd, 3); dense_small (B, Cd <= 4, Nd) with element
+ * strides db / dn / dc or NULL; tables = Wd4 (256 x 4) | scale1 (256) | shift1 (256); everything else as above.        */
+int regnet_fp_head_chain_interp_f32(const float* Ys, int64_t ys_sb, int64_t ys_sn, const int64_t* idx,
+                                    const float* dist2, float eps, const float* dense_small, int64_t db, int64_t dn,
+                                    int64_t dc, int64_t Cd_small, const float* tables, int64_t B, int64_t Nd,
+                                    const float* stream_w, int64_t n_stages, const float* affine, int64_t affine_floats,
+                                    const float* wscore, float score_bias, float score_bn_scale, float score_bn_shift,
+                                    float* F, int64_t ldf, float* score, int32_t* ticket, void* stream);
 int regnet_fp_head_chain_f32(const float* X, int64_t ldx, const float* stream_w, int64_t n_stages,
                              const float* affine, int64_t affine_floats, const float* wscore, float score_bias,
                              float score_bn_scale, float score_bn_shift, float* F, int64_t ldf, float* score,

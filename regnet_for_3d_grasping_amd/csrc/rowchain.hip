@@ -48,6 +48,7 @@ typedef float rc_f32x4 __attribute__((ext_vector_type(4)));
                                                // SLOWER per kernel, same step time); 0: all right behind the barrier
 #endif
 #define RC_AFFINE_MAX 4096                     // floats of folded BN affine kept in LDS
+#define RC_INTERP_FLOATS 1536                  // + the interpolating prologue's tables: Wd4 (256 x 4) | scale1 (256) | shift1 (256)
 
 struct RcArgs {
   const float* X;  long long ldx;              // (P, 256) first-layer activation (channels-last), 16-byte aligned rows
@@ -63,6 +64,12 @@ struct RcArgs {
   int* ticket;                                 // work queue head (zeroed by the caller before the launch)
   long long n_blocks;                          // tickets to hand out: n_full whole blocks (8 waves) + half blocks (waves 0-3)
   long long n_full;                            // tickets < n_full are whole blocks; ticket t >= n_full: half block t - n_full
+  // ---- interpolating prologue (fp_head_chain_kernel<true>): the first FP layer is evaluated right here, X is not read
+  const float* ys; long long ys_sb, ys_sn;     // (B, Ns, 256) sparse rows already multiplied by the layer's W[:, :Cs]
+  const long long* idx; const float* dist2;    // (P, 3) three nearest sparse points and their SQUARED distances
+  float eps; long long Nd;                     // weights 1 / max(d2, eps), normalised (modules.py:117-122); points per scene
+  const float* dsm; long long db, dn, dc; int Cdsm;   // narrow skip input (B, Cd <= 4, Nd), element strides (rgb)
+  const float* tables;                         // Wd4 (256 x 4) | scale1 (256) | shift1 (256)
 };
 
 __device__ __forceinline__ void rc_glds16(const float* gsrc, unsigned lds_dst) {
@@ -269,14 +276,20 @@ __device__ __forceinline__ void rc_pair(const rc_f32x4 (&xin)[16], rc_f32x4 (&xo
 // FP3 tail + segmentation head: 256 -> 256 -> [F] 256 -> 512 -> 256 -> 256 -> 128 -> score, as three layer pairs.
 // Stages per pass: 2 x (4 + 4) + 4 x (4 + 4) + 2 x (4 + 2) = 60.  Affine table (floats): layer i at the sum of 2 N of
 // the layers before it: 0, 512, 1024, 2048, 2560, 3072 (total 3328).
+// INTERP: the block's first layer (pn2_utils/modules.py:104-131 + the first SharedMLP layer, evaluated on the sparse rows:
+// fused._fp_first_layer) happens in the prologue -- x0 = relu(scale1 (sum_k w_k Ys[idx_k] + Wd4 . rgb) + shift1) -- instead
+// of in interp_affine_kernel, whose (P x 256) output (210 MB per batch of 8 written, then read here) never exists.
+template <bool INTERP>
 __global__ __launch_bounds__(RC_THREADS, 2) void fp_head_chain_kernel(const RcArgs p) {
-  extern __shared__ __attribute__((aligned(1024))) float smem[];   // ring | affine | wscore
+  extern __shared__ __attribute__((aligned(1024))) float smem[];   // ring | affine | wscore | ticket | (interp tables)
   float* const aff = smem + RC_STAGES * RC_STAGE_FLOATS;
   float* const wsc = aff + RC_AFFINE_MAX;
+  float* const itab = wsc + 128 + 4;
   const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   for (int i = tid; i < p.affine_floats; i += RC_THREADS) aff[i] = p.affine[i];
   for (int i = tid; i < 128; i += RC_THREADS) wsc[i] = p.wscore[i];
+  if (INTERP) for (int i = tid; i < RC_INTERP_FLOATS; i += RC_THREADS) itab[i] = p.tables[i];
 #ifndef RC_NO_TABLE_SYNC
   __syncthreads();   // the tables are read after the ring's barriers, which do not wait for LDS writes (lgkmcnt)
 #endif
@@ -319,10 +332,50 @@ __global__ __launch_bounds__(RC_THREADS, 2) void fp_head_chain_kernel(const RcAr
     if (!row_ok) row = 0;
     // ---- h1: x0[kt] = X[row][16 kt + 4 g ..]
     rc_f32x4 x0[16];
-    {
+    if (!INTERP) {
       const float* xr = p.X + row * p.ldx + 4 * g;
 #pragma unroll
       for (int kt = 0; kt < 16; ++kt) x0[kt] = *reinterpret_cast<const rc_f32x4*>(xr + 16 * kt);
+    } else {
+      const long long b = row / p.Nd;
+      const long long j0 = p.idx[row * 3], j1 = p.idx[row * 3 + 1], j2 = p.idx[row * 3 + 2];
+      const float i0 = 1.0f / fmaxf(p.dist2[row * 3], p.eps), i1 = 1.0f / fmaxf(p.dist2[row * 3 + 1], p.eps),
+                  i2 = 1.0f / fmaxf(p.dist2[row * 3 + 2], p.eps);
+      const float norm = (i0 + i1) + i2;
+      const float w0 = i0 / norm, w1 = i1 / norm, w2 = i2 / norm;
+      float d[4] = {0.f, 0.f, 0.f, 0.f};
+      if (p.dsm) {
+        const float* dp = p.dsm + b * p.db + (row - b * p.Nd) * p.dn;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) d[c] = c < p.Cdsm ? dp[(long long)(c < p.Cdsm ? c : 0) * p.dc] : 0.f;
+      }
+      const float* r0 = p.ys + b * p.ys_sb + j0 * p.ys_sn + 4 * g;
+      const float* r1 = p.ys + b * p.ys_sb + j1 * p.ys_sn + 4 * g;
+      const float* r2 = p.ys + b * p.ys_sb + j2 * p.ys_sn + 4 * g;
+#pragma unroll
+      for (int kq = 0; kq < 8; ++kq) {     // two k-tiles' gathers (six 16-byte loads) in flight at a time
+        rc_f32x4 a0[2], a1[2], a2[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          a0[t] = *reinterpret_cast<const rc_f32x4*>(r0 + 16 * (2 * kq + t));
+          a1[t] = *reinterpret_cast<const rc_f32x4*>(r1 + 16 * (2 * kq + t));
+          a2[t] = *reinterpret_cast<const rc_f32x4*>(r2 + 16 * (2 * kq + t));
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int c0 = 16 * (2 * kq + t) + 4 * g;          // this lane's four channels of the k-tile
+          const rc_f32x4 sc = *reinterpret_cast<const rc_f32x4*>(itab + 1024 + c0);
+          const rc_f32x4 sh = *reinterpret_cast<const rc_f32x4*>(itab + 1280 + c0);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const rc_f32x4 wq = *reinterpret_cast<const rc_f32x4*>(itab + 4 * (c0 + r));
+            float v = (a0[t][r] * w0 + a1[t][r] * w1) + a2[t][r] * w2;
+            v += ((wq.x * d[0] + wq.y * d[1]) + wq.z * d[2]) + wq.w * d[3];
+            x0[2 * kq + t][r] = fmaxf(v * sc[r] + sh[r], 0.f);
+          }
+        }
+        RC_PIN();
+      }
     }
     rc_f32x4 x2[16];
     rc_pair<256, 256, true>(x0, x2, ring, smem, aff + 0, aff + 512, active, fo);
@@ -699,11 +752,12 @@ static bool rc_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p)
 
 // > 64 KiB of dynamic LDS needs the function attribute, once per (kernel, device) -- one process may drive several GPUs
 static int rc_allow_lds(const void* kernel, size_t bytes) {
-  static unsigned long long done[3] = {0ull, 0ull, 0ull};   // bit per device id < 64, per kernel
+  static unsigned long long done[4] = {0ull, 0ull, 0ull, 0ull};   // bit per device id < 64, per kernel
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return (int)hipGetLastError();
-  const int which = kernel == reinterpret_cast<const void*>(fp_head_chain_kernel) ? 0
-                  : kernel == reinterpret_cast<const void*>(sa_premul_chain_kernel) ? 1 : 2;
+  const int which = kernel == reinterpret_cast<const void*>(fp_head_chain_kernel<false>) ? 0
+                  : kernel == reinterpret_cast<const void*>(sa_premul_chain_kernel) ? 1
+                  : kernel == reinterpret_cast<const void*>(sa3_premul_chain_kernel) ? 2 : 3;
   if (dev >= 0 && dev < 64 && (done[which] >> dev) & 1ull) return REGNET_OK;
   hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
   if (e != hipSuccess) return (int)e;
@@ -776,6 +830,27 @@ extern "C" int regnet_sa3_premul_chain_f32(const float* U, int64_t ldu, const fl
 
 extern "C" int64_t regnet_fp_head_chain_stream_floats(void) { return 60ll * RC_STAGE_FLOATS; }
 
+static int rc_launch_fp_head(RcArgs& a, bool interp, void* stream_handle) {
+  {
+    const long long units = (a.P + 15) / 16, blocks = (units + RC_WAVES - 1) / RC_WAVES;
+    const long long split = (RC_WAVES == 8 && RC_TAIL_HALF) ? (blocks < 128 ? blocks : 128) : 0;
+    a.n_full = blocks - split;
+    const long long rest = units - a.n_full * RC_WAVES;        // 16-row units left for half blocks (4 each)
+    a.n_blocks = a.n_full + (rest > 0 ? (rest + RC_WAVES / 2 - 1) / (RC_WAVES / 2) : 0);
+  }
+  const int cus = 256 * RC_WG_PER_CU;
+  const long long wgs = a.n_blocks < cus ? a.n_blocks : cus;
+  const size_t lds = (size_t)(RC_STAGES * RC_STAGE_FLOATS + RC_AFFINE_MAX + 128 + 4 + (interp ? RC_INTERP_FLOATS : 0)) * sizeof(float);
+  const void* kernel = interp ? reinterpret_cast<const void*>(fp_head_chain_kernel<true>)
+                              : reinterpret_cast<const void*>(fp_head_chain_kernel<false>);
+  int rc_attr = rc_allow_lds(kernel, lds);
+  if (rc_attr) return rc_attr;
+  if (interp) hipLaunchKernelGGL(fp_head_chain_kernel<true>, dim3((unsigned)wgs), dim3(RC_THREADS), lds, as_stream(stream_handle), a);
+  else hipLaunchKernelGGL(fp_head_chain_kernel<false>, dim3((unsigned)wgs), dim3(RC_THREADS), lds, as_stream(stream_handle), a);
+  REGNET_LAUNCH_CHECK();
+  return REGNET_OK;
+}
+
 extern "C" int regnet_fp_head_chain_f32(const float* X, int64_t ldx, const float* stream, int64_t n_stages,
                                         const float* affine, int64_t affine_floats, const float* wscore,
                                         float score_bias, float score_bn_scale, float score_bn_shift, float* F,
@@ -791,19 +866,31 @@ extern "C" int regnet_fp_head_chain_f32(const float* X, int64_t ldx, const float
   a.stream = stream; a.n_stages = (int)n_stages; a.affine = affine; a.affine_floats = (int)affine_floats;
   a.wscore = wscore; a.score_bias = score_bias; a.score_bn_scale = score_bn_scale; a.score_bn_shift = score_bn_shift;
   a.ticket = ticket;
-  {
-    const long long units = (P + 15) / 16, blocks = (units + RC_WAVES - 1) / RC_WAVES;
-    const long long split = (RC_WAVES == 8 && RC_TAIL_HALF) ? (blocks < 128 ? blocks : 128) : 0;
-    a.n_full = blocks - split;
-    const long long rest = units - a.n_full * RC_WAVES;        // 16-row units left for half blocks (4 each)
-    a.n_blocks = a.n_full + (rest > 0 ? (rest + RC_WAVES / 2 - 1) / (RC_WAVES / 2) : 0);
-  }
-  const int cus = 256 * RC_WG_PER_CU;
-  const long long wgs = a.n_blocks < cus ? a.n_blocks : cus;
-  const size_t lds = (size_t)(RC_STAGES * RC_STAGE_FLOATS + RC_AFFINE_MAX + 128 + 4) * sizeof(float);
-  int rc_attr = rc_allow_lds(reinterpret_cast<const void*>(fp_head_chain_kernel), lds);
-  if (rc_attr) return rc_attr;
-  hipLaunchKernelGGL(fp_head_chain_kernel, dim3((unsigned)wgs), dim3(RC_THREADS), lds, as_stream(stream_handle), a);
-  REGNET_LAUNCH_CHECK();
-  return REGNET_OK;
+  return rc_launch_fp_head(a, false, stream_handle);
+}
+
+extern "C" int regnet_fp_head_chain_interp_f32(const float* Ys, int64_t ys_sb, int64_t ys_sn, const int64_t* idx,
+                                               const float* dist2, float eps, const float* dense_small, int64_t db,
+                                               int64_t dn, int64_t dc, int64_t Cd_small, const float* tables,
+                                               int64_t B, int64_t Nd, const float* stream, int64_t n_stages,
+                                               const float* affine, int64_t affine_floats, const float* wscore,
+                                               float score_bias, float score_bn_scale, float score_bn_shift, float* F,
+                                               int64_t ldf, float* score, int32_t* ticket, void* stream_handle) {
+  if (B < 0 || Nd < 0 || ldf < 256 || (ldf & 3) || n_stages != 60 || affine_floats != 3328 || (ys_sb & 3) || (ys_sn & 3) ||
+      ys_sn < 256 || (dense_small && (Cd_small < 1 || Cd_small > 4)))
+    return REGNET_ERR_SHAPE;
+  const long long P = B * Nd;
+  if (P == 0) return REGNET_OK;
+  if (!Ys || !idx || !dist2 || !tables || !stream || !affine || !wscore || !F || !score || !ticket) return REGNET_ERR_NULL;
+  if (!rc_aligned16(Ys) || !rc_aligned16(F) || !rc_aligned16(stream) || !rc_aligned16(affine) || !rc_aligned16(wscore) ||
+      !rc_aligned16(tables))
+    return REGNET_ERR_SHAPE;
+  RcArgs a = {};
+  a.F = F; a.ldf = ldf; a.score = score; a.P = P;
+  a.stream = stream; a.n_stages = (int)n_stages; a.affine = affine; a.affine_floats = (int)affine_floats;
+  a.wscore = wscore; a.score_bias = score_bias; a.score_bn_scale = score_bn_scale; a.score_bn_shift = score_bn_shift;
+  a.ticket = ticket;
+  a.ys = Ys; a.ys_sb = ys_sb; a.ys_sn = ys_sn; a.idx = (const long long*)idx; a.dist2 = dist2; a.eps = eps; a.Nd = Nd;
+  a.dsm = dense_small; a.db = db; a.dn = dn; a.dc = dc; a.Cdsm = (int)Cd_small; a.tables = tables;
+  return rc_launch_fp_head(a, true, stream_handle);
 }

@@ -282,7 +282,15 @@ def _fp_split_layers(first, Cs):
             wd4[:, :Cd] = first.W[:first.N, Cs:first.K]
             wd4 = wd4.contiguous()
         first.premul = (part(first.W[:, :Cs]), part(first.W[:, Cs:first.K]) if Cd > 4 else None, wd4)
-    return first.premul
+    return first.premul[:3]
+
+
+def _interp_tables(first, wd4):
+    """Wd4 (256 x 4) | scale1 (256) | shift1 (256): the tables of fp_head_chain_interp's prologue, cached on the layer."""
+    if len(first.premul) < 4:
+        wd = wd4 if wd4 is not None else torch.zeros((256, 4), dtype=torch.float32, device=first.W.device)
+        first.premul = tuple(first.premul[:3]) + (torch.cat([wd.reshape(-1), first.scale[:256], first.shift[:256]]).contiguous(),)
+    return first.premul[3]
 
 
 @_on_tensor_device
@@ -345,6 +353,8 @@ TIMED_OPS = {
         "P%d K256 N512 flop%d" % (B * M * 64, 2 * B * M * 64 * (256 * 256 + 256 * 512)),
     "sa3_premul_chain": lambda U, V, nbr, module, layers, B, Nsrc, M:
         "P%d K512 N1024 flop%d" % (B * M * 64, 2 * B * M * 64 * (512 * 512 + 512 * 1024)),
+    "fp_head_chain_interp": lambda Ys, idx, dist2, eps, dense_small, wd4, first, seg, fp_layers, B, Ns, Nd:
+        "P%d K256 N256 flop%d" % (B * Nd, 2 * B * Nd * 491520),
     "fp_head_chain": lambda h1, seg, fp_layers, P: "P%d K256 N256 flop%d" % (P, 2 * P * 491520),
     "sa_layer12": lambda feature, xyz, nbr, ctr, first, layer, B, M, group, pool_group=0:
         "P%d K%d N%d flop%d" % (B * M * group, layer.K, layer.N,
@@ -674,6 +684,32 @@ def fp_head_chain(h1, seg, fp_layers, P):
     return F, score
 
 
+FP_HEAD_INTERP = True   # ... with the block's first layer (interpolation of the pre-multiplied sparse rows) in its prologue
+
+
+@_on_tensor_device
+def fp_head_chain_interp(Ys, idx, dist2, eps, dense_small, wd4, first, seg, fp_layers, B, Ns, Nd):
+    """(Ys (B*Ns, 256) pre-multiplied sparse rows, 3-NN indices / squared distances, rgb-like skip input) -> (F, score):
+    the whole last feature-propagation block + the segmentation head in one launch; h1 is never written."""
+    stream, affine = _packed_rowchain(seg, fp_layers)
+    w, bias, bn_scale, bn_shift = _packed_head(seg)
+    tables = _interp_tables(first, wd4)
+    P = B * Nd
+    F = torch.empty((P, 256), dtype=torch.float32, device=Ys.device)
+    score = torch.empty((P,), dtype=torch.float32, device=Ys.device)
+    ticket = torch.zeros((1,), dtype=torch.int32, device=Ys.device)
+    if dense_small is None:
+        dptr, db, dc, dn, Cd = None, 0, 0, 0, 0
+    else:
+        dptr, (db, dc, dn), Cd = dense_small.data_ptr(), dense_small.stride(), dense_small.size(1)
+    _check(_L.regnet_fp_head_chain_interp_f32(Ys.data_ptr(), Ns * Ys.stride(0), Ys.stride(0), idx.data_ptr(),
+                                              dist2.data_ptr(), float(eps), dptr, db, dn, dc, Cd, tables.data_ptr(), B, Nd,
+                                              stream.data_ptr(), 60, affine.data_ptr(), affine.numel(), w.data_ptr(), bias,
+                                              bn_scale, bn_shift, F.data_ptr(), F.stride(0), score.data_ptr(),
+                                              ticket.data_ptr(), _stream(Ys)), "fp_head_chain_interp")
+    return F, score
+
+
 def fp_head_forward(seg, fp_module, dense_xyz, dense_feature, sparse_feature, geo):
     """Last feature-propagation block + segmentation head (pointnet2.py:64-84, :116-119) -> (feature (B,256,N) view,
     score (B,N)); None when the chained kernel does not apply (the caller then runs the two blocks separately)."""
@@ -681,6 +717,18 @@ def fp_head_forward(seg, fp_module, dense_xyz, dense_feature, sparse_feature, ge
         return None
     B, _, Nd = dense_xyz.shape
     layers = _packed_stack(fp_module, fp_module.mlp)
+    Cs, Ns = sparse_feature.size(1), sparse_feature.size(2)
+    Cd = 0 if dense_feature is None else dense_feature.size(1)
+    first = layers[0]
+    if (FP_HEAD_INTERP and PREMUL and first.N == 256 and first.relu and Cs % 4 == 0 and Cd <= 4 and Ns < Nd
+            and first.K == Cs + Cd and sparse_feature.dtype == torch.float32
+            and (dense_feature is None or dense_feature.dtype == torch.float32)):
+        # the first layer on the SPARSE rows (fused._fp_first_layer), its interpolation inside the chain's prologue
+        lay_s, _, wd4 = _fp_split_layers(first, Cs)
+        Ys = mlp_layer(_as_channels_last(sparse_feature).view(B * Ns, Cs), Cs, lay_s, B * Ns)
+        F, score = fp_head_chain_interp(Ys, geo["idx"], geo["dist2"], fp_module.interpolator._eps,
+                                        dense_feature if wd4 is not None else None, wd4, first, seg, layers, B, Ns, Nd)
+        return F.view(B, Nd, 256).transpose(1, 2), score.view(B, Nd)
     h1 = _fp_first_layer(fp_module, layers, dense_xyz, dense_feature, sparse_feature, geo)
     if h1 is None:
         return None
@@ -709,7 +757,9 @@ def prepack(score_net, region_net=None):
         layers = _packed_stack(fp, fp.mlp)
         Cs = sparse
         if Cs <= layers[0].K:
-            _fp_split_layers(layers[0], Cs)
+            split = _fp_split_layers(layers[0], Cs)
+            if fp is seg.fp_modules[-1] and layers[0].N == 256:
+                _interp_tables(layers[0], split[2])
         sparse = fp.out_channels
     _packed_stack(seg.mlp, seg.mlp)
     _packed_head(seg)

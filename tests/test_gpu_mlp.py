@@ -456,3 +456,32 @@ def test_sa3_premul_chain_equals_layerwise_kernels(B, M):
             ref = x.squeeze(-1).view(B, 1024, M, 64).amax(-1).permute(0, 2, 1).reshape(B * M, 1024)
             score_net.float()
         torch.testing.assert_close(got.double(), ref, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("B,Nd,Ns", [(2, 1000, 200), (1, 129, 16), (8, 25600, 5120)])
+def test_fp_head_chain_interp_equals_interp_affine_then_chain(B, Nd, Ns):
+    """fp_head_chain_kernel<true> (first FP layer -- 3-NN interpolation of the pre-multiplied sparse rows + rgb skip + BN +
+    ReLU -- in the chain's prologue) against interp_affine_kernel followed by the plain chain: same F and scores up to
+    fp32 contraction order; ragged row counts and the bench shape."""
+    from regnet_for_3d_grasping_amd import fused, pipeline
+    torch.manual_seed(B * 1000 + Nd)
+    score_net, _ = pipeline.build_models(DEV)
+    seg = score_net.extrat_featurePN2
+    fp = seg.fp_modules[-1]
+    layers = fused._packed_stack(fp, fp.mlp)
+    Cs = layers[0].K - 3
+    lay_s, lay_d, wd4 = fused._fp_split_layers(layers[0], Cs)
+    assert lay_d is None and wd4 is not None
+    Ys = torch.randn(B * Ns, 256, device=DEV)
+    idx = torch.randint(0, Ns, (B, Nd, 3), device=DEV)
+    dist2 = torch.rand(B, Nd, 3, device=DEV) * 1e-3
+    dist2[0, 0, 0] = 0.0                                  # coincident point: the eps clamp
+    rgb = torch.rand(B, Nd, 6, device=DEV).permute(0, 2, 1)[:, 3:6, :]   # strided view like the network's
+    eps = fp.interpolator._eps
+    h1 = fused.interp_affine(Ys, idx, dist2, eps, None, rgb, wd4, layers[0], B, Ns, Nd)
+    F_ref, s_ref = fused.fp_head_chain(h1, seg, layers, B * Nd)
+    F, s = fused.fp_head_chain_interp(Ys, idx, dist2, eps, rgb, wd4, layers[0], seg, layers, B, Ns, Nd)
+    torch.cuda.synchronize()
+    assert torch.isfinite(F).all() and torch.isfinite(s).all()
+    torch.testing.assert_close(F, F_ref, rtol=2e-5, atol=2e-5)
+    torch.testing.assert_close(s, s_ref, rtol=0, atol=2e-5)
