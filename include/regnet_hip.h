@@ -245,10 +245,12 @@ int regnet_grasp_antipodal_stats_f32(const float* points, int64_t pn, int64_t pc
  * ascending member lists of regnet_radius_group_f32; pos (B,Nc,G) int64: positions into them drawn on the host with numpy's
  * RNG stream (-1 in every slot of a centre without candidates); pc (B,N,C) rows with element strides (pb, pn), channels
  * contiguous.  index[b,c,g] = cand[b,c,pos[b,c,g]] and points[b,c,g,:] = pc[b,index,:], or -1 / -1.0f where pos < 0 (the
- * reference fills empty groups with -1, :346-350).  Replaces seven tensor ops per pass.                                  */
+ * reference fills empty groups with -1, :346-350).  Replaces seven tensor ops per pass.
+ * A position >= cap or a candidate outside [0, N) (an upstream count / capacity mismatch; the torch.gather this replaces
+ * raised on it) reads nothing, yields -1 and ORs 1 into *out_of_range (device int32, may be NULL).                       */
 int regnet_resample_groups_f32(const float* pc, int64_t pb, int64_t pn, int64_t C, const int32_t* cand, int64_t cap,
-                               const int64_t* pos, int64_t B, int64_t Nc, int64_t G, int64_t* index, float* points,
-                               void* stream);
+                               const int64_t* pos, int64_t B, int64_t Nc, int64_t G, int64_t N, int32_t* out_of_range,
+                               int64_t* index, float* points, void* stream);
 
 /* regnet_estimate_normals_f32: surface normals of a scene cloud for validation records that carry no scene_normal --
  * dataset_utils/eval_score/eval_utils/torch_scene_point_cloud.py:17-19 -> eval_utils/pointcloud.py:27-43, i.e. open3d's

@@ -52,7 +52,7 @@ SIGNATURES = {
                                                  _vp, _vp]),
     "regnet_grasp_antipodal_stats_f32": (_int, [_vp, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _i64, _f32, _f32, _vp, _f32,
                                                 _f32, _f32, _f32, _f32, _vp, _vp, _vp]),
-    "regnet_resample_groups_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _vp]),
+    "regnet_resample_groups_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
     "regnet_normals_workspace_bytes": (_i64, [_i64]),
     "regnet_estimate_normals_f32": (_int, [_vp, _i64, _f64, _i64, _f64, _f64, _f64, _vp, _vp, _vp, _vp]),
     "regnet_bn_workspace_bytes": (_i64, [_i64]),

@@ -416,7 +416,8 @@ extern "C" int regnet_gather_max_f32(const float* feat, int64_t num_rows, int64_
 __global__ __launch_bounds__(256) void resample_groups_kernel(const float* __restrict__ pc, int64_t pb, int64_t pn, int C,
                                                               const int* __restrict__ cand, int64_t cap,
                                                               const int64_t* __restrict__ pos, long long total, int G,
-                                                              int64_t groups_per_scene, int64_t* __restrict__ index,
+                                                              int64_t groups_per_scene, int64_t N, int* __restrict__ bad,
+                                                              int64_t* __restrict__ index,
                                                               float* __restrict__ points) {
   const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
   if (t >= total) return;
@@ -428,22 +429,30 @@ __global__ __launch_bounds__(256) void resample_groups_kernel(const float* __res
     for (int c = 0; c < C; ++c) o[c] = -1.0f;
     return;
   }
-  const int64_t j = (int64_t)cand[grp * cap + p];
+  // (the torch.gather this kernel replaced raised on an out-of-range position; a position beyond the candidate list or
+  //  a candidate beyond the cloud -- a count / capacity mismatch upstream -- is flagged and reads nothing)
+  const int64_t j = p < cap ? (int64_t)cand[grp * cap + p] : -1;
+  if (j < 0 || j >= N) {
+    if (bad) atomicOr(bad, 1);
+    index[t] = -1;
+    for (int c = 0; c < C; ++c) o[c] = -1.0f;
+    return;
+  }
   index[t] = j;
   const float* src = pc + (grp / groups_per_scene) * pb + j * pn;
   for (int c = 0; c < C; ++c) o[c] = src[c];
 }
 
 extern "C" int regnet_resample_groups_f32(const float* pc, int64_t pb, int64_t pn, int64_t C, const int32_t* cand,
-                                          int64_t cap, const int64_t* pos, int64_t B, int64_t Nc, int64_t G,
-                                          int64_t* index, float* points, void* stream) {
+                                          int64_t cap, const int64_t* pos, int64_t B, int64_t Nc, int64_t G, int64_t N,
+                                          int32_t* out_of_range, int64_t* index, float* points, void* stream) {
   if (B < 0 || Nc < 0 || G < 0 || C <= 0 || cap < 0) return REGNET_ERR_SHAPE;
   const long long total = (long long)B * Nc * G;
   if (total >= (1ll << 40) || G >= (int64_t)1 << 31 || C > 64) return REGNET_ERR_UNSUPPORTED;
   if (total == 0) return REGNET_OK;
   if (!pc || !cand || !pos || !index || !points) return REGNET_ERR_NULL;
   hipLaunchKernelGGL(resample_groups_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), pc, pb,
-                     pn, (int)C, cand, cap, pos, total, (int)G, Nc, index, points);
+                     pn, (int)C, cand, cap, pos, total, (int)G, Nc, N, out_of_range, index, points);
   REGNET_LAUNCH_CHECK();
   return REGNET_OK;
 }

@@ -160,7 +160,10 @@ def eval_test(points, predicted_grasp, view_num, table_height, depth, width, gpu
 def estimate_normals(points, camera_pos=(0.0, 0.0, 0.0), radius=NORMAL_RADIUS, max_nn=NORMAL_MAX_NN, return_count=False):
     """PointCloud.estimate_normals (pointcloud.py:27-43): unit normals (N,3) float32 of the cloud ``points`` (N,3) on the
     GPU -- for every point the eigenvector of the smallest eigenvalue of the covariance of its ``max_nn`` nearest
-    neighbours within ``radius`` (itself included; (0,0,1) when fewer than 3), facing ``camera_pos``."""
+    neighbours within ``radius`` (itself included; (0,0,1) when fewer than 3), facing ``camera_pos``.
+    Caveat: the neighbourhood test runs on float32 coordinates (the cloud is cast before the radius test), whereas the
+    reference's open3d path keeps float64 points; a neighbour whose distance is within float32 rounding of the radius
+    can fall on the other side."""
     if not points.is_cuda:
         raise RuntimeError("estimate_normals: points must be on the GPU (no CPU fallback)")
     pts = points.float().contiguous()

@@ -330,3 +330,6 @@ class ForwardPipeline:
             worker.join()
         for s in streams:
             cur.wait_stream(s)
+        if self.with_region:
+            from . import region_ops
+            region_ops.raise_if_out_of_range()

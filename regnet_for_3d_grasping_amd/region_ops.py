@@ -83,10 +83,33 @@ def resample_groups(pc, cand, pos):
     with torch.cuda.device(pc.device):
         index = torch.empty((B, Nc, G), dtype=torch.int64, device=pc.device)
         points = torch.empty((B, Nc, G, C), dtype=torch.float32, device=pc.device)
+        flag = _range_flag(pc.device)
         _check(_L.regnet_resample_groups_f32(pc.data_ptr(), pc.stride(0), pc.stride(1), C, cand.data_ptr(), cand.size(2),
-                                             pos.data_ptr(), B, Nc, G, index.data_ptr(), points.data_ptr(), _stream(pc)),
-               "resample_groups")
+                                             pos.data_ptr(), B, Nc, G, pc.shape[1], flag.data_ptr(), index.data_ptr(),
+                                             points.data_ptr(), _stream(pc)), "resample_groups")
     return index, points
+
+
+_range_flags = {}
+
+
+def _range_flag(device):
+    """Per-device int32 the kernels OR into when a drawn position / candidate is out of range (checked lazily: reading
+    it is a synchronisation)."""
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    if key not in _range_flags:
+        _range_flags[key] = torch.zeros((1,), dtype=torch.int32, device=device)
+    return _range_flags[key]
+
+
+def raise_if_out_of_range():
+    """RuntimeError if any resample_groups launch since the last check saw a position beyond its candidate list or a
+    candidate beyond the cloud (the torch.gather it replaced raised at once).  Synchronises; called where the caller
+    synchronises anyway (end of pipeline.forward_scenes / ForwardPipeline.run)."""
+    for flag in _range_flags.values():
+        if int(flag.item()):
+            flag.zero_()
+            raise RuntimeError("resample_groups: a drawn position or candidate index was out of range")
 
 
 def box_candidates(group_points, centre, rot, xlim, ylim, zlim):
