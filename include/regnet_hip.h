@@ -438,6 +438,19 @@ int regnet_np_choice_rows_dev(uint32_t* d_mt_key, int32_t* d_mt_pos, const int32
                               int64_t size, int64_t max_count, int mode, int64_t* d_out, uint8_t* d_valid,
                               int32_t* d_workspace, void* stream);
 
+/* regnet_np_rand_doubles_dev: np.random.rand(count) from the device-resident generator (two words per double,
+ * randomkit's rk_double), d_out (count) float64 device.  Used by the device-side dataset item (scoredataset.py:52-58). */
+int regnet_np_rand_doubles_dev(uint32_t* d_mt_key, int32_t* d_mt_pos, int64_t count, double* d_out, void* stream);
+
+/* regnet_dataset_resample_f32: the gather + colour jitter + tanh of ScoreDataset.__getitem__
+ * (dataset_utils/scoredataset.py:60-81) for one record on the device: cloud / color (M,3), score / label (M) float32
+ * contiguous; pick (N) int64 rows drawn with numpy's stream; rand6 = the six np.random.rand() values of _noise_color
+ * (:52-58: table gains, then the object draws r -> gain 1 - r / 5), float64 device.  Outputs pc (N,6) = [xyz | rgb *
+ * gain], tanh(score) (N), label (N).  A pick outside [0, M) ORs 1 into *out_of_range (may be NULL).                 */
+int regnet_dataset_resample_f32(const float* cloud, const float* color, const float* score, const float* label, int64_t M,
+                                const int64_t* pick, int64_t N, const double* rand6, float* pc, float* score_out,
+                                float* label_out, int32_t* out_of_range, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -90,6 +90,8 @@ SIGNATURES = {
     "regnet_np_choice_rows": (_int, [_vp, _vp, _vp, _i64, _i64, _int, _vp, _vp]),
     "regnet_np_choice_rows_dev_workspace_ints": (_i64, [_i64, _i64]),
     "regnet_np_choice_rows_dev": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _int, _vp, _vp, _vp, _vp]),
+    "regnet_np_rand_doubles_dev": (_int, [_vp, _vp, _i64, _vp, _vp]),
+    "regnet_dataset_resample_f32": (_int, [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
 }
 
 

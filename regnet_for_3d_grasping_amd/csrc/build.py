@@ -27,6 +27,7 @@ SOURCES = [
     ("bn_train.hip", []),
     ("np_random.hip", []),
     ("np_random_dev.hip", []),
+    ("dataset.hip", ["-ffp-contract=off"]),
 ]
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
           "-fno-gpu-rdc"]

@@ -255,7 +255,44 @@ __global__ __launch_bounds__(128) void np_choice_scan_kernel(const ScanArgs p) {
 }
 
 // One wave per row; rows that are not shuffle rows leave at once.  a[] lives in LDS (lds_cap ints) or, for longer
-// candidate lists, in the row's slice of `scratch` (global memory, slow, rare).
+// candidate lists, in the row's slice of `scratch` (global memory, device-scope accesses).  The n - 1 swaps
+// (a[i], a[j_i]), i = n - 1 .. 1, are replayed 64 at a time: step q of a chunk only depends on an earlier step p of the
+// chunk if p's j is q's i or q's j (the i's are distinct and above every later index), so every lane finds its LATEST
+// such predecessor with 64 readlanes, and the chunk runs as a few rounds of mutually independent swaps -- one round
+// almost always (collisions need two of 64 draws to hit the same element of n) -- instead of 64 dependent round trips.
+template <bool IN_LDS>
+__device__ __forceinline__ void shuffle_replay(int* a, const int* __restrict__ jbuf, int joff, int n, int lane) {
+  const int steps = n - 1;
+  for (int t0 = 0; t0 < steps; t0 += 64) {
+    const int m = steps - t0 < 64 ? steps - t0 : 64;
+    const bool live = lane < m;
+    const int j = live ? jbuf[joff + t0 + lane] : -1 - lane;     // (dead lanes: distinct negatives, never equal to anything)
+    const int i = live ? n - 1 - (t0 + lane) : -100 - lane;
+    int cp = -1;                                                  // latest earlier step of the chunk this one must wait for
+    for (int q = 0; q < m; ++q) {
+      const int jq = __builtin_amdgcn_readlane(j, q);
+      if (q < lane && (jq == j || jq == i)) cp = q;
+    }
+    int s = 0;
+    while (s < m) {
+      const unsigned long long blocked = __ballot(live && lane >= s && cp >= s);
+      const int f = blocked ? __builtin_ctzll(blocked) : m;
+      if (live && lane >= s && lane < f) {
+        if (IN_LDS) { const int ai = a[i], aj = a[j]; a[j] = ai; a[i] = aj; }
+        else {
+          const int ai = __hip_atomic_load(a + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const int aj = __hip_atomic_load(a + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(a + j, ai, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(a + i, aj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      if (IN_LDS) wave_sync();
+      else __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");    // the next round may read what this one wrote
+      s = f;
+    }
+  }
+}
+
 __global__ __launch_bounds__(64) void np_shuffle_rows_kernel(const int* __restrict__ counts, const int* __restrict__ row_joff,
                                                              const int* __restrict__ jbuf, int size,
                                                              long long* __restrict__ out, int lds_cap,
@@ -266,29 +303,51 @@ __global__ __launch_bounds__(64) void np_shuffle_rows_kernel(const int* __restri
   if (joff < 0) return;
   const int n = counts[r], lane = threadIdx.x;
   int* a_glb = scratch + (long long)joff + r;   // n ints (the row's n - 1 draws start at joff; r rows before it)
-  const bool in_lds = n <= lds_cap;
-  if (in_lds) { for (int k = lane; k < n; k += 64) a_lds[k] = k; }
-  else { for (int k = lane; k < n; k += 64) a_glb[k] = k; __threadfence_block(); }
+  if (n <= lds_cap) {
+    for (int k = lane; k < n; k += 64) a_lds[k] = k;
+    wave_sync();
+    shuffle_replay<true>(a_lds, jbuf, joff, n, lane);
+    for (int k = lane; k < size; k += 64) out[r * (long long)size + k] = a_lds[k];
+  } else {
+    for (int k = lane; k < n; k += 64) __hip_atomic_store(a_glb + k, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+    shuffle_replay<false>(a_glb, jbuf, joff, n, lane);
+    for (int k = lane; k < size; k += 64)
+      out[r * (long long)size + k] = __hip_atomic_load(a_glb + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// np.random.rand / random_sample: count doubles, two words each -- (a >> 5, b >> 6) -> (a 2^26 + b) / 2^53 (randomkit's rk_double).
+__global__ __launch_bounds__(64) void np_rand_doubles_kernel(unsigned* __restrict__ key, int* __restrict__ pos_ptr, int count,
+                                                             double* __restrict__ out) {
+  __shared__ unsigned raw[2][MT_PAD];
+  __shared__ unsigned tmp[2][MT_PAD];
+  const int lane = threadIdx.x;
+  for (int i = lane; i < MT_PAD; i += 64) {
+    const unsigned k = i < MT_N ? key[i] : 0u;
+    raw[0][i] = k; raw[1][i] = 0u; tmp[0][i] = mt_temper(k); tmp[1][i] = 0u;
+  }
   wave_sync();
-  const int steps = n - 1;
-  for (int t0 = 0; t0 < steps; t0 += 64) {
-    const int jl = (t0 + lane < steps) ? jbuf[joff + t0 + lane] : 0;
-    const int m = steps - t0 < 64 ? steps - t0 : 64;
-    for (int q = 0; q < m; ++q) {
-      const int j = __builtin_amdgcn_readlane(jl, q);
-      const int i = n - 1 - (t0 + q);
-      if (lane == 0) {
-        if (in_lds) { const int ai = a_lds[i], aj = a_lds[j]; a_lds[j] = ai; a_lds[i] = aj; }
-        else {
-          volatile int* g = a_glb;
-          const int ai = g[i], aj = g[j]; g[j] = ai; g[i] = aj;
-        }
-      }
+  int cur = 0, pos = __builtin_amdgcn_readfirstlane(*pos_ptr);
+  unsigned have = 0;
+  bool half = false;
+  for (int k = 0; k < 2 * count; ++k) {
+    if (pos >= MT_N) {
+      mt_next_block(raw[cur], raw[cur ^ 1], tmp[cur ^ 1], lane);
+      wave_sync();
+      cur ^= 1;
+      pos = 0;
+    }
+    const unsigned w = tmp[cur][pos++];
+    if (!half) { have = w >> 5; half = true; }
+    else {
+      if (lane == 0) out[k >> 1] = ((double)have * 67108864.0 + (double)(w >> 6)) / 9007199254740992.0;
+      half = false;
     }
   }
   wave_sync();
-  if (!in_lds) __threadfence_block();
-  for (int k = lane; k < size; k += 64) out[r * (long long)size + k] = in_lds ? a_lds[k] : ((volatile int*)a_glb)[k];
+  for (int i = lane; i < MT_N; i += 64) key[i] = raw[cur][i];
+  if (lane == 0) *pos_ptr = pos;
 }
 
 }  // namespace
@@ -317,9 +376,18 @@ extern "C" int regnet_np_choice_rows_dev(uint32_t* d_mt_key, int32_t* d_mt_pos, 
   if (hipMemsetAsync(a.status, 0, sizeof(int), s) != hipSuccess) return (int)hipGetLastError();
   hipLaunchKernelGGL(np_choice_scan_kernel, dim3(1), dim3(128), 0, s, a);
   REGNET_LAUNCH_CHECK();
-  const int lds_cap = 12288;   // 48 KiB: three shuffle rows per CU side by side
+  const int lds_cap = 12288;   // 48 KiB: three shuffle rows per CU side by side (longer lists replay in global memory)
   hipLaunchKernelGGL(np_shuffle_rows_kernel, dim3((unsigned)rows), dim3(64), lds_cap * sizeof(int), s, d_counts,
                      a.row_joff, a.jbuf, (int)size, (long long*)d_out, lds_cap, scratch);
+  REGNET_LAUNCH_CHECK();
+  return REGNET_OK;
+}
+
+extern "C" int regnet_np_rand_doubles_dev(uint32_t* d_mt_key, int32_t* d_mt_pos, int64_t count, double* d_out, void* stream) {
+  if (count < 0 || count >= (1ll << 30)) return REGNET_ERR_SHAPE;
+  if (count == 0) return REGNET_OK;
+  if (!d_mt_key || !d_mt_pos || !d_out) return REGNET_ERR_NULL;
+  hipLaunchKernelGGL(np_rand_doubles_kernel, dim3(1), dim3(64), 0, as_stream(stream), d_mt_key, d_mt_pos, (int)count, d_out);
   REGNET_LAUNCH_CHECK();
   return REGNET_OK;
 }

@@ -143,6 +143,20 @@ def choice_rows_device(counts, size, mode, max_count):
     return out.view(tuple(counts.shape) + (int(size),)), valid.bool().view(counts.shape)
 
 
+def rand_device(count, device):
+    """``np.random.rand(count)`` drawn from the device-resident generator -> float64 GPU tensor (no synchronisation)."""
+    import torch
+    st = _stream_for(device)
+    with torch.cuda.device(st.device):
+        out = torch.empty((int(count),), dtype=torch.float64, device=st.device)
+        if count:
+            cur = st.acquire()
+            _check(_L.regnet_np_rand_doubles_dev(st.key.data_ptr(), st.pos.data_ptr(), int(count), out.data_ptr(),
+                                                 cur.cuda_stream), "np_rand_doubles_dev")
+            st.release(cur)
+    return out
+
+
 def flush(device=None):
     """Give ``np.random`` the state the device draws left behind (no-op when the host state is current)."""
     for st in list(_streams.values()):

@@ -68,6 +68,45 @@ class ScoreDataset(torch.utils.data.Dataset):
         color = self._noise_color(color, label)
         return np.c_[cloud, color], np.tanh(score), label, data_path, self.width
 
+    def gpu_item(self, index, device):
+        """``__getitem__`` with everything after the file read on the GPU: the record's arrays go up once, the resampling
+        positions and the six colour gains are drawn from numpy's stream BY THE DEVICE (np_random.choice_rows_device /
+        rand_device: same values and same stream consumption as the host's np.random.choice + 2 x rand(3)), and one kernel
+        gathers, jitters and squashes (csrc/dataset.hip).  Returns GPU tensors (view (N,6), tanh(score) (N,), label (N,))
+        + the record path and width; call ``np_random.flush()`` (or leave a ``np_random.deferred()`` block) before using
+        ``np.random`` on the host again."""
+        import torch
+        from . import _lib, np_random, region_ops
+        data_path = os.path.join(self.base_path, self.data_name[index])
+        data = np.load(data_path, allow_pickle=True)
+        dev = torch.device(device)
+        up = lambda key: torch.from_numpy(np.ascontiguousarray(data[key], dtype=np.float32)).to(dev, non_blocking=True)
+        cloud, color, score, label = up("view_cloud"), up("view_cloud_color"), up("view_cloud_score"), up("view_cloud_label")
+        M, N = cloud.shape[0], self.all_points_num
+        counts = torch.full((1,), M, dtype=torch.int32, device=dev)
+        # mode 0 = "without replacement when the list has at least `size` entries, else with" = scoredataset.py:68-72
+        pick = np_random.choice_rows_device(counts, N, 0, M)[0].view(N)
+        rand6 = np_random.rand_device(6, dev)
+        with torch.cuda.device(dev):
+            pc = torch.empty((N, 6), dtype=torch.float32, device=dev)
+            score_out = torch.empty((N,), dtype=torch.float32, device=dev)
+            label_out = torch.empty((N,), dtype=torch.float32, device=dev)
+            _lib.check(_lib.lib.regnet_dataset_resample_f32(
+                cloud.data_ptr(), color.data_ptr(), score.data_ptr(), label.data_ptr(), M, pick.data_ptr(), N,
+                rand6.data_ptr(), pc.data_ptr(), score_out.data_ptr(), label_out.data_ptr(),
+                region_ops._range_flag(dev).data_ptr(), torch.cuda.current_stream(dev).cuda_stream), "dataset_resample")
+        return pc, score_out, label_out, data_path, self.width
+
+    def gpu_batch(self, indices, device):
+        """A batch of ``gpu_item``s stacked on the device: (pc (B,N,6), score (B,N), label (B,N), paths, widths) -- the
+        collated batch of the reference's 8-worker DataLoader (utils.py:31-57) without the host-side resampling."""
+        import torch
+        from . import np_random
+        with np_random.deferred():
+            items = [self.gpu_item(i, device) for i in indices]
+        return (torch.stack([it[0] for it in items]), torch.stack([it[1] for it in items]),
+                torch.stack([it[2] for it in items]), [it[3] for it in items], np.stack([it[4] for it in items]))
+
     def __len__(self):
         return len(self.data_name)
 

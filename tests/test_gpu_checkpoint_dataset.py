@@ -125,3 +125,35 @@ def test_dataset_batches_through_the_pipeline(tmp_path):
         assert _rel_err(g["all_feature"], w["all_feature"]) <= 1e-4
         for key in ("center_pc_index", "pc_group_index", "pc_group_more_index"):
             assert torch.equal(g[key].cpu(), w[key]), key
+
+
+def test_dataset_item_on_the_gpu_equals_the_host_item(tmp_path):
+    """ScoreDataset.gpu_item / gpu_batch (csrc/dataset.hip + the device-side numpy stream) against __getitem__
+    (scoredataset.py:60-81) under the same seed: same picked rows (with AND without replacement, incl. a 30 000-point
+    record whose shuffle is replayed in global memory), same colour gains (float64 products rounded to float32), tanh
+    to 1e-6, same numpy stream position afterwards."""
+    from regnet_for_3d_grasping_amd import np_random, region_ops, scoredataset, synthetic
+    roots = golden_util.dataset_records(str(tmp_path))
+    big = synthetic.make_scene(123, 30000)
+    rng = np.random.default_rng(5)
+    label = (big[:, 2] > 0.7525).astype(np.float32) * rng.integers(1, 9, 30000)
+    scoredataset.write_record(os.path.join(roots["training"], "training_data", "zz_big_scene.p"), big,
+                              rng.uniform(0, 1.5, 30000) * (label > 0), label, synthetic.make_grasp_labels(big, 1))
+    for N in (256, 1024, 25600):        # 256: some records have more points (no replacement); 1024 / 25600: all fewer, except the big one
+        ds = scoredataset.ScoreDataset(N, roots["training"], "train", 1, [0.06, 0.08])
+        names = list(ds.data_name)
+        items = [0, 5, 11] + ([names.index("zz_big_scene.p")] if "zz_big_scene.p" in names else [])
+        np.random.seed(77)
+        want = [ds[i] for i in items]
+        after = int(np.random.randint(0, 2 ** 31 - 1))
+        np.random.seed(77)
+        pc, score, label_g, paths, widths = ds.gpu_batch(items, DEV)
+        torch.cuda.synchronize()
+        assert int(np.random.randint(0, 2 ** 31 - 1)) == after, "numpy stream position, N=%d" % N
+        region_ops.raise_if_out_of_range()
+        assert pc.shape == (len(items), N, 6) and widths.shape == (len(items), 2)
+        for k, w in enumerate(want):
+            np.testing.assert_array_equal(pc[k].cpu().numpy(), w[0].astype(np.float32))
+            np.testing.assert_allclose(score[k].cpu().numpy(), w[1], rtol=0, atol=1e-6)
+            np.testing.assert_array_equal(label_g[k].cpu().numpy(), w[2])
+            assert paths[k] == w[3]
