@@ -69,6 +69,7 @@ def parse():
                     help="steps of the extra pass AFTER the timed region with one sampling launch per batch and no enlarged "
                          "first launch (value_no_lookahead); 0 = skip")
     ap.add_argument("--lookahead", type=int, default=3, help="batches whose region stage may be pending (pipeline depth)")
+    ap.add_argument("--geometry-ahead", type=int, default=1, help="batches whose ball-query / 3-NN geometry is queued ahead of the feature stage")
     ap.add_argument("--set", action="append", default=[], metavar="module.NAME=0|1",
                     help="A/B measurement only: flip a module-level switch of the package before the run, e.g. "
                          "--set fused.FP_HEAD_INTERP=0 (reported in config.switches)")
@@ -456,7 +457,7 @@ def main():
     # steps happens inside the timed region; the pipeline drains before the closing fence).
     pipe = pipeline.ForwardPipeline(score_net, region_net, with_region=not args.score_only, fps_streams=args.fps_streams,
                                     mlp_streams=args.mlp_streams, fps_group=args.fps_group,
-                                    first_launch_groups=args.first_launch_groups)
+                                    first_launch_groups=args.first_launch_groups, geometry_ahead=args.geometry_ahead)
 
     def run_steps(n):
         last = None

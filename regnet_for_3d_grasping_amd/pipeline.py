@@ -82,7 +82,7 @@ class ForwardPipeline:
     """
 
     def __init__(self, score_net, region_net, with_region=True, fps_streams=2, mlp_streams=1, fps_group=0,
-                 first_launch_groups=1):
+                 first_launch_groups=1, geometry_ahead=1):
         """``fps_streams``: level-1 sampling launches in flight (each ~10 ms on one CU per scene, whatever the batch
         size).  ``fps_group``: consecutive batches whose level-1 sampling shares one launch (0: as many as give 64 scenes,
         at most 8): +6 % at 8 scenes per batch, +12-15 % at 1 and 4, at the price of reading that many batches ahead.
@@ -100,6 +100,7 @@ class ForwardPipeline:
         self.score_net, self.region_net, self.with_region = score_net, region_net, with_region
         self.fps_group = int(fps_group)   # batches whose level-1 sampling shares one launch; 0 = as many as give 64 scenes (<= 8)
         self.first_launch_groups = max(1, int(first_launch_groups))
+        self.geometry_ahead = max(1, int(geometry_ahead))   # batches whose ball-query / 3-NN geometry runs ahead of the features
         self.first_launch_batches = None  # what the first sampling launch of the last ``run`` really took (bench.py reports it)
         self._one_sampling_stream = False
         dev = next(score_net.parameters()).device
@@ -261,11 +262,12 @@ class ForwardPipeline:
         try:
             import collections
             sampled = collections.deque()   # batches whose level-1 FPS is enqueued
-            st_geo = None                   # batch whose remaining geometry is enqueued
+            geo_q = collections.deque()     # batches whose remaining geometry is enqueued, oldest first
             it = iter(batches)
             exhausted = False
             group = self.fps_group
             first_launch, first_want = True, 0
+            first_features = True
             self.first_launch_batches = None
             while True:
                 # keep the sampling ahead: a new group launch when at most one group's worth of sampled batches is left (a
@@ -304,14 +306,19 @@ class ForwardPipeline:
                             self.first_launch_batches = len(pcs)
                         sampled.extend(self._sample_group(pcs))
                         first_launch = False
-                if not sampled and st_geo is None:
+                if not sampled and not geo_q:
                     break
-                # enqueue the asynchronous stages, deepest look-ahead first
-                new_geo = self._geometry(sampled.popleft()) if sampled else None
-                if st_geo is not None:
-                    todo.put(self._features(st_geo))
+                # enqueue the asynchronous stages, deepest look-ahead first.  ``geometry_ahead`` batches stay queued BEHIND
+                # the one whose features are enqueued now (1 = one batch of geometry in flight beside the feature stage;
+                # 2-3 measured the same step time: the feature stream never waits for geometry, scripts/mlp_idle_probe.py)
+                while sampled and len(geo_q) < self.geometry_ahead + 1:
+                    geo_q.append(self._geometry(sampled.popleft()))
+                    if first_features:
+                        break            # start of a run: the first batch's features should not queue behind a second geometry
+                if geo_q and (first_features or len(geo_q) > self.geometry_ahead or not sampled):
+                    todo.put(self._features(geo_q.popleft()))
                     pending += 1
-                st_geo = new_geo
+                    first_features = False
                 while pending > max_pending_regions:      # back-pressure: wait for the oldest region stage
                     yield collect(True)
                     pending -= 1
