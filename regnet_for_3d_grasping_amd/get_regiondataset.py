@@ -80,8 +80,17 @@ def _get_center_grasp(center_pc_index, center_pc, data_paths, depth, use_theta=T
     score_l = torch.full((B, Nc), -1.0, device=dev)
     anti_l = torch.full((B, Nc), -1.0, device=dev)
     cen_l = torch.full((B, Nc), -1.0, device=dev)
-    for i, entry in enumerate(data_paths):
-        frames, score, anti, cen = (t.to(dev) for t in _load_grasp_record(entry))
+    # every scene's label arrays go up in ONE host->device copy (four pageable copies per scene, each a
+    # synchronisation, before)
+    loaded = [_load_grasp_record(entry) for entry in data_paths]
+    flat = torch.cat([t.reshape(-1) for rec in loaded for t in rec]).to(dev)
+    at = 0
+    for i, rec in enumerate(loaded):
+        parts = []
+        for t in rec:
+            parts.append(flat[at:at + t.numel()].view(t.shape))
+            at += t.numel()
+        frames, score, anti, cen = parts
         approach = frames[:, :3, 0]
         # the reference shifts the grasp centre along the approach by `depth` and back again (:91-92)
         contact = ((frames[:, :3, 3] + approach * depth).float() - approach * depth).float()

@@ -105,17 +105,14 @@ class GripperRegionNetwork(nn.Module):
         sim = torch.stack([compute_cos_sim(anchors[:, a, 3:6], gt7[:, 3:6]).view(-1) for a in range(A)], dim=1)
         ground_8 = torch.sort(sim, dim=1, descending=False)[1][:, 0]
 
-        # class-balanced subset: the same number of centres per (non-empty) anchor class
-        counts = [int((ground_8 == a).sum()) for a in range(A)]
-        per_class = max(int(min(counts)), 1)
-        chosen = []
+        # class-balanced subset: the same number of centres per (non-empty) anchor class.  ONE device->host read (the
+        # <= B*64 class ids) instead of a count + a nonzero per class; the draws stay on numpy's global stream, in class order
+        classes = ground_8.cpu().numpy()
+        members = [np.nonzero(classes == a)[0] for a in range(A)]
+        per_class = max(int(min(len(mem) for mem in members)), 1)
         np_random.flush()    # host-side draws below: numpy's generator must hold the state the device draws left
-        for a in range(A):
-            members = torch.nonzero(ground_8 == a).view(-1)
-            if len(members) == 0:
-                continue
-            chosen.append(members[np.random.choice(len(members), per_class, replace=False)])
-        balanced = torch.cat(chosen).long()
+        chosen = [mem[np.random.choice(len(mem), per_class, replace=False)] for mem in members if len(mem)]
+        balanced = torch.from_numpy(np.concatenate(chosen).astype(np.int64)).to(dev)
         loss_class = self.criterion_cls(first_cls[balanced], ground_8[balanced].long())
         correct_tuple = ((ground_8 == pick).sum().float(), (ground_8 != pick).sum().float())
 
@@ -147,31 +144,39 @@ class GripperRegionNetwork(nn.Module):
         final_grasp[:, :3] = final_grasp[:, :3] + next_x_reg[:, :3] * self.radius
         final_grasp[:, 3:] = final_grasp[:, 3:] + next_x_reg[:, 3:]
         predicted = torch.max(next_x_cls, dim=-1)[1]
-        class_select = torch.nonzero(predicted == 1).view(-1)
-        score_select = torch.nonzero((predicted == 1) & (final_grasp[:, 7] > self.grasp_score_thre)).view(-1)
+        is_class = predicted == 1
+        is_score = is_class & (final_grasp[:, 7] > self.grasp_score_thre)
+        if next_gt is None:
+            flags = torch.stack((is_class, is_score)).cpu().numpy()                      # one read for both selections
+        else:
+            offset = next_grasp[:, :3] - next_gt[:, :3]
+            near = torch.sqrt(offset[:, 0] * offset[:, 0] + offset[:, 1] * offset[:, 1] + offset[:, 2] * offset[:, 2]) < 0.025
+            aligned = compute_cos_sim(next_grasp[:, 3:6], next_gt[:, 3:6]).view(-1) < 0.5
+            same_angle = torch.abs(next_grasp[:, 6] - next_gt[:, 6]) < 1.047
+            gt_positive = near & aligned & same_angle
+            flags = torch.stack((is_class, is_score, gt_positive)).cpu().numpy()         # ... and the label classes
+        class_select = torch.from_numpy(np.nonzero(flags[0])[0]).to(dev)
+        score_select = torch.from_numpy(np.nonzero(flags[1])[0]).to(dev)
         sel_class, sel_score = final_grasp[class_select].data, final_grasp[score_select].data
         sel_class_stage2 = next_grasp[class_select].data
         if next_gt is None:
             return (sel_class, sel_score, sel_class_stage2, class_select, score_select, (None, None),
                     (None, None, None, None))
 
-        offset = next_grasp[:, :3] - next_gt[:, :3]
-        near = torch.sqrt(offset[:, 0] * offset[:, 0] + offset[:, 1] * offset[:, 1] + offset[:, 2] * offset[:, 2]) < 0.025
-        aligned = compute_cos_sim(next_grasp[:, 3:6], next_gt[:, 3:6]).view(-1) < 0.5
-        same_angle = torch.abs(next_grasp[:, 6] - next_gt[:, 6]) < 1.047
-        gt_class = (near & aligned & same_angle).float()
-        pos = torch.nonzero(gt_class == 1).view(-1)
-        neg = torch.nonzero(gt_class == 0).view(-1)
-        num = min(len(neg), len(pos))
+        gt_class = gt_positive.float()
+        pos_np, neg_np = np.nonzero(flags[2])[0], np.nonzero(~flags[2])[0]
+        pos = torch.from_numpy(pos_np).to(dev)
+        neg = torch.from_numpy(neg_np).to(dev)
+        num = min(len(neg_np), len(pos_np))
 
-        zero = torch.tensor(0.0, device=dev)
+        zero = torch.zeros((), device=dev)
         loss = loss_class = l_center = l_axis = l_theta = l_score = zero
         sl1 = nn.functional.smooth_l1_loss
         if num > 0:
             np_random.flush()
-            idx0 = neg[np.random.choice(len(neg), num, replace=False)].view(-1)
-            idx1 = pos[np.random.choice(len(pos), num, replace=False)].view(-1)
-            index = torch.cat((idx0, idx1), dim=-1)
+            idx0 = neg_np[np.random.choice(len(neg_np), num, replace=False)]
+            idx1 = pos_np[np.random.choice(len(pos_np), num, replace=False)]
+            index = torch.from_numpy(np.concatenate((idx0, idx1)).astype(np.int64)).to(dev)
             loss_class = self.criterion_cls(next_x_cls.view(-1, 2)[index], gt_class.view(-1)[index].long())
             l_center = sl1(next_x_reg[pos, :3], (next_gt[pos, :3] - next_grasp[pos, :3]) / self.radius, reduction="mean")
             l_axis = sl1(next_x_reg[pos, 3:6], next_gt[pos, 3:6] - next_grasp[pos, 3:6], reduction="mean")
@@ -269,8 +274,9 @@ def _unit(v, fallback, eps):
     if eps:
         norm = norm + eps
     out = torch.div(v, norm.view(-1, 1))
-    fb = torch.tensor(fallback, dtype=torch.float32, device=v.device)
-    return torch.where(torch.eq(norm, 0).view(-1, 1), fb.view(1, 3).expand_as(out), out)
+    fb = out.new_zeros((1, 3))
+    fb[0, fallback.index(1.0)] = 1.0      # the fallbacks are unit axes: built on the device (no host->device copy)
+    return torch.where(torch.eq(norm, 0).view(-1, 1), fb.expand_as(out), out)
 
 
 def gripper_frame(grasp):
