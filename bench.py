@@ -427,13 +427,6 @@ def main():
         # of the cores, so that N ranks' region-stage host threads do not fight over them
         torch.set_num_threads(max(1, (os.cpu_count() or world) // (2 * world)))
         sharding.init("nccl", dev)   # RCCL; used only for the barrier + max-over-ranks of the contract
-    if args.train:
-        run_train(args, rank, world, dev)
-        if world > 1:
-            torch.distributed.destroy_process_group()
-        return
-
-    from regnet_for_3d_grasping_amd import pipeline, synthetic
     import importlib
     for item in args.set:
         target, value = item.split("=")
@@ -441,6 +434,13 @@ def main():
         module = importlib.import_module("regnet_for_3d_grasping_amd." + mod)
         assert isinstance(getattr(module, name), bool), target
         setattr(module, name, value not in ("0", "false", "False"))
+    if args.train:
+        run_train(args, rank, world, dev)
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
+
+    from regnet_for_3d_grasping_amd import pipeline, synthetic
     timer = OpTimer(args.time_every)
     install_timers(timer)
 

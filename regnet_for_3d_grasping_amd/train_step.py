@@ -57,6 +57,15 @@ def allreduce_gradients(parameters, reduce="sum"):
     return n_grad
 
 
+# RefineTrainer: back-propagate the ScoreNet loss through the segmentation head RIGHT AFTER the ScoreNet forward, before the
+# region stage.  The region stage (centre selection, grouping draws, label matching, class-balanced losses) is ~8-10 ms
+# of host-paced work during which the GPU has nothing to do, and the head's backward (four 204 800-row layers: ~5 ms of
+# GEMMs and BatchNorm passes at 8 scenes) depends on the score loss only; its gradient with respect to the 256-channel
+# point feature is kept and joins the region losses' gradient at that tensor, so the trunk is still traversed once.
+# Same gradients as one ``total.backward()`` up to the order of one fp32 addition (tests/test_gpu_train.py).
+EARLY_HEAD_BACKWARD = True
+
+
 def _distributed():
     import torch.distributed as dist
     return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
@@ -97,6 +106,13 @@ class GradientBucket:
         self._comm_stream = None
         self._events = None
         self._host_flags = None
+
+    def mark_touched(self, params):
+        """Gradients written into ``p.grad`` by hand (``torch.autograd.grad`` results) do not fire the accumulate hooks."""
+        ids = {id(p) for p in params}
+        for i, p in enumerate(self.params):
+            if id(p) in ids:
+                self.touched[i] = True
 
     def prepare(self):
         """Replaces ``optimizer.zero_grad()``: one fill, every ``.grad`` a view of the bucket."""
@@ -274,6 +290,7 @@ class RefineTrainer:
         self.sched_score = torch.optim.lr_scheduler.StepLR(self.opt_score, step_size=5, gamma=0.5)
         self.sched_region = torch.optim.lr_scheduler.StepLR(self.opt_region, step_size=5, gamma=0.5)
         self.geometry = GeometryPrefetcher(score_net)
+        self._region_stream = None
         # both networks' gradients in ONE flat buffer: one all-reduce per training iteration (28.3 MB for the reference's
         # 5 542 531 + 1 524 396 parameters)
         self.bucket = GradientBucket([score_net, region_net], reduce) if _distributed() else None
@@ -282,29 +299,64 @@ class RefineTrainer:
         """Start the geometry of a FUTURE batch on a side stream; pass the result to ``step(..., plan=...)``."""
         return self.geometry.prefetch(pc)
 
-    def forward_losses(self, pc, pc_score, grasp_records, plan=None):
-        """-> (loss_total, parts) with parts = dict(score=..., stage2=... or None, refine=... or None)."""
+    def forward_losses(self, pc, pc_score, grasp_records, plan=None, early_head_backward=False):
+        """-> (loss_total, parts) with parts = dict(score=..., stage2=... or None, refine=... or None).
+        ``early_head_backward`` (used by ``step``): the score loss is back-propagated through the segmentation head
+        right after the ScoreNet forward (see EARLY_HEAD_BACKWARD); ``parts['early']`` then carries what ``step`` needs
+        to finish the backward pass, and the returned total has the same VALUE but only the region losses' graph."""
         import contextlib
         import io
 
         from .get_regiondataset import get_grasp_allobj
-        all_feature, output_score, loss = self.score_net(pc, pc_score, None,
-                                                         plan=GeometryPrefetcher.acquire(plan, pc.device))
+        grabbed = {}
+        hook = None
+        if early_head_backward and torch.is_grad_enabled():
+            # the tensor the segmentation head consumes = PointNet2Seg's first output (held by this call only)
+            hook = self.score_net.extrat_featurePN2.register_forward_hook(
+                lambda _m, _i, out: grabbed.__setitem__("feat", out[0]))
+        try:
+            all_feature, output_score, loss = self.score_net(pc, pc_score, None,
+                                                             plan=GeometryPrefetcher.acquire(plan, pc.device))
+        finally:
+            if hook is not None:
+                hook.remove()
         parts = {"score": loss, "stage2": None, "refine": None}
         total = loss.sum()
-        try:
-            with contextlib.redirect_stdout(io.StringIO()):
-                g = get_grasp_allobj(pc, output_score, self.params, grasp_records)
-                res = self.region_net(g[3], g[5], g[2], g[4], g[0], g[1], pc, all_feature, self.gripper_params, g[6],
-                                      grasp_records)
-            loss_tuple, loss_refine_tuple = res[3], res[13]
-            total = total + loss_tuple[0].sum()
-            parts["stage2"] = loss_tuple[0]
-            if len(loss_refine_tuple) > 2:
-                total = total + loss_refine_tuple[0].sum()
-                parts["refine"] = loss_refine_tuple[0]
-        except (RuntimeError, IndexError, ValueError) as exc:   # the reference uses a bare except (train.py:430)
-            parts["region_error"] = repr(exc)
+        feat = grabbed.get("feat")
+        region_stream = contextlib.nullcontext()
+        if feat is not None and feat.requires_grad and total.requires_grad:
+            seg = self.score_net.extrat_featurePN2
+            head = [p for m in (seg.mlp, seg.conv_score, seg.bn_score) for p in m.parameters() if p.requires_grad]
+            forward_done = None
+            if feat.is_cuda:
+                forward_done = torch.cuda.Event()
+                forward_done.record()
+            grads = torch.autograd.grad(total, [feat] + head, retain_graph=True, allow_unused=True)
+            parts["early"] = (feat, grads[0], head, grads[1:], total)
+            total = total.detach()       # its gradient is already out; what is added below is the region stage's share
+            if forward_done is not None:
+                # the region stage on its OWN stream, behind the forward only: its device->host reads would otherwise wait
+                # for the head's backward just enqueued on this stream (autograd runs a node's backward on the stream of its
+                # forward and orders streams itself; ``step`` joins the streams before the optimizer)
+                if self._region_stream is None:
+                    self._region_stream = torch.cuda.Stream(feat.device)
+                self._region_stream.wait_event(forward_done)
+                region_stream = torch.cuda.stream(self._region_stream)
+                parts["region_stream"] = self._region_stream
+        with region_stream:
+            try:
+                with contextlib.redirect_stdout(io.StringIO()):
+                    g = get_grasp_allobj(pc, output_score, self.params, grasp_records)
+                    res = self.region_net(g[3], g[5], g[2], g[4], g[0], g[1], pc, all_feature, self.gripper_params, g[6],
+                                          grasp_records)
+                loss_tuple, loss_refine_tuple = res[3], res[13]
+                total = total + loss_tuple[0].sum()
+                parts["stage2"] = loss_tuple[0]
+                if len(loss_refine_tuple) > 2:
+                    total = total + loss_refine_tuple[0].sum()
+                    parts["refine"] = loss_refine_tuple[0]
+            except (RuntimeError, IndexError, ValueError) as exc:   # the reference uses a bare except (train.py:430)
+                parts["region_error"] = repr(exc)
         return total, parts
 
     def step(self, pc, pc_score, grasp_records, plan=None):
@@ -316,8 +368,28 @@ class RefineTrainer:
         else:
             self.bucket.prepare()
         with torch.enable_grad():
-            total, parts = self.forward_losses(pc, pc_score, grasp_records, plan)
-            total.backward()
+            total, parts = self.forward_losses(pc, pc_score, grasp_records, plan, early_head_backward=EARLY_HEAD_BACKWARD)
+            early = parts.pop("early", None)
+            side = parts.pop("region_stream", None)
+            if side is not None:
+                torch.cuda.current_stream(pc.device).wait_stream(side)   # (device-side: the region stage's losses are roots below)
+            if early is None:
+                total.backward()
+            else:
+                feat, g_feat, head, g_head, _ = early
+                for p, g in zip(head, g_head):
+                    if g is not None:
+                        if p.grad is None:
+                            p.grad = g
+                        else:
+                            p.grad.add_(g)
+                if self.bucket is not None:
+                    self.bucket.mark_touched([p for p, g in zip(head, g_head) if g is not None])
+                roots, seeds = [feat], [g_feat]
+                if total.requires_grad:          # the region stage contributed losses
+                    roots.append(total)
+                    seeds.append(None)
+                torch.autograd.backward(roots, seeds)
         if self.bucket is not None:
             self.bucket.reduce_gradients()
         self.opt_score.step()

@@ -352,3 +352,45 @@ def test_training_step_51200_point_scene():
     gpu.load_state_dict(ref.state_dict())      # undo the running-statistics update of the probe forward
     out = trainer.step(pc.to(DEV), target.to(DEV))
     assert torch.isfinite(out) and abs(float(out) - float(loss_ref)) < 1e-5
+
+
+def test_early_head_backward_gives_the_same_gradients():
+    """RefineTrainer.step with the score loss back-propagated through the segmentation head before the region stage
+    (train_step.EARLY_HEAD_BACKWARD) against one ``total.backward()``: every parameter gradient of both networks agrees
+    (the only difference is the order of one fp32 addition at the 256-channel point feature)."""
+    from regnet_for_3d_grasping_amd import pipeline, synthetic, train_step
+    from regnet_for_3d_grasping_amd.gripper_region_network import GripperRegionNetwork
+    from regnet_for_3d_grasping_amd.score_network import ScoreNetwork
+    B, N = 2, 6144
+    pc = synthetic.make_batch(8100, B, N).to(DEV)
+    records = [synthetic.make_grasp_labels(pc[b].cpu().numpy(), 50 + b) for b in range(B)]
+    target = torch.from_numpy(np.random.default_rng(2).uniform(0, 1, (B, N)).astype(np.float32)).to(DEV)
+    grads = []
+    for early in (True, False):
+        s = ScoreNetwork(training=True)
+        s.load_state_dict(synthetic.seeded_state_dict(s, 3))
+        r = GripperRegionNetwork(training=True, group_num=256, gripper_num=64, grasp_score_threshold=0.5, radius=0.06,
+                                 reg_channel=10)
+        r.load_state_dict(synthetic.seeded_state_dict(r, 4))
+        s.extrat_featurePN2.mlp.dropout_prob = 0.0
+        t = train_step.RefineTrainer(s.to(DEV), r.to(DEV), pipeline.PARAMS, pipeline.GRIPPER_PARAMS, lr=0.0)
+        old = train_step.EARLY_HEAD_BACKWARD
+        train_step.EARLY_HEAD_BACKWARD = early
+        try:
+            np.random.seed(31)
+            total, parts = t.step(pc, target, records)
+        finally:
+            train_step.EARLY_HEAD_BACKWARD = old
+        assert "region_error" not in parts and parts["stage2"] is not None
+        named = list(s.named_parameters()) + [("region." + k, p) for k, p in r.named_parameters()]
+        grads.append((float(total), {k: (None if p.grad is None else p.grad.detach().clone()) for k, p in named}))
+    (t0, g0), (t1, g1) = grads
+    assert abs(t0 - t1) <= 1e-6 * abs(t1)
+    assert set(g0) == set(g1)
+    for k in g0:
+        assert (g0[k] is None) == (g1[k] is None), k
+        if g0[k] is not None:
+            # relative to the tensor's size, plus an absolute floor: gradients in front of a train-mode BatchNorm are
+            # differences of large sums (DESIGN.md par. 9) -- a bias whose true gradient is ~0 carries 1e-7-level noise
+            scale = float(g1[k].abs().max())
+            assert float((g0[k] - g1[k]).abs().max()) <= 1e-4 * scale + 1e-6, (k, float((g0[k] - g1[k]).abs().max()), scale)
