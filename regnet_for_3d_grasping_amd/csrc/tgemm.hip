@@ -27,6 +27,10 @@ typedef float tg_f32x16 __attribute__((ext_vector_type(16)));
 #define TG_BK 16
 #define TG_STAGES 3
 #define TG_THREADS 512
+#ifndef TG_WGRAD_BLOCKS
+#define TG_WGRAD_BLOCKS 256    // weight gradient: (slice x tile x scene) workgroups to aim for -- one per CU: every slice costs a partial matrix and a
+                               // shorter K loop; measured over a training iteration (8 x 25 600): 1024 -> 29.7 ms of tgemm, 512 -> 28.6, 256 -> 27.4, 128 -> 33.3
+#endif
 
 struct TgArgs {
   const float* A; long long lda, a_batch, a_slice;   // per block: A + batch * a_batch + slice * a_slice
@@ -265,7 +269,7 @@ extern "C" int regnet_conv1x1_dgrad_f32(const float* W, const float* dY, float* 
 extern "C" int64_t regnet_conv1x1_wgrad_slices(int64_t B, int64_t Co, int64_t Ci, int64_t L) {
   const int64_t tiles = ((Co + TG_BM - 1) / TG_BM) * ((Ci + 255) / 256);
   int64_t s = 1;
-  while (L % (2 * s) == 0 && (L / (2 * s)) % 16 == 0 && L / (2 * s) >= 256 && s * tiles * B < 1024) s *= 2;
+  while (L % (2 * s) == 0 && (L / (2 * s)) % 16 == 0 && L / (2 * s) >= 256 && s * tiles * B < TG_WGRAD_BLOCKS) s *= 2;
   return s;
 }
 
