@@ -1,0 +1,90 @@
+"""float64 evaluation of the S8 ScoreNet (tests/golden/make_golden_b8.py's network, 8 x 25 600 points): the same graph
+with the fp32 kernels' index tensors (furthest point sampling, ball query, 3-NN: integer outputs, identical on every
+implementation) and fp32 3-NN squared distances, but every floating-point operation of the shared MLPs, the
+interpolation and the head in double precision.  It is NOT a parity oracle (the reference computes in fp32) -- it is the
+yardstick that says how much of |HIP - reference| is each side's own fp32 rounding:
+
+    python tests/golden/make_fp64_truth.py      # CPU only; writes tests/golden/s8_score_fp64.npz, prints |reference - fp64|
+"""
+import copy
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "tests"))
+
+
+def main():
+    import golden_util as gu
+    from oracle.install import oracle_backend
+    from regnet_for_3d_grasping_amd import fused, synthetic
+    from regnet_for_3d_grasping_amd.pn2_utils import modules
+    m7 = gu.meta_full()
+    with open(os.path.join(HERE, "s8_meta.json")) as f:
+        cfg = json.load(f)["cfg"]
+    net = gu.build_scorenet_full(m7, "cpu")
+    pc = synthetic.make_batch(cfg["scene_seed"], cfg["B"], cfg["N"])
+
+    with oracle_backend():
+        F32 = modules._F
+
+        class F64:
+            gather_points = staticmethod(F32.gather_points)
+
+            @staticmethod
+            def farthest_point_sample(points, m):
+                return F32.farthest_point_sample(points.float().contiguous(), m)
+
+            @staticmethod
+            def ball_query(points, centroids, radius, k):
+                return F32.ball_query(points.float().contiguous(), centroids.float().contiguous(), radius, k)
+
+            @staticmethod
+            def group_points(points, index):
+                B, C, _ = points.shape
+                _, M, K = index.shape
+                return torch.gather(points, 2, index.reshape(B, 1, M * K).expand(B, C, M * K)).view(B, C, M, K)
+
+            @staticmethod
+            def search_nn_distance(query, key, k):
+                index, dist2 = F32.search_nn_distance(query.float().contiguous(), key.float().contiguous(), k)
+                return index, dist2.double()          # the graph's weights are functions of the fp32 squared distances
+
+            @staticmethod
+            def feature_interpolate(feature, index, weight):
+                B, C, _ = feature.shape
+                N, K = index.shape[1], index.shape[2]
+                picked = torch.gather(feature, 2, index.reshape(B, 1, N * K).expand(B, C, N * K)).view(B, C, N, K)
+                return (picked * weight.unsqueeze(1)).sum(-1)
+
+        net64 = copy.deepcopy(net).double().eval()
+        saved = (modules._F, fused.ENABLED)
+        modules._F, fused.ENABLED = F64, False
+        t0 = time.time()
+        try:
+            with torch.no_grad():
+                scores = []
+                for b in range(cfg["B"]):
+                    _, s, _ = net64(pc[b:b + 1].double())
+                    scores.append(s[0].numpy())
+                    print("scene %d: %.0f s" % (b, time.time() - t0), flush=True)
+        finally:
+            modules._F, fused.ENABLED = saved
+    s64 = np.stack(scores, 0)
+    ref = np.load(os.path.join(HERE, "s8_b8_25600.npz"))["score"].astype(np.float64)
+    err = np.abs(ref - s64)
+    print("|reference (fp32, torch CPU) - fp64|: max %.3e, mean %.3e, per scene max %s" % (
+        err.max(), err.mean(), ["%.2e" % v for v in err.max(1)]))
+    np.savez_compressed(os.path.join(HERE, "s8_score_fp64.npz"), score=s64, reference_max_abs_err=err.max(1))
+    print("s8_score_fp64.npz", os.path.getsize(os.path.join(HERE, "s8_score_fp64.npz")), "bytes")
+
+
+if __name__ == "__main__":
+    main()
