@@ -420,13 +420,18 @@ def main():
     rank, local_rank, world = sharding.env_world()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (there is no CPU fallback)")
+    # tests only (tests/test_gpu_bench_contract.py): all ranks on device 0 over gloo, to drive the multi-rank code paths of
+    # this script on a one-GPU box (RCCL refuses two ranks on one device)
+    one_device = os.environ.get("REGNET_BENCH_ONE_DEVICE_GLOO") == "1"
+    if one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         # one process per GPU on one host: keep each rank's CPU-side helpers (torch intra-op pool, OpenMP) to its share
         # of the cores, so that N ranks' region-stage host threads do not fight over them
         torch.set_num_threads(max(1, (os.cpu_count() or world) // (2 * world)))
-        sharding.init("nccl", dev)   # RCCL; used only for the barrier + max-over-ranks of the contract
+        sharding.init("gloo" if one_device else "nccl", dev)   # RCCL; forward: only the barrier + max-over-ranks of the contract
     import importlib
     for item in args.set:
         target, value = item.split("=")
@@ -543,7 +548,10 @@ def main():
     if args.train_steps > 0 and not args.score_only:
         # configs[3]'s training iteration on the same box, after the timed region (every rank takes part: the gradient
         # all-reduce is a collective)
-        train_line = measure_train(args, rank, world, dev, args.train_steps, 3, args.train_batch)
+        try:
+            train_line = measure_train(args, rank, world, dev, args.train_steps, 3, args.train_batch)
+        except Exception as exc:   # the headline line must survive a failure of this side measurement (all ranks raise alike)
+            train_line = {"error": repr(exc)}
 
     if rank == 0:
         total_scenes = args.batch * args.steps * world
@@ -603,11 +611,14 @@ def main():
             res["roofline_exclusive"] = r1
         else:
             res.pop("roofline_exclusive")
-        if train_line is not None:
+        if train_line is not None and "error" in train_line:
+            res["train"] = train_line
+        elif train_line is not None:
             res["train"] = {"scenes_per_s": train_line["value"], "ms_per_step": train_line["ms_per_step"],
                             "steps": train_line["steps"], "warmup": train_line["warmup"],
                             "batch_per_gpu": args.train_batch, "roofline": train_line["roofline"],
                             "allreduce_ms": train_line["allreduce_ms"], "workload": train_line["config"]["workload"],
+                            "parallelism": train_line["config"]["parallelism"],
                             "note": "measured after the timed region; `python bench.py --train` times it alone"}
         if world == 1 and args.cpu_scenes > 0:
             res["cpu_baseline"] = cpu_baseline(args, args.cpu_scenes, (score_net, region_net))

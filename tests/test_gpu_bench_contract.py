@@ -45,3 +45,30 @@ def test_bench_under_torch_distributed_run_single_rank():
     d = _line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
                "127.0.0.1", "--master-port", "29533", "bench.py", "--gpus", "1", "--steps", "4", "--warmup", "1", "--cpu-scenes", "1"], env)
     assert d["n_gpus"] == 1 and d["steps"] == 4 and d["value"] > 0 and "cpu_baseline" in d
+
+
+def test_bench_line_carries_the_round3_fields():
+    d = _line([sys.executable, "bench.py", "--steps", "6", "--warmup", "2", "--cpu-scenes", "0", "--latency-runs", "0",
+               "--no-lookahead-steps", "4", "--train-steps", "2"])
+    assert d["config"]["sampling_lookahead_batches"] == 6          # all six batches of the run were sampled by the first launch
+    assert d["value_no_lookahead"] > 0 and "fps-group 1" in d["value_no_lookahead_note"]
+    t = d["train"]
+    assert t["scenes_per_s"] > 0 and t["ms_per_step"] > 0 and t["roofline"]["kernel"] == "tgemm_kernel"
+    assert t["allreduce_ms"] is None                                # one rank: no collective
+
+
+def test_bench_two_ranks_over_gloo_on_one_device():
+    """The multi-rank paths of bench.py -- barrier + max-over-ranks around the timed region, scene sharding by rank, the
+    train object's gradient all-reduce through GradientBucket -- driven with two ranks on the ONE GPU of the test box
+    (REGNET_BENCH_ONE_DEVICE_GLOO: gloo instead of RCCL, which refuses two ranks on one device).  Small scenes, few steps:
+    this checks that the line comes out and adds up, not its speed."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", REGNET_BENCH_ONE_DEVICE_GLOO="1")
+    d = _line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+               "127.0.0.1", "--master-port", "29544", "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1",
+               "--batch", "2", "--points", "6144", "--train-steps", "2", "--train-batch", "1"], env)
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 4 and d["scaling"] == "weak"
+    assert abs(d["value"] - 4 * 3 / (d["ms_per_step"] * 3 / 1e3)) < 1e-2 * d["value"]     # whole-job scenes / max-over-ranks time
+    assert "cpu_baseline" not in d and d["value_no_lookahead"] is None                    # single-rank extras stay off
+    t = d["train"]
+    assert "error" not in t, t
+    assert t["allreduce_ms"] is not None and t["allreduce_ms"] >= 0 and t["parallelism"].startswith("dp2: ONE flat")
