@@ -378,6 +378,11 @@ int regnet_sa3_premul_chain_f32(const float* U, int64_t ldu, const float* V, int
  * `ticket`: one int32 in device memory, ZERO when the kernel starts (the caller clears it on the same stream): the
  * work queue through which the resident workgroups draw their 128-row blocks.                                          */
 int64_t regnet_fp_head_chain_stream_floats(void);
+/* A launch hands out the 128-row blocks [block_first, block_first + block_count) of the regnet_fp_head_chain_blocks(P) the
+ * rows make (block_count < 0: all of them).  Two launches over disjoint ranges, each with its OWN zeroed ticket word, may
+ * run on different streams: the caller can put the last, partial round of blocks (P = 204 800 rows: 1600 blocks = 6 x 256 +
+ * 64) beside whatever its main stream runs next instead of leaving 3/4 of the chip idle for a whole pass.            */
+int64_t regnet_fp_head_chain_blocks(int64_t P);
 /* regnet_fp_head_chain_interp_f32: the same chain with the block's FIRST layer in its prologue -- 3-NN interpolation of
  * the pre-multiplied sparse rows + the narrow skip input + folded BN + ReLU, i.e. regnet_interp_affine_f32's arithmetic
  * (pn2_utils/modules.py:104-131, :500-509) -- so that the (P x 256) first-layer activation is never written:
@@ -388,11 +393,12 @@ int regnet_fp_head_chain_interp_f32(const float* Ys, int64_t ys_sb, int64_t ys_s
                                     int64_t dc, int64_t Cd_small, const float* tables, int64_t B, int64_t Nd,
                                     const float* stream_w, int64_t n_stages, const float* affine, int64_t affine_floats,
                                     const float* wscore, float score_bias, float score_bn_scale, float score_bn_shift,
-                                    float* F, int64_t ldf, float* score, int32_t* ticket, void* stream);
+                                    float* F, int64_t ldf, float* score, int32_t* ticket, int64_t block_first,
+                                    int64_t block_count, void* stream);
 int regnet_fp_head_chain_f32(const float* X, int64_t ldx, const float* stream_w, int64_t n_stages,
                              const float* affine, int64_t affine_floats, const float* wscore, float score_bias,
                              float score_bn_scale, float score_bn_shift, float* F, int64_t ldf, float* score,
-                             int64_t P, int32_t* ticket, void* stream);
+                             int64_t P, int32_t* ticket, int64_t block_first, int64_t block_count, void* stream);
 
 /* ---- training: the 1x1 convolutions of the shared-MLP blocks on the matrix cores (csrc/tgemm.hip) ------------------
  * nn.Conv1d / nn.Conv2d(kernel_size = 1, bias = False) of pn2_utils/nn/modules/conv.py:20-36, :60-76 under autograd

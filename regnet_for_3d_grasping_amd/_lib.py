@@ -77,10 +77,12 @@ SIGNATURES = {
     "regnet_sa3_premul_chain_f32": (_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _int, _vp, _i64,
                                            _vp, _vp]),
     "regnet_fp_head_chain_stream_floats": (_i64, []),
+    "regnet_fp_head_chain_blocks": (_i64, [_i64]),
     "regnet_fp_head_chain_f32": (_int, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _f32, _f32, _f32, _vp, _i64, _vp, _i64, _vp,
-                                        _vp]),
+                                        _i64, _i64, _vp]),
     "regnet_fp_head_chain_interp_f32": (_int, [_vp, _i64, _i64, _vp, _vp, _f32, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _i64,
-                                               _vp, _i64, _vp, _i64, _vp, _f32, _f32, _f32, _vp, _i64, _vp, _vp, _vp]),
+                                               _vp, _i64, _vp, _i64, _vp, _f32, _f32, _f32, _vp, _i64, _vp, _vp, _i64, _i64,
+                                               _vp]),
     "regnet_conv1x1_train_supported": (_int, [_i64, _i64, _i64]),
     "regnet_conv1x1_fwd_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp]),
     "regnet_conv1x1_dgrad_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp]),

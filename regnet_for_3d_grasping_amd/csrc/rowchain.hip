@@ -64,6 +64,8 @@ struct RcArgs {
   int* ticket;                                 // work queue head (zeroed by the caller before the launch)
   long long n_blocks;                          // tickets to hand out: n_full whole blocks (8 waves) + half blocks (waves 0-3)
   long long n_full;                            // tickets < n_full are whole blocks; ticket t >= n_full: half block t - n_full
+  long long blk_first, blk_count;              // this LAUNCH hands out blocks [blk_first, blk_first + blk_count) (a launch may be
+                                               // split: the last partial round of blocks on a side stream, fused.py)
   // ---- interpolating prologue (fp_head_chain_kernel<true>): the first FP layer is evaluated right here, X is not read
   const float* ys; long long ys_sb, ys_sn;     // (B, Ns, 256) sparse rows already multiplied by the layer's W[:, :Cs]
   const long long* idx; const float* dist2;    // (P, 3) three nearest sparse points and their SQUARED distances
@@ -315,8 +317,9 @@ __global__ __launch_bounds__(RC_THREADS, 2) void fp_head_chain_kernel(const RcAr
   for (;;) {
     if (tid == 0) *s_blk = atomicAdd(p.ticket, 1);
     __syncthreads();
-    const long long blk = __builtin_amdgcn_readfirstlane(*s_blk);
-    if (blk >= p.n_blocks) break;
+    const long long tick = __builtin_amdgcn_readfirstlane(*s_blk);
+    if (tick >= p.blk_count) break;
+    const long long blk = p.blk_first + tick;
     if (!primed) {   // prologue of the ring: RC_STAGES - 1 stages in flight
 #pragma unroll
       for (int d = 0; d < RC_STAGES - 1; ++d) ring.fetch();
@@ -830,16 +833,25 @@ extern "C" int regnet_sa3_premul_chain_f32(const float* U, int64_t ldu, const fl
 
 extern "C" int64_t regnet_fp_head_chain_stream_floats(void) { return 60ll * RC_STAGE_FLOATS; }
 
-static int rc_launch_fp_head(RcArgs& a, bool interp, void* stream_handle) {
-  {
-    const long long units = (a.P + 15) / 16, blocks = (units + RC_WAVES - 1) / RC_WAVES;
-    const long long split = (RC_WAVES == 8 && RC_TAIL_HALF) ? (blocks < 128 ? blocks : 128) : 0;
-    a.n_full = blocks - split;
-    const long long rest = units - a.n_full * RC_WAVES;        // 16-row units left for half blocks (4 each)
-    a.n_blocks = a.n_full + (rest > 0 ? (rest + RC_WAVES / 2 - 1) / (RC_WAVES / 2) : 0);
-  }
+static long long rc_fp_head_blocks(long long P, long long* n_full) {
+  const long long units = (P + 15) / 16, blocks = (units + RC_WAVES - 1) / RC_WAVES;
+  const long long split = (RC_WAVES == 8 && RC_TAIL_HALF) ? (blocks < 128 ? blocks : 128) : 0;
+  const long long full = blocks - split;
+  const long long rest = units - full * RC_WAVES;              // 16-row units left for half blocks (4 each)
+  if (n_full) *n_full = full;
+  return full + (rest > 0 ? (rest + RC_WAVES / 2 - 1) / (RC_WAVES / 2) : 0);
+}
+
+extern "C" int64_t regnet_fp_head_chain_blocks(int64_t P) { return P <= 0 ? 0 : rc_fp_head_blocks(P, nullptr); }
+
+static int rc_launch_fp_head(RcArgs& a, bool interp, int64_t block_first, int64_t block_count, void* stream_handle) {
+  a.n_blocks = rc_fp_head_blocks(a.P, &a.n_full);
+  if (block_count < 0) { block_first = 0; block_count = a.n_blocks; }
+  if (block_first < 0 || block_first + block_count > a.n_blocks) return REGNET_ERR_SHAPE;
+  if (block_count == 0) return REGNET_OK;
+  a.blk_first = block_first; a.blk_count = block_count;
   const int cus = 256 * RC_WG_PER_CU;
-  const long long wgs = a.n_blocks < cus ? a.n_blocks : cus;
+  const long long wgs = block_count < cus ? block_count : cus;
   const size_t lds = (size_t)(RC_STAGES * RC_STAGE_FLOATS + RC_AFFINE_MAX + 128 + 4 + (interp ? RC_INTERP_FLOATS : 0)) * sizeof(float);
   const void* kernel = interp ? reinterpret_cast<const void*>(fp_head_chain_kernel<true>)
                               : reinterpret_cast<const void*>(fp_head_chain_kernel<false>);
@@ -854,7 +866,8 @@ static int rc_launch_fp_head(RcArgs& a, bool interp, void* stream_handle) {
 extern "C" int regnet_fp_head_chain_f32(const float* X, int64_t ldx, const float* stream, int64_t n_stages,
                                         const float* affine, int64_t affine_floats, const float* wscore,
                                         float score_bias, float score_bn_scale, float score_bn_shift, float* F,
-                                        int64_t ldf, float* score, int64_t P, int32_t* ticket, void* stream_handle) {
+                                        int64_t ldf, float* score, int64_t P, int32_t* ticket, int64_t block_first,
+                                        int64_t block_count, void* stream_handle) {
   if (P < 0 || ldx < 256 || ldf < 256 || (ldx & 3) || (ldf & 3) || n_stages != 60 || affine_floats != 3328)
     return REGNET_ERR_SHAPE;
   if (P == 0) return REGNET_OK;
@@ -866,7 +879,7 @@ extern "C" int regnet_fp_head_chain_f32(const float* X, int64_t ldx, const float
   a.stream = stream; a.n_stages = (int)n_stages; a.affine = affine; a.affine_floats = (int)affine_floats;
   a.wscore = wscore; a.score_bias = score_bias; a.score_bn_scale = score_bn_scale; a.score_bn_shift = score_bn_shift;
   a.ticket = ticket;
-  return rc_launch_fp_head(a, false, stream_handle);
+  return rc_launch_fp_head(a, false, block_first, block_count, stream_handle);
 }
 
 extern "C" int regnet_fp_head_chain_interp_f32(const float* Ys, int64_t ys_sb, int64_t ys_sn, const int64_t* idx,
@@ -875,7 +888,8 @@ extern "C" int regnet_fp_head_chain_interp_f32(const float* Ys, int64_t ys_sb, i
                                                int64_t B, int64_t Nd, const float* stream, int64_t n_stages,
                                                const float* affine, int64_t affine_floats, const float* wscore,
                                                float score_bias, float score_bn_scale, float score_bn_shift, float* F,
-                                               int64_t ldf, float* score, int32_t* ticket, void* stream_handle) {
+                                               int64_t ldf, float* score, int32_t* ticket, int64_t block_first,
+                                               int64_t block_count, void* stream_handle) {
   if (B < 0 || Nd < 0 || ldf < 256 || (ldf & 3) || n_stages != 60 || affine_floats != 3328 || (ys_sb & 3) || (ys_sn & 3) ||
       ys_sn < 256 || (dense_small && (Cd_small < 1 || Cd_small > 4)))
     return REGNET_ERR_SHAPE;
@@ -892,5 +906,5 @@ extern "C" int regnet_fp_head_chain_interp_f32(const float* Ys, int64_t ys_sb, i
   a.ticket = ticket;
   a.ys = Ys; a.ys_sb = ys_sb; a.ys_sn = ys_sn; a.idx = (const long long*)idx; a.dist2 = dist2; a.eps = eps; a.Nd = Nd;
   a.dsm = dense_small; a.db = db; a.dn = dn; a.dc = dc; a.Cdsm = (int)Cd_small; a.tables = tables;
-  return rc_launch_fp_head(a, true, stream_handle);
+  return rc_launch_fp_head(a, true, block_first, block_count, stream_handle);
 }

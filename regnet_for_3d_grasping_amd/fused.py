@@ -679,12 +679,23 @@ def fp_head_chain(h1, seg, fp_layers, P):
     ticket = torch.zeros((1,), dtype=torch.int32, device=h1.device)   # work-queue head, cleared on this stream
     _check(_L.regnet_fp_head_chain_f32(h1.data_ptr(), h1.stride(0), stream.data_ptr(), 60, affine.data_ptr(),
                                        affine.numel(), w.data_ptr(), bias, bn_scale, bn_shift, F.data_ptr(),
-                                       F.stride(0), score.data_ptr(), P, ticket.data_ptr(), _stream(h1)),
+                                       F.stride(0), score.data_ptr(), P, ticket.data_ptr(), 0, -1, _stream(h1)),
            "fp_head_chain")
     return F, score
 
 
 FP_HEAD_INTERP = True   # ... with the block's first layer (interpolation of the pre-multiplied sparse rows) in its prologue
+TAIL_SINK = None        # a list (set by ForwardPipeline around a feature stage): fp_head_chain_interp puts its partial last round
+                        # of blocks on a side stream and appends the event that marks its end; None: one launch, as always
+_CUS = 256
+_tail_streams = {}
+
+
+def _tail_stream(device):
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    if key not in _tail_streams:
+        _tail_streams[key] = torch.cuda.Stream(device)
+    return _tail_streams[key]
 
 
 @_on_tensor_device
@@ -697,16 +708,40 @@ def fp_head_chain_interp(Ys, idx, dist2, eps, dense_small, wd4, first, seg, fp_l
     P = B * Nd
     F = torch.empty((P, 256), dtype=torch.float32, device=Ys.device)
     score = torch.empty((P,), dtype=torch.float32, device=Ys.device)
-    ticket = torch.zeros((1,), dtype=torch.int32, device=Ys.device)
+    tickets = torch.zeros((2,), dtype=torch.int32, device=Ys.device)
     if dense_small is None:
         dptr, db, dc, dn, Cd = None, 0, 0, 0, 0
     else:
         dptr, (db, dc, dn), Cd = dense_small.data_ptr(), dense_small.stride(), dense_small.size(1)
-    _check(_L.regnet_fp_head_chain_interp_f32(Ys.data_ptr(), Ns * Ys.stride(0), Ys.stride(0), idx.data_ptr(),
-                                              dist2.data_ptr(), float(eps), dptr, db, dn, dc, Cd, tables.data_ptr(), B, Nd,
-                                              stream.data_ptr(), 60, affine.data_ptr(), affine.numel(), w.data_ptr(), bias,
-                                              bn_scale, bn_shift, F.data_ptr(), F.stride(0), score.data_ptr(),
-                                              ticket.data_ptr(), _stream(Ys)), "fp_head_chain_interp")
+
+    def launch(first, count, ticket, stream_handle):
+        _check(_L.regnet_fp_head_chain_interp_f32(Ys.data_ptr(), Ns * Ys.stride(0), Ys.stride(0), idx.data_ptr(),
+                                                  dist2.data_ptr(), float(eps), dptr, db, dn, dc, Cd, tables.data_ptr(), B,
+                                                  Nd, stream.data_ptr(), 60, affine.data_ptr(), affine.numel(), w.data_ptr(),
+                                                  bias, bn_scale, bn_shift, F.data_ptr(), F.stride(0), score.data_ptr(),
+                                                  ticket.data_ptr(), first, count, stream_handle), "fp_head_chain_interp")
+
+    # The last round of 128-row blocks is partial (8 x 25 600 rows: 1600 blocks = 6 x 256 + 64): run alone it keeps 64 CUs
+    # busy for a whole pass while 192 idle (a pass costs the same however few blocks it holds).  A caller that can run
+    # something else meanwhile -- ForwardPipeline: the NEXT batch's first kernels -- collects it from TAIL_SINK: the tail
+    # goes to a side stream behind the inputs, and the caller orders the consumers of F / score behind the event it gets.
+    blocks = _L.regnet_fp_head_chain_blocks(P)
+    tail = blocks % _CUS
+    if TAIL_SINK is not None and blocks > _CUS and 0 < tail <= _CUS // 2:
+        cur = torch.cuda.current_stream(Ys.device)
+        side = _tail_stream(Ys.device)
+        ready = torch.cuda.Event()
+        ready.record(cur)
+        side.wait_event(ready)
+        launch(blocks - tail, tail, tickets[1:], side.cuda_stream)
+        done = torch.cuda.Event()
+        done.record(side)
+        for t in (Ys, idx, dist2, tables, stream, affine, w, F, score, tickets) + (() if dense_small is None else (dense_small,)):
+            t.record_stream(side)
+        TAIL_SINK.append(done)
+        launch(0, blocks - tail, tickets[:1], cur.cuda_stream)
+    else:
+        launch(0, -1, tickets[:1], _stream(Ys))
     return F, score
 
 

@@ -100,7 +100,8 @@ class ForwardPipeline:
         self.score_net, self.region_net, self.with_region = score_net, region_net, with_region
         self.fps_group = int(fps_group)   # batches whose level-1 sampling shares one launch; 0 = as many as give 64 scenes (<= 8)
         self.first_launch_groups = max(1, int(first_launch_groups))
-        self.geometry_ahead = max(1, int(geometry_ahead))   # batches whose ball-query / 3-NN geometry runs ahead of the features
+        self.geometry_ahead = max(1, int(geometry_ahead))
+        self.split_chain_tail = True      # see _features   # batches whose ball-query / 3-NN geometry runs ahead of the features
         self.first_launch_batches = None  # what the first sampling launch of the last ``run`` really took (bench.py reports it)
         self._one_sampling_stream = False
         dev = next(score_net.parameters()).device
@@ -174,11 +175,19 @@ class ForwardPipeline:
     def _features(self, item):
         s_mlp = self.s_mlps[self._n_featured % len(self.s_mlps)]
         self._n_featured += 1
+        from . import fused
         with torch.cuda.stream(s_mlp), torch.no_grad():
             s_mlp.wait_event(item["geo_done"])
-            all_feature, score, _ = self.score_net(item["pc"], plan=item["plan"])
+            # the last, partial round of the final chain kernel runs on a side stream beside the NEXT batch's first kernels
+            # (fused.TAIL_SINK); whoever reads this batch's feature / scores waits for that event too
+            fused.TAIL_SINK = tails = [] if self.split_chain_tail else None
+            try:
+                all_feature, score, _ = self.score_net(item["pc"], plan=item["plan"])
+            finally:
+                fused.TAIL_SINK = None
             done = torch.cuda.Event()
             done.record(s_mlp)
+            item["tail_done"] = list(tails or ())
         all_feature.record_stream(self.s_reg)
         score.record_stream(self.s_reg)
         item.update(all_feature=all_feature, score=score, mlp_done=done)
@@ -191,6 +200,8 @@ class ForwardPipeline:
         out = {"all_feature": all_feature, "score": score}
         with torch.cuda.stream(self.s_reg), torch.no_grad():
             self.s_reg.wait_event(item["mlp_done"])
+            for ev in item.get("tail_done", ()):
+                self.s_reg.wait_event(ev)
             if self.with_region:
                 (center_pc, center_idx, g_idx, g, gm_idx, gm, _) = get_grasp_allobj(pc, score, PARAMS, [])
                 with contextlib.redirect_stdout(io.StringIO()):
@@ -205,6 +216,8 @@ class ForwardPipeline:
             # nothing here blocks the host, so without this the driver thread would enqueue every remaining batch at
             # once; a bounded look-ahead (max_pending_regions batches) is what the full pipeline runs with
             item["mlp_done"].synchronize()
+            for ev in item.get("tail_done", ()):
+                ev.synchronize()
         out["done"] = done
         return out
 

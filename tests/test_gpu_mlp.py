@@ -485,3 +485,15 @@ def test_fp_head_chain_interp_equals_interp_affine_then_chain(B, Nd, Ns):
     assert torch.isfinite(F).all() and torch.isfinite(s).all()
     torch.testing.assert_close(F, F_ref, rtol=2e-5, atol=2e-5)
     torch.testing.assert_close(s, s_ref, rtol=0, atol=2e-5)
+    # the partial last round of blocks on a side stream (what ForwardPipeline does): bit-identical rows
+    fused.TAIL_SINK = sink = []
+    try:
+        F2, s2 = fused.fp_head_chain_interp(Ys, idx, dist2, eps, rgb, wd4, layers[0], seg, layers, B, Ns, Nd)
+    finally:
+        fused.TAIL_SINK = None
+    blocks = (B * Nd + 127) // 128
+    assert len(sink) == (1 if blocks > 256 and 0 < blocks % 256 <= 128 else 0)
+    for ev in sink:
+        ev.synchronize()
+    torch.cuda.synchronize()
+    assert torch.equal(F2, F) and torch.equal(s2, s)
