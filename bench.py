@@ -570,6 +570,10 @@ def main():
                 small = float((count <= 32).float().mean())
                 roofline["executed_share_of_algorithmic_flops"] = round(1.0 - 0.5 * small * 49152.0 / 49920.0, 4)
                 roofline["frac_executed"] = round(roofline["frac"] * roofline["executed_share_of_algorithmic_flops"], 4)
+        if roofline and getattr(pipe, "split_chain_tail", False):
+            roofline["overlap_note"] = ("the previous batch's last chain kernel leaves its partial final round of row blocks (64 of "
+                                        "1600 workgroup passes) on a side stream; it runs beside the first ~0.25 ms of this kernel's "
+                                        "launches, whose duration includes that sharing")
         if roofline and args.mlp_streams > 1:
             roofline["concurrency"] = ("%d feature-stage streams: launches of this family overlap each other, so the launch "
                                        "duration above (what rocprofv3 shows too) includes time-sharing; roofline_exclusive "
