@@ -69,6 +69,24 @@ def _round_up(x, m):
     return (x + m - 1) // m * m
 
 
+_ticket_pools = {}
+
+
+def _tickets(device, n=1):
+    """``n`` zeroed int32 work-queue heads for a ticket-driven chain kernel.  Carved out of a pool that is zeroed once per 256
+    words ON THE STREAM THAT USES IT (a word is handed out once and never reused): one fill kernel per ~60 feature stages
+    instead of one -- and its ~10 us launch gap -- in front of every chain launch."""
+    stream = torch.cuda.current_stream(device)
+    key = (device.index if device.index is not None else torch.cuda.current_device(), stream.cuda_stream)
+    pool = _ticket_pools.get(key)
+    if pool is None or pool[1] + n > pool[0].numel():
+        pool = [torch.zeros((256,), dtype=torch.int32, device=device), 0]
+        _ticket_pools[key] = pool
+    out = pool[0][pool[1]:pool[1] + n]
+    pool[1] += n
+    return out
+
+
 class _Layer:
     """One conv(1x1, bias-free or biased) + eval BatchNorm (+ReLU) packed for the GEMM kernel."""
 
@@ -390,6 +408,23 @@ def sa_group(module, xyz, ctr):
         # matrix cores' critical path
         geo["count"] = count
         geo["order"] = torch.argsort((count.view(-1) > 32).to(torch.uint8), stable=True)
+    elif (PREMUL and not module.training and not torch.is_grad_enabled() and module.use_xyz
+          and module.mlp[0].conv.in_channels > 8 and len(module.mlp) >= 2):
+        # wide gathered input (levels 2+, see sa_features): everything of the pre-multiplied first layer that depends on the
+        # coordinates only -- the scene mean, the centred source coordinates, the per-centre term V -- is computed HERE, in
+        # the geometry stage, off the feature stage's stream (two reductions / subtractions, a pack and a tiny GEMM per level)
+        Cf = module.mlp[0].conv.in_channels - 3
+        layers = _packed_stack(module, module.mlp,
+                               lambda: torch.cat([torch.arange(3, 3 + Cf), torch.arange(0, 3)]).to(xyz.device))
+        first = layers[0]
+        if first.relu and first.N % 4 == 0 and layers[1].K == first.N:
+            _, v_layer = _premul_layers(first, Cf)
+            if PREMUL_CENTRE:
+                mu = xyz.mean(dim=2, keepdim=True)
+                geo["src_xyz"], ctr_xyz = xyz - mu, new_xyz - mu
+            else:
+                geo["src_xyz"], ctr_xyz = xyz, new_xyz
+            geo["V"] = mlp_layer(pack_rows(None, ctr_xyz, 4), 4, v_layer, B * M)
     return geo
 
 
@@ -436,13 +471,16 @@ def sa_features(module, xyz, feature, geo):
         # U[j] - V[c] = s W [f_j | x_j - x_c] - t only up to fp32 rounding of the two big terms: both sides use the
         # coordinates RELATIVE TO THE SCENE'S MEAN (the difference is unchanged, the magnitudes -- table-top scenes sit
         # ~0.75 m from the origin -- and with them the cancellation error of the subtraction shrink)
-        if PREMUL_CENTRE:
-            mu = xyz.mean(dim=2, keepdim=True)
-            src_xyz, ctr_xyz = xyz - mu, geo["new_xyz"] - mu
+        if "V" in geo:                       # coordinate-only parts already done by the geometry stage (sa_group)
+            src_xyz, V = geo["src_xyz"], geo["V"]
         else:
-            src_xyz, ctr_xyz = xyz, geo["new_xyz"]
+            if PREMUL_CENTRE:
+                mu = xyz.mean(dim=2, keepdim=True)
+                src_xyz, ctr_xyz = xyz - mu, geo["new_xyz"] - mu
+            else:
+                src_xyz, ctr_xyz = xyz, geo["new_xyz"]
+            V = mlp_layer(pack_rows(None, ctr_xyz, 4), 4, v_layer, B * M)
         U = mlp_layer(pack_rows(feature, src_xyz, width), width, u_layer, B * N1)
-        V = mlp_layer(pack_rows(None, ctr_xyz, 4), 4, v_layer, B * M)
         if supports_sa3_chain(layers) and U.size(1) == 512:
             # level 3: the same with 512-wide activations (layer 2 as two K-halves, csrc/rowchain.hip)
             pooled = sa3_premul_chain(U, V, geo["nbr"], module, layers, B, N1, M)
@@ -566,7 +604,7 @@ def sa_premul_chain(U, V, nbr, module, layers, B, Nsrc, M):
     """relu(U[nbr] - V[centre]) -> 256 -> 512 -> max over the 64 neighbours, one launch; -> (B*M, 512)."""
     stream, affine = _packed_sa_chain(module, layers)
     out = torch.empty((B * M, 512), dtype=torch.float32, device=U.device)
-    ticket = torch.zeros((1,), dtype=torch.int32, device=U.device)
+    ticket = _tickets(U.device)
     _check(_L.regnet_sa_premul_chain_f32(U.data_ptr(), U.stride(0), V.data_ptr(), V.stride(0), nbr.data_ptr(), B, Nsrc,
                                          M, stream.data_ptr(), 24, affine.data_ptr(), affine.numel(), layers[2].relu,
                                          out.data_ptr(), out.stride(0), ticket.data_ptr(), _stream(U)),
@@ -602,7 +640,7 @@ def sa3_premul_chain(U, V, nbr, module, layers, B, Nsrc, M):
     """relu(U[nbr] - V[centre]) -> 512 -> 1024 -> max over the 64 neighbours, one launch; -> (B*M, 1024)."""
     stream, affine = _packed_sa3_chain(module, layers)
     out = torch.empty((B * M, 1024), dtype=torch.float32, device=U.device)
-    ticket = torch.zeros((1,), dtype=torch.int32, device=U.device)
+    ticket = _tickets(U.device)
     _check(_L.regnet_sa3_premul_chain_f32(U.data_ptr(), U.stride(0), V.data_ptr(), V.stride(0), nbr.data_ptr(), B, Nsrc,
                                           M, stream.data_ptr(), 96, affine.data_ptr(), affine.numel(), layers[2].relu,
                                           out.data_ptr(), out.stride(0), ticket.data_ptr(), _stream(U)),
@@ -676,7 +714,7 @@ def fp_head_chain(h1, seg, fp_layers, P):
     w, bias, bn_scale, bn_shift = _packed_head(seg)
     F = torch.empty((P, 256), dtype=torch.float32, device=h1.device)
     score = torch.empty((P,), dtype=torch.float32, device=h1.device)
-    ticket = torch.zeros((1,), dtype=torch.int32, device=h1.device)   # work-queue head, cleared on this stream
+    ticket = _tickets(h1.device)   # work-queue head, zeroed on this stream
     _check(_L.regnet_fp_head_chain_f32(h1.data_ptr(), h1.stride(0), stream.data_ptr(), 60, affine.data_ptr(),
                                        affine.numel(), w.data_ptr(), bias, bn_scale, bn_shift, F.data_ptr(),
                                        F.stride(0), score.data_ptr(), P, ticket.data_ptr(), 0, -1, _stream(h1)),
@@ -708,7 +746,7 @@ def fp_head_chain_interp(Ys, idx, dist2, eps, dense_small, wd4, first, seg, fp_l
     P = B * Nd
     F = torch.empty((P, 256), dtype=torch.float32, device=Ys.device)
     score = torch.empty((P,), dtype=torch.float32, device=Ys.device)
-    tickets = torch.zeros((2,), dtype=torch.int32, device=Ys.device)
+    tickets = _tickets(Ys.device, 2)
     if dense_small is None:
         dptr, db, dc, dn, Cd = None, 0, 0, 0, 0
     else:
