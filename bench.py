@@ -28,6 +28,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
+TRAIN_GC_INTERVAL = 50     # RefineTrainer(gc_interval=...): iterations between the trainer's own garbage collections
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32-input MFMA peak (same as the fp32 vector peak)
 SCORENET_GFLOP_PER_SCENE = {25600: 148.27, 51200: 180.20}  # SURVEY.md §8(d), 2*MAC of every 1x1 conv
@@ -296,7 +297,10 @@ def measure_train(args, rank, world, dev, steps, warmup, batch):
                                       grasp_score_threshold=pipeline.GRASP_SCORE_THRESHOLD, radius=pipeline.DEPTH,
                                       reg_channel=pipeline.REG_CHANNEL)
     region_net.load_state_dict(synthetic.seeded_state_dict(region_net, 11))
-    trainer = RefineTrainer(score_net.to(dev), region_net.to(dev), pipeline.PARAMS, pipeline.GRIPPER_PARAMS)
+    import gc
+    gc_was_on = gc.isenabled()
+    trainer = RefineTrainer(score_net.to(dev), region_net.to(dev), pipeline.PARAMS, pipeline.GRIPPER_PARAMS,
+                            gc_interval=TRAIN_GC_INTERVAL)
     pc = pc_cpu.to(dev)
     np.random.seed(rank)
     # HIP events around the native 1x1-convolution kernels (forward / input gradient / weight gradient: the MFMA work of
@@ -336,6 +340,12 @@ def measure_train(args, rank, world, dev, steps, warmup, batch):
     timer.enabled = False
     for name, fn in originals.items():
         setattr(conv1x1_train, name, fn)
+    # what the trainer's own collection (every TRAIN_GC_INTERVAL iterations) costs: one collection timed here, amortised below
+    t1 = time.perf_counter()
+    gc.collect()
+    gc_ms = (time.perf_counter() - t1) * 1e3
+    if gc_was_on:
+        gc.enable()
     if rank != 0:
         return None
     _, roofline = roofline_of(timer.summary(), steps, B)
@@ -346,6 +356,10 @@ def measure_train(args, rank, world, dev, steps, warmup, batch):
             "dtype": "f32", "data": "synthetic", "roofline": roofline,
             # event-timed duration of the iteration's single flat gradient all-reduce (RCCL, side stream); null at 1 GPU
             "allreduce_ms": round(sum(allreduce_ms) / len(allreduce_ms), 4) if allreduce_ms else None,
+            # CPython's automatic cyclic collector is off during training (RefineTrainer(gc_interval=N) collects every N
+            # iterations itself: left on, it stalls every ~10th iteration by 60-100 ms); the amortised cost is in this figure
+            "gc": {"interval_iterations": TRAIN_GC_INTERVAL, "one_collection_ms": round(gc_ms, 2),
+                   "ms_per_step_incl_amortised_gc": round(dt / steps * 1e3 + gc_ms / TRAIN_GC_INTERVAL, 3)},
             "config": {"workload": "configs[3]: training iteration (forward with labels, stage-2 + refine losses, backward, "
                                    "two Adam steps), %d-pt synthetic scenes, batch=%d per GPU" % (N, B),
                        "points": N, "batch_per_gpu": B, "global_batch": B * world,

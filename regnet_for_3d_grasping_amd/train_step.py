@@ -281,8 +281,19 @@ class RefineTrainer:
     initialised.  BatchNorm running statistics stay per rank, as ``nn.DataParallel`` keeps them per replica (only device
     0's survive there; here ``broadcast_module_state`` before saving a checkpoint gives every rank rank 0's)."""
 
-    def __init__(self, score_net, region_net, params, gripper_params, lr=0.001, reduce="sum"):
+    def __init__(self, score_net, region_net, params, gripper_params, lr=0.001, reduce="sum", gc_interval=None):
+        """``gc_interval``: every iteration builds and drops an autograd graph of a few thousand Python objects; CPython's
+        automatic cyclic collector then runs a full collection every ~10 iterations that takes 60-100 ms with the device idle
+        (measured: iterations of 59.5 ms with spikes of 106-157 ms; none with the collector off).  With ``gc_interval=N`` the
+        trainer switches the automatic collector OFF (process-wide, like the "manual GC" switches of large training
+        frameworks) and collects itself every N iterations; None leaves the interpreter alone."""
         self.score_net, self.region_net = score_net, region_net
+        self.gc_interval, self._iterations = gc_interval, 0
+        if gc_interval:
+            import gc
+            gc.collect()
+            gc.freeze()      # what exists now (modules, parameters, the interpreter's own objects) is never traversed again:
+            gc.disable()     # a periodic collection then only walks the iterations' garbage (~100 ms -> a few ms)
         self.params, self.gripper_params, self.reduce = params, gripper_params, reduce
         broadcast_module_state(score_net, region_net)
         self.opt_score = torch.optim.Adam([{"params": score_net.parameters(), "initial_lr": lr}], lr=lr)
@@ -394,6 +405,10 @@ class RefineTrainer:
             self.bucket.reduce_gradients()
         self.opt_score.step()
         self.opt_region.step()
+        self._iterations += 1
+        if self.gc_interval and self._iterations % self.gc_interval == 0:
+            import gc
+            gc.collect()
         return total.detach(), parts
 
     def end_epoch(self):
