@@ -67,6 +67,35 @@ __device__ __forceinline__ float wave_max_f32(float v) {
   return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
 }
 
+#define DPP_MINU_STEP(v, CTRL)                                                                                     \
+  v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, false))
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
+  DPP_MINU_STEP(v, 0xB1);
+  DPP_MINU_STEP(v, 0x4E);
+  DPP_MINU_STEP(v, 0x141);
+  DPP_MINU_STEP(v, 0x140);
+  const unsigned r0 = (unsigned)__builtin_amdgcn_readlane((int)v, 0), r1 = (unsigned)__builtin_amdgcn_readlane((int)v, 16);
+  const unsigned r2 = (unsigned)__builtin_amdgcn_readlane((int)v, 32), r3 = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
+  return min(min(r0, r1), min(r2, r3));
+}
+// lexicographic maximum of (hi, lo) pairs over a 16-lane row, left in every lane of the row
+#define DPP_MAXPAIR_STEP(hi, lo, CTRL)                                                                             \
+  {                                                                                                                \
+    const unsigned ohi = (unsigned)__builtin_amdgcn_update_dpp((int)hi, (int)hi, CTRL, 0xf, 0xf, false);           \
+    const unsigned olo = (unsigned)__builtin_amdgcn_update_dpp((int)lo, (int)lo, CTRL, 0xf, 0xf, false);           \
+    const bool take = ohi > hi || (ohi == hi && olo > lo);                                                         \
+    hi = take ? ohi : hi;                                                                                          \
+    lo = take ? olo : lo;                                                                                          \
+  }
+
+#ifndef FPS_ONE_BARRIER
+#define FPS_ONE_BARRIER 0   // 1: fps_sorted_kernel with ONE barrier per round (measurement builds, scripts/fps_multi_probe.py).
+                            // Bit-identical, but SLOWER: 2.02 us per round against 1.63 (N = 25 600, one scene) -- every wave
+                            // then searches its candidate's slot in front of the barrier (75 VALU instructions x 16 waves on 4
+                            // SIMDs) where the two-barrier scheme lets the ONE winning wave do it; what the second barrier
+                            // costs is less than that.
+#endif
+
 // min(a, b) for non-NaN operands as ONE v_min_f32 (fminf() inserts a canonicalising v_max first).
 __device__ __forceinline__ float vmin_f32(float a, float b) {
   float r;
@@ -197,6 +226,7 @@ __global__ __launch_bounds__(1024) void fps_sorted_kernel(const float* __restric
   __shared__ float red[6][W];
   __shared__ unsigned wsum[W];
   __shared__ unsigned win_key[2];
+  __shared__ uint2 rec[2][W];          // FPS_ONE_BARRIER: per wave (bits of its maximum, ~its smallest tie-break key)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* base = xyz + (int64_t)blockIdx.x * sb;
   int64_t* out = index + (int64_t)blockIdx.x * M;
@@ -352,6 +382,48 @@ __global__ __launch_bounds__(1024) void fps_sorted_kernel(const float* __restric
     }
     FPS_T(2);
     const float wmax = wave_max_f32(tmax);
+#if FPS_ONE_BARRIER && FPS_ABLATE == 0
+    {
+      // ONE barrier per round: every wave settles its own candidate BEFORE the barrier -- the lanes holding the wave's
+      // maximum look up which slot it was and their tie-break key (the search rounds 1-2 ran after a first barrier, in the
+      // winning wave only: it was on the critical path there too), the wave's smallest key and its maximum go to LDS as one
+      // 64-bit record; behind the barrier every wave reduces the 16 records by itself (4 DPP steps on (bits, ~key) pairs:
+      // largest distance, then smallest key -- the order the two-barrier scheme realised with a block maximum followed by
+      // an LDS atomicMin over the keys).  No atomics, no second barrier, no re-arming; records are double-buffered by the
+      // round's parity (a wave can be at most one barrier ahead of the slowest).
+      unsigned kmin = 0xffffffffu;
+      if (wmax > 0.f && tmax == wmax) {
+        int nmatch = 0, slot = 0;
+#pragma unroll
+        for (int s = 0; s < PPT; ++s) {
+          const bool hit = dist[s] == wmax;
+          nmatch += hit ? 1 : 0;
+          slot = hit ? s : slot;
+        }
+        kmin = fps_key((int)perm[tid * PPT + slot], rb_log2);
+        if (nmatch > 1) {
+#pragma unroll 1
+          for (int s = 0; s < PPT; ++s)
+            if (dist_at(dist, s) == wmax) kmin = min(kmin, fps_key((int)perm[tid * PPT + s], rb_log2));
+        }
+      }
+      const unsigned wkey = wave_min_u32(kmin);
+      if (lane == 0) rec[buf][wave] = make_uint2(__float_as_uint(wmax), ~wkey);
+      __syncthreads();
+      const uint2 r16 = rec[buf][lane & (W - 1)];
+      unsigned hi = r16.x, lo = r16.y;
+      DPP_MAXPAIR_STEP(hi, lo, 0xB1)
+      DPP_MAXPAIR_STEP(hi, lo, 0x4E)
+      DPP_MAXPAIR_STEP(hi, lo, 0x141)
+      DPP_MAXPAIR_STEP(hi, lo, 0x140)
+      const unsigned bhi = (unsigned)__builtin_amdgcn_readfirstlane((int)hi);
+      const unsigned blo = (unsigned)__builtin_amdgcn_readfirstlane((int)lo);
+      if (bhi != 0u) cur = fps_unkey(~blo, rb_log2);      // all distances 0: repeat cur (the reference's max_ind stays cur)
+      cur = __builtin_amdgcn_readfirstlane(cur);
+      if (tid == 0) out[i] = cur;
+      continue;
+    }
+#endif
     if (lane == 0) part[buf][wave] = wmax;
     FPS_T(3);
     __syncthreads();

@@ -10,6 +10,7 @@ import hashlib, json, os, subprocess, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 LIBS = {"default (1 workgroup per scene)": None,
+        "one barrier per round (-DFPS_ONE_BARRIER=1)": os.path.join(REPO, "scripts", "ablate", "libregnet_fps_1barrier.so"),
         "2 cooperating workgroups": os.path.join(REPO, "scripts", "ablate", "libregnet_fps2.so"),
         "4 cooperating workgroups": os.path.join(REPO, "scripts", "ablate", "libregnet_fps4.so")}
 
@@ -18,6 +19,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "build":
     for g, path in ((2, LIBS["2 cooperating workgroups"]), (4, LIBS["4 cooperating workgroups"])):
         build.build_variant(path, ["-DFPS_FORCE_MULTI=%d" % g])
         print("built", path)
+    build.build_variant(LIBS["one barrier per round (-DFPS_ONE_BARRIER=1)"], ["-DFPS_ONE_BARRIER=1"])
     sys.exit(0)
 
 if len(sys.argv) > 1 and sys.argv[1] == "child":
