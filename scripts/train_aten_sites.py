@@ -1,0 +1,47 @@
+"""Which Python lines launch ATen kernels in one TRAINING iteration (RefineTrainer.step): torch profiler with stacks,
+device time per (op, innermost package frame), leaf ops only.  usage: python scripts/train_aten_sites.py"""
+import os, sys, collections
+sys.path.insert(0, os.getcwd())
+import numpy as np, torch
+from torch.profiler import profile, ProfilerActivity
+from regnet_for_3d_grasping_amd import pipeline, synthetic
+from regnet_for_3d_grasping_amd.gripper_region_network import GripperRegionNetwork
+from regnet_for_3d_grasping_amd.score_network import ScoreNetwork
+from regnet_for_3d_grasping_amd.train_step import RefineTrainer
+dev = "cuda:0"; B, N = 8, 25600
+pc = synthetic.make_batch(1000, B, N)
+records = [synthetic.make_grasp_labels(pc[b].numpy(), 50 + b) for b in range(B)]
+target = torch.from_numpy(np.random.default_rng(2).uniform(0, 1, (B, N)).astype(np.float32)).to(dev)
+s = ScoreNetwork(training=True); s.load_state_dict(synthetic.seeded_state_dict(s, 7))
+r = GripperRegionNetwork(training=True, group_num=256, gripper_num=64, grasp_score_threshold=0.5, radius=0.06, reg_channel=10)
+r.load_state_dict(synthetic.seeded_state_dict(r, 11))
+t = RefineTrainer(s.to(dev), r.to(dev), pipeline.PARAMS, pipeline.GRIPPER_PARAMS, gc_interval=1000)
+pc = pc.to(dev); np.random.seed(0)
+ahead = t.prefetch(pc)
+for _ in range(4):
+    nxt = t.prefetch(pc); t.step(pc, target, records, plan=ahead); ahead = nxt
+torch.cuda.synchronize()
+n = 3
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+    for _ in range(n):
+        nxt = t.prefetch(pc); t.step(pc, target, records, plan=ahead); ahead = nxt
+    torch.cuda.synchronize()
+agg = collections.defaultdict(lambda: [0.0, 0])
+for ev in prof.events():
+    if not ev.name.startswith("aten::") or ev.device_time <= 0:
+        continue
+    if any(c.name.startswith("aten::") and c.device_time > 0 for c in ev.cpu_children):
+        continue                                   # count the leaf that launched the kernel
+    site = "(autograd / no package frame)"
+    for fr in ev.stack:
+        if "regnet_for_3d_grasping_amd" in fr and "/torch/" not in fr:
+            site = fr.split("regnet_for_3d_grasping_amd/")[-1]
+            break
+    a = agg[(ev.name, site)]
+    a[0] += ev.device_time; a[1] += 1
+rows = sorted(agg.items(), key=lambda kv: -kv[1][0])
+tot = sum(v[0] for v in agg.values()) / n
+print("ATen kernels: %.2f ms of device time per iteration" % (tot / 1e3))
+print("device us per iteration | calls per iteration | op | site")
+for (name, site), (tt, c) in rows[:40]:
+    print("%10.1f %6.1f  %-30s %s" % (tt / n, c / n, name, site))
