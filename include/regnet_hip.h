@@ -241,6 +241,15 @@ int regnet_grasp_antipodal_stats_f32(const float* points, int64_t pn, int64_t pc
                                      const float* x_hi_per_grasp, float half_thickness, float half_width, float half_space,
                                      float back_x, float neighbour_depth, float* stats, int32_t* side_counts, void* stream);
 
+/* Training twins (round 3).  regnet_gather_max_arg_f32: regnet_gather_max_f32 that also returns, per (row, channel), the
+ * source row that gave the maximum (arg (R,F) int64; first maximum in group order; a negative row id counts from the end as
+ * the reference's `all_feature.view(-1,F)[index]` does, gripper_region_network.py:382-390) -- the backward of the pooled
+ * region feature then scatters R x F values.  regnet_rowsum_neg_f32: out[r] = -sum_k x[r*K + k] (K a power of two in
+ * 4..256): the gradient of the per-centre term of a pre-multiplied first layer (dV = -sum over the K neighbours of dY). */
+int regnet_gather_max_arg_f32(const float* feat, int64_t num_rows, int64_t F, const int64_t* rows, int64_t R, int64_t G,
+                              float* out, int64_t* arg, void* stream);
+int regnet_rowsum_neg_f32(const float* x, int64_t rows, int64_t K, float* out, void* stream);
+
 /* regnet_resample_groups_f32: the gather half of get_regiondataset.py:331-352 (_get_group_pc).  cand (B,Nc,cap) int32: the
  * ascending member lists of regnet_radius_group_f32; pos (B,Nc,G) int64: positions into them drawn on the host with numpy's
  * RNG stream (-1 in every slot of a centre without candidates); pc (B,N,C) rows with element strides (pb, pn), channels

@@ -409,6 +409,74 @@ extern "C" int regnet_gather_max_f32(const float* feat, int64_t num_rows, int64_
   return REGNET_OK;
 }
 
+// Training twin of gather_max_kernel: also records WHICH row gave the maximum (the backward scatters R x F values instead
+// of going through the reference's materialised (R, G, F) gather and its zero-filled gradient), and a negative row id
+// counts from the end like the reference's advanced indexing does (all_feature.view(-1, F)[index]).
+__global__ __launch_bounds__(256) void gather_max_arg_kernel(const float* __restrict__ feat, int64_t num_rows, int F,
+                                                            const int64_t* __restrict__ rows, int G,
+                                                            float* __restrict__ out, int64_t* __restrict__ arg) {
+  const int64_t r = blockIdx.x;
+  const int64_t* idx = rows + r * G;
+  for (int ch = threadIdx.x; ch < F; ch += 256) {
+    float m = -__builtin_inff();
+    int64_t am = -1;
+    for (int g = 0; g < G; ++g) {
+      int64_t row = idx[g];
+      if (row < 0) row += num_rows;
+      if (row >= 0 && row < num_rows) {
+        const float v = feat[row * F + ch];
+        if (v > m || am < 0) { m = v; am = row; }     // first maximum wins, as torch.max over the group axis
+      }
+    }
+    out[r * F + ch] = m;
+    arg[r * F + ch] = am;
+  }
+}
+
+extern "C" int regnet_gather_max_arg_f32(const float* feat, int64_t num_rows, int64_t F, const int64_t* rows, int64_t R,
+                                         int64_t G, float* out, int64_t* arg, void* stream) {
+  if (num_rows < 0 || F < 0 || R < 0 || G <= 0) return REGNET_ERR_SHAPE;
+  if (F >= (int64_t)1 << 31 || G >= (int64_t)1 << 31 || R >= (int64_t)1 << 31) return REGNET_ERR_UNSUPPORTED;
+  if (R == 0 || F == 0) return REGNET_OK;
+  if (!feat || !rows || !out || !arg) return REGNET_ERR_NULL;
+  hipLaunchKernelGGL(gather_max_arg_kernel, dim3((unsigned)R), dim3(256), 0, as_stream(stream), feat, num_rows, (int)F,
+                     rows, (int)G, out, arg);
+  REGNET_LAUNCH_CHECK();
+  return REGNET_OK;
+}
+
+// out[r] = -(x[r][0] + ... + x[r][K-1]): the gradient of the per-centre term V of a pre-multiplied first layer
+// (pn2_utils/modules.py: Y = U[nbr] - V, so dV = -sum over the K neighbours of dY).  One wave per 64 / K ... rows of K
+// contiguous floats; torch's own `neg` + 4-D `sum` took 0.78 ms for the level-2 block's 537 MB gradient (0.7 TB/s).
+__global__ __launch_bounds__(256) void rowsum_neg_kernel(const float* __restrict__ x, long long rows, int K,
+                                                        float* __restrict__ out) {
+  // K is a multiple of 4 and <= 256: K / 4 lanes per row, float4 loads
+  const int lpr = K / 4;
+  const int rows_per_block = 256 / lpr;
+  const long long r = (long long)blockIdx.x * rows_per_block + threadIdx.x / lpr;
+  const int c = threadIdx.x % lpr;
+  float s = 0.f;
+  if (r < rows && threadIdx.x < rows_per_block * lpr) {
+    const float4 v = *reinterpret_cast<const float4*>(x + r * K + 4 * c);
+    s = (v.x + v.y) + (v.z + v.w);
+  }
+  for (int off = 1; off < lpr; off <<= 1) s += __shfl_xor(s, off, 64);    // lpr is a power of two <= 64
+  if (c == 0 && r < rows && threadIdx.x < rows_per_block * lpr) out[r] = -s;
+}
+
+extern "C" int regnet_rowsum_neg_f32(const float* x, int64_t rows, int64_t K, float* out, void* stream) {
+  if (rows < 0 || K < 4 || K > 256 || (K & (K - 1))) return REGNET_ERR_SHAPE;
+  if (rows == 0) return REGNET_OK;
+  if (!x || !out) return REGNET_ERR_NULL;
+  if ((reinterpret_cast<uintptr_t>(x) & 15)) return REGNET_ERR_SHAPE;
+  const long long per_block = 256 / (K / 4);
+  const long long blocks = (rows + per_block - 1) / per_block;
+  if (blocks >= (1ll << 31)) return REGNET_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(rowsum_neg_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), x, (long long)rows, (int)K, out);
+  REGNET_LAUNCH_CHECK();
+  return REGNET_OK;
+}
+
 // ---- resampled groups ---------------------------------------------------------------------------------------------------
 // get_regiondataset.py:331-352: every (scene, centre) candidate list is resampled to exactly G entries at positions drawn
 // on the host (numpy's RNG), then the member indices and their points are gathered; a centre without candidates gets -1

@@ -28,11 +28,29 @@ from .pointnet2 import PointNet2Refine, PointNet2TwoStage
 def _pool_rows(all_feature, rows):
     """max over the G gathered rows: all_feature (B,N,F), rows (R,G) global row ids -> (R,F,1)."""
     F = all_feature.shape[2]
-    flat = all_feature.contiguous().view(-1, F)
+    flat = _contiguous_rows(all_feature)
     if flat.is_cuda and not torch.is_grad_enabled():
         return region_ops.gather_max(flat, rows).unsqueeze(-1)
+    if flat.is_cuda and hasattr(region_ops, "gather_max_train"):
+        return region_ops.gather_max_train(flat, rows).unsqueeze(-1)     # same values; the backward scatters R x F values
     # autograd path: the reference's materialised gather followed by a max over the group axis
     return flat[rows.reshape(-1)].view(rows.shape[0], rows.shape[1], F).max(dim=1)[0].unsqueeze(-1)
+
+
+_rows_cache = [None, None]
+
+
+def _contiguous_rows(all_feature):
+    """``all_feature.contiguous().view(-1, F)``, made ONCE per feature map: ScoreNet hands the map out as a transposed view
+    in training, the region head and the refine head both pool from it, and every ``.contiguous()`` is a 210 MB transpose
+    copy forward and another one backward (B = 8).  Keyed on the tensor object (weakly: the cache keeps no graph alive)."""
+    import weakref
+    ref, flat = _rows_cache
+    if ref is not None and ref() is all_feature and flat is not None:
+        return flat
+    flat = all_feature.contiguous().view(-1, all_feature.shape[2])
+    _rows_cache[0], _rows_cache[1] = weakref.ref(all_feature), (flat if flat.requires_grad else None)
+    return flat
 
 
 class GripperRegionNetwork(nn.Module):

@@ -36,6 +36,30 @@ class FarthestPointSampler(nn.Module):
         return "num_centroids={:d}".format(self.num_centroids)
 
 
+class _GroupMinus(torch.autograd.Function):
+    """Y[b,c,m,k] = U[b,c,index[b,m,k]] - V[b,c,m] (the grouping of a pre-multiplied first layer, GPU training).  Backward:
+    dU by the grouping's own scatter-add kernel, dV = -sum_k dY by one pass at HBM speed (torch's `neg` of the whole
+    (B,C,M,K) gradient followed by a 4-D `sum` took 0.78 + 0.40 ms per iteration for levels 2-3)."""
+
+    @staticmethod
+    def forward(ctx, U, V, index):
+        from .. import pn2_ext
+        Y = pn2_ext.group_points_forward(U.contiguous(), index)
+        Y -= V.unsqueeze(-1)
+        ctx.save_for_backward(index)
+        ctx.num_points = U.shape[2]
+        return Y
+
+    @staticmethod
+    def backward(ctx, dY):
+        from .. import pn2_ext, region_ops
+        (index,) = ctx.saved_tensors
+        dY = dY.contiguous()
+        dU = pn2_ext.group_points_backward(dY, index, ctx.num_points) if ctx.needs_input_grad[0] else None
+        dV = region_ops.rowsum_neg(dY, dY.shape[-1]) if ctx.needs_input_grad[1] else None
+        return dU, dV, None
+
+
 def _ball_group(radius, k, new_xyz, xyz, index=None):
     """Ball query + xyz grouping shared by the groupers: returns (index, centred group_xyz).
     group_xyz is (B,3,M,K) with the centroid subtracted in place (modules.py:41-46).
@@ -186,9 +210,7 @@ class _SetAbstraction(nn.Module):
         src = torch.cat([xyz, feature], dim=1).contiguous()                # (B, 3 + C, N): source points, not groups
         U = conv1x1_train.gemm_conv(src, W)                                # (B, C1, N)
         V = conv1x1_train.gemm_conv(new_xyz.contiguous(), W[:, :3].contiguous())   # (B, C1, M)
-        Y = _F.group_points(U, index)
-        Y -= V.unsqueeze(-1)
-        return Y
+        return _GroupMinus.apply(U, V, index)
 
     def _mlp_reduce(self, group_feature):
         """SharedMLP then the reduction over the K neighbours (modules.py:244-245)."""

@@ -90,6 +90,51 @@ def resample_groups(pc, cand, pos):
     return index, points
 
 
+class _GatherMaxFn(torch.autograd.Function):
+    """gather_max with autograd (training): the backward scatters the R x F incoming values to the rows that gave the
+    maxima, instead of the reference's materialised (R, G, F) gather, its max and their zero-filled gradients."""
+
+    @staticmethod
+    def forward(ctx, feature_rows, rows):
+        R, G = rows.shape
+        F = feature_rows.shape[1]
+        with torch.cuda.device(feature_rows.device):
+            out = torch.empty((R, F), dtype=torch.float32, device=feature_rows.device)
+            arg = torch.empty((R, F), dtype=torch.int64, device=feature_rows.device)
+            _check(_L.regnet_gather_max_arg_f32(feature_rows.data_ptr(), feature_rows.shape[0], F, rows.data_ptr(), R, G,
+                                                out.data_ptr(), arg.data_ptr(), _stream(feature_rows)), "gather_max_arg")
+        ctx.save_for_backward(arg)
+        ctx.src_shape = tuple(feature_rows.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        (arg,) = ctx.saved_tensors
+        n, F = ctx.src_shape
+        grad = torch.zeros((n * F,), dtype=dy.dtype, device=dy.device)
+        flat = (arg * F + torch.arange(F, device=arg.device).view(1, F)).reshape(-1)
+        grad.index_put_((flat.clamp_(min=0),), torch.where(arg.reshape(-1) >= 0, dy.reshape(-1), dy.new_zeros(())), accumulate=True)
+        return grad.view(n, F), None
+
+
+def gather_max_train(feature_rows, rows):
+    """``gather_max`` for tensors that need gradients (GPU): (R_all,F) contiguous float32, rows (R,G) int64 -> (R,F)."""
+    _need_f32(feature_rows, "feature_rows")
+    _need_i64(rows, "rows")
+    return _GatherMaxFn.apply(feature_rows.contiguous(), rows.contiguous())
+
+
+def rowsum_neg(x, K):
+    """-(sum over the last axis of K contiguous floats): x (..., K) contiguous float32 GPU -> x.shape[:-1]."""
+    _need_f32(x, "x")
+    x = x.contiguous()
+    rows = x.numel() // K
+    with torch.cuda.device(x.device):
+        out = torch.empty(x.shape[:-1], dtype=torch.float32, device=x.device)
+        _check(_L.regnet_rowsum_neg_f32(x.data_ptr(), rows, K, out.data_ptr(), _stream(x)), "rowsum_neg")
+    return out
+
+
 _range_flags = {}
 
 

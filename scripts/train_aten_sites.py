@@ -22,7 +22,7 @@ for _ in range(4):
     nxt = t.prefetch(pc); t.step(pc, target, records, plan=ahead); ahead = nxt
 torch.cuda.synchronize()
 n = 3
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
     for _ in range(n):
         nxt = t.prefetch(pc); t.step(pc, target, records, plan=ahead); ahead = nxt
     torch.cuda.synchronize()
@@ -32,16 +32,18 @@ for ev in prof.events():
         continue
     if any(c.name.startswith("aten::") and c.device_time > 0 for c in ev.cpu_children):
         continue                                   # count the leaf that launched the kernel
-    site = "(autograd / no package frame)"
+    site = "(backward of %s)" % ev.name if not ev.stack else "(no package frame)"
     for fr in ev.stack:
         if "regnet_for_3d_grasping_amd" in fr and "/torch/" not in fr:
             site = fr.split("regnet_for_3d_grasping_amd/")[-1]
             break
+    shapes = str(getattr(ev, "input_shapes", ""))[:60]
+    site = site + " " + shapes
     a = agg[(ev.name, site)]
     a[0] += ev.device_time; a[1] += 1
 rows = sorted(agg.items(), key=lambda kv: -kv[1][0])
 tot = sum(v[0] for v in agg.values()) / n
 print("ATen kernels: %.2f ms of device time per iteration" % (tot / 1e3))
 print("device us per iteration | calls per iteration | op | site")
-for (name, site), (tt, c) in rows[:40]:
+for (name, site), (tt, c) in rows[:70]:
     print("%10.1f %6.1f  %-30s %s" % (tt / n, c / n, name, site))

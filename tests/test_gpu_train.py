@@ -394,3 +394,47 @@ def test_early_head_backward_gives_the_same_gradients():
             # differences of large sums (DESIGN.md par. 9) -- a bias whose true gradient is ~0 carries 1e-7-level noise
             scale = float(g1[k].abs().max())
             assert float((g0[k] - g1[k]).abs().max()) <= 1e-4 * scale + 1e-6, (k, float((g0[k] - g1[k]).abs().max()), scale)
+
+
+def test_group_minus_matches_the_plain_expression():
+    """modules._GroupMinus (grouping of a pre-multiplied first layer) against group_points(U, index) - V[..., None] under
+    torch autograd: the same forward bits, dU by the same scatter-add kernel (atomic accumulation order), dV = -sum_k dY within fp32
+    reassociation of a K-term sum."""
+    from regnet_for_3d_grasping_amd.pn2_utils import function as F
+    from regnet_for_3d_grasping_amd.pn2_utils.modules import _GroupMinus
+    g = torch.Generator().manual_seed(12)
+    for (B, C, N, M, K) in [(2, 64, 300, 37, 64), (1, 40, 129, 50, 32), (2, 16, 64, 9, 4)]:
+        U = torch.randn(B, C, N, generator=g).to(DEV).requires_grad_(True)
+        V = torch.randn(B, C, M, generator=g).to(DEV).requires_grad_(True)
+        index = torch.randint(0, N, (B, M, K), generator=g).to(DEV)
+        dY = torch.randn(B, C, M, K, generator=g).to(DEV)
+        y0 = F.group_points(U, index) - V.unsqueeze(-1)
+        dU0, dV0 = torch.autograd.grad(y0, [U, V], dY)
+        y1 = _GroupMinus.apply(U, V, index)
+        dU1, dV1 = torch.autograd.grad(y1, [U, V], dY)
+        assert torch.equal(y0, y1)
+        torch.testing.assert_close(dU1, dU0, rtol=0.0, atol=2e-5)    # the scatter-add accumulates with atomics: order varies
+        torch.testing.assert_close(dV1, dV0, rtol=0.0, atol=2e-5)
+        ref = -(dY.double().sum(-1))
+        assert float((dV1.double() - ref).abs().max()) <= float((dV0.double() - ref).abs().max()) + 2e-6
+
+
+def test_gather_max_train_matches_the_materialised_gather():
+    """region_ops.gather_max_train (training twin of the pooled region feature) against the reference's expression
+    flat[rows].view(R, G, F).max(1)[0] (gripper_region_network.py:382-390), values and gradient; -1 row ids count from the
+    end as advanced indexing does; repeated rows inside a group (draws with replacement) included."""
+    from regnet_for_3d_grasping_amd import region_ops
+    g = torch.Generator().manual_seed(13)
+    for (n, F_, R, G) in [(500, 256, 40, 64), (64, 48, 7, 5), (1000, 128, 33, 256)]:
+        flat = torch.randn(n, F_, generator=g).to(DEV).requires_grad_(True)
+        rows = torch.randint(0, n, (R, G), generator=g)
+        rows[:, 1] = rows[:, 0]
+        rows[0, 2] = -1
+        rows = rows.to(DEV)
+        dy = torch.randn(R, F_, generator=g).to(DEV)
+        y0 = flat[rows.reshape(-1)].view(R, G, F_).max(dim=1)[0]
+        (g0,) = torch.autograd.grad(y0, [flat], dy)
+        y1 = region_ops.gather_max_train(flat, rows)
+        (g1,) = torch.autograd.grad(y1, [flat], dy)
+        assert torch.equal(y0, y1)
+        torch.testing.assert_close(g1, g0, rtol=0.0, atol=1e-6)
