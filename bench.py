@@ -71,6 +71,9 @@ def parse():
                          "first launch (value_no_lookahead); 0 = skip")
     ap.add_argument("--lookahead", type=int, default=3, help="batches whose region stage may be pending (pipeline depth)")
     ap.add_argument("--geometry-ahead", type=int, default=1, help="batches whose ball-query / 3-NN geometry is queued ahead of the feature stage")
+    ap.add_argument("--graphs", choices=("auto", "on", "off"), default="auto",
+                    help="replay the geometry + feature stages of a batch as hipGraphs: auto = batches of at most 3 x 25 600 "
+                         "points (launch-bound shapes; the default workload, 8 x 25 600, is not one of them)")
     ap.add_argument("--set", action="append", default=[], metavar="module.NAME=0|1",
                     help="A/B measurement only: flip a module-level switch of the package before the run, e.g. "
                          "--set fused.FP_HEAD_INTERP=0 (reported in config.switches)")
@@ -93,7 +96,7 @@ class OpTimer:
         orig = getattr(module, name)
 
         def timed(*a, **k):
-            if not self.enabled:
+            if not self.enabled or torch.cuda.is_current_stream_capturing():   # (a hipGraph capture: no timing events inside)
                 return orig(*a, **k)
             key = (name, meta_fn(*a, **k))
             n = self.calls.get(key, 0)
@@ -476,7 +479,8 @@ def main():
     # steps happens inside the timed region; the pipeline drains before the closing fence).
     pipe = pipeline.ForwardPipeline(score_net, region_net, with_region=not args.score_only, fps_streams=args.fps_streams,
                                     mlp_streams=args.mlp_streams, fps_group=args.fps_group,
-                                    first_launch_groups=args.first_launch_groups, geometry_ahead=args.geometry_ahead)
+                                    first_launch_groups=args.first_launch_groups, geometry_ahead=args.geometry_ahead,
+                                    graphs={"auto": "auto", "on": True, "off": False}[args.graphs])
 
     def run_steps(n):
         last = None
@@ -496,6 +500,7 @@ def main():
     # feature stream that is bound first -- before the pipeline's own first use of its streams -- ends up 8 % slower)
     timer.critical_streams = {m.cuda_stream for m in pipe.s_mlps}
     timer.enabled = True
+    pipe.graph_replays = 0
     t0 = time.perf_counter()
     out = run_steps(args.steps)
     fence()
@@ -504,6 +509,25 @@ def main():
     main_summary = timer.summary() if rank == 0 else None
     dt = sharding.max_over_ranks(dt, dev)
     first_launch_batches = pipe.first_launch_batches
+    graph_replays = pipe.graph_replays
+    graph_accounting_steps = 0
+    if graph_replays and rank == 0:
+        # the timed steps replayed hipGraphs: no per-launch events exist for their kernels.  The per-kernel accounting of the
+        # line comes from a short pass of the SAME launches issued one by one (graphs off), outside the timed region.
+        timer.records, timer.calls = [], {}
+        pipe_e = pipeline.ForwardPipeline(score_net, region_net, with_region=not args.score_only, fps_streams=args.fps_streams,
+                                          mlp_streams=1, fps_group=args.fps_group, graphs=False)
+        timer.critical_streams = {m.cuda_stream for m in pipe_e.s_mlps}
+        for _ in pipe_e.run((pc for _ in range(4)), max_pending_regions=args.lookahead):
+            pass
+        torch.cuda.synchronize()
+        timer.enabled = True
+        graph_accounting_steps = max(8, min(args.steps, 48))
+        for _ in pipe_e.run((pc for _ in range(graph_accounting_steps)), max_pending_regions=args.lookahead):
+            pass
+        torch.cuda.synchronize()
+        timer.enabled = False
+        main_summary = timer.summary()
 
     no_lookahead = None
     if world == 1 and args.no_lookahead_steps > 0:
@@ -573,7 +597,12 @@ def main():
         by_time = sorted(agg.items(), key=lambda kv: -kv[1][0])
         kernels = [{"op": k[0], "shape": k[1], "calls": c, "avg_ms": round(tot / c, 4), "total_ms": round(tot, 3)}
                    for k, (tot, c) in by_time]
-        fam, roofline = roofline_of(agg, args.steps, args.batch, timer.critical if timer.critical_streams is not None else None)
+        fam, roofline = roofline_of(agg, graph_accounting_steps or args.steps, args.batch,
+                                    timer.critical if timer.critical_streams is not None else None)
+        if roofline and graph_accounting_steps:
+            roofline["accounting_note"] = ("the %d timed steps replayed hipGraphs (%d feature stages); launch durations are from %d "
+                                           "extra steps outside the timed region with the same launches issued one by one"
+                                           % (args.steps, graph_replays, graph_accounting_steps))
         if roofline and roofline["kernel"] == "sa_chain_kernel":
             # the level-1 chain skips the second point tile of neighbourhoods with <= 32 members (their slots 32..63 repeat
             # slot 0): "achieved" counts the ALGORITHMIC flops (all 64 slots, what the reference multiplies); say how much of
@@ -607,6 +636,7 @@ def main():
                        # launch of the timed run); steady state: up to 2 x sampling_group_batches
                        "sampling_lookahead_batches": first_launch_batches,
                        "switches": args.set or None,
+                       "hip_graphs": bool(graph_replays),
                        "scorenet_gflop_per_scene": SCORENET_GFLOP_PER_SCENE.get(args.points),
                        "executed_gflop_per_scene": round(sum(f["units"] for f in fam.values() if f["bound"] == "mfma")
                                                          / 1e9 / max(args.steps * args.batch, 1), 2)},

@@ -76,6 +76,10 @@ def _tickets(device, n=1):
     """``n`` zeroed int32 work-queue heads for a ticket-driven chain kernel.  Carved out of a pool that is zeroed once per 256
     words ON THE STREAM THAT USES IT (a word is handed out once and never reused): one fill kernel per ~60 feature stages
     instead of one -- and its ~10 us launch gap -- in front of every chain launch."""
+    if torch.cuda.is_current_stream_capturing():
+        # inside a hipGraph capture (pipeline.StageGraphs): the word is reused by every replay, so its zero-fill is a node of
+        # the graph (memory from the graph's private pool)
+        return torch.zeros((n,), dtype=torch.int32, device=device)
     stream = torch.cuda.current_stream(device)
     key = (device.index if device.index is not None else torch.cuda.current_device(), stream.cuda_stream)
     pool = _ticket_pools.get(key)

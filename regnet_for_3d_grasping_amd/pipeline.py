@@ -59,6 +59,69 @@ def sampling_workgroups_per_scene(num_points):
     return max(1, -(-int(num_points) // SINGLE_CU_POINTS))
 
 
+GRAPH_MAX_POINTS = 3 * 25600   # graphs="auto": batches of at most this many points replay hipGraphs (they are launch-bound; at 4 x 25 600 it is a wash)
+
+
+class _StageGraphs:
+    """hipGraph replays of the geometry stage and the feature stage for ONE batch shape.
+
+    A batch of 1-4 scenes is launch-bound: its geometry + feature stages are ~75 launches (ctypes calls, torch allocations
+    and views: 0.9-1.3 ms of host time) for 1.7 ms of device time at one scene, and the interpreter is shared with the
+    host-paced region stage.  Both stages depend on the batch only through its values -- shapes, launch grids and every
+    address are fixed by (B, N) -- so each is captured once as a hipGraph over static buffers and replayed per batch:
+    65 us of host time for both (scripts/graph_probe.py), the same kernels in the same order, bit-identical results
+    (tests/test_gpu_pipeline.py).  ``slots`` sets of buffers rotate so that the geometry of batch i+1 can be written while
+    the features of batch i are read; the stage outputs are copied out of the slot (26 MB per scene, ~10 us) so that
+    results handed to the caller are never overwritten.  The level-1..3 sampling stays outside (grouped launches of
+    varying size).  Captured addresses include the packed weights: ``signature`` (parameter versions + the fused module's
+    switches) is compared at the start of every ``run`` and the graphs are dropped when it changed."""
+
+    def __init__(self, pipe, pc, ctr, signature, slots=3):
+        from . import fused
+        self.signature = signature
+        self.key = _graph_key(pc)
+        self.slots = []
+        self.next = 0
+        dev = pc.device
+        cur = torch.cuda.current_stream(dev)
+        with torch.no_grad():
+            # one eager pass first: every lazily built cache (interpolation tables, grid workspaces, LDS opt-ins) must exist
+            # BEFORE a capture, or it would be allocated from a graph's private pool and filled by replays only
+            plan = pipe._plan(pc, ctr)
+            pipe.score_net(pc, plan=plan)
+            cur.synchronize()
+            for _ in range(slots):
+                slot = {"pc": pc.clone(), "ctr": [c.clone() for c in ctr]}
+                slot["g_geo"], slot["g_feat"] = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                # thread_local: the region worker thread may allocate or synchronise while this thread captures
+                with torch.cuda.graph(slot["g_geo"], stream=pipe.s_geo, capture_error_mode="thread_local"):
+                    slot["plan"] = pipe._plan(slot["pc"], slot["ctr"])
+                old_sink, fused.TAIL_SINK = fused.TAIL_SINK, None    # no side-stream tail inside a graph
+                try:
+                    with torch.cuda.graph(slot["g_feat"], stream=pipe.s_mlp, capture_error_mode="thread_local"):
+                        slot["all_feature"], slot["score"], _ = pipe.score_net(slot["pc"], plan=slot["plan"])
+                finally:
+                    fused.TAIL_SINK = old_sink
+                slot["free"] = None     # event: the slot's last feature replay and the copies of its outputs are done
+                self.slots.append(slot)
+            torch.cuda.synchronize(dev)
+
+    def take(self):
+        slot = self.slots[self.next % len(self.slots)]
+        self.next += 1
+        return slot
+
+
+def _graph_key(pc):
+    return (tuple(pc.shape), tuple(pc.stride()), pc.dtype, pc.device.index)
+
+
+def _graph_signature(score_net):
+    from . import fused
+    switches = tuple(sorted((k, v) for k, v in vars(fused).items() if k.isupper() and isinstance(v, (bool, int, float))))
+    return (fused._signature(score_net), switches, score_net.training)
+
+
 class ForwardPipeline:
     """Software pipeline over a stream of scene batches (inference).
 
@@ -82,7 +145,7 @@ class ForwardPipeline:
     """
 
     def __init__(self, score_net, region_net, with_region=True, fps_streams=2, mlp_streams=1, fps_group=0,
-                 first_launch_groups=1, geometry_ahead=1):
+                 first_launch_groups=1, geometry_ahead=1, graphs="auto"):
         """``fps_streams``: level-1 sampling launches in flight (each ~10 ms on one CU per scene, whatever the batch
         size).  ``fps_group``: consecutive batches whose level-1 sampling shares one launch (0: as many as give 64 scenes,
         at most 8): +6 % at 8 scenes per batch, +12-15 % at 1 and 4, at the price of reading that many batches ahead.
@@ -96,8 +159,14 @@ class ForwardPipeline:
         holes with the next batch's kernels: 9.70 -> 9.14 ms per batch of 8 (824 -> 875 scenes/s) with
         ``mlp_streams=2``; 3 measured slower.  The default stays 1 because overlapping launches time-share the chip:
         a launch's duration (the quantity the roofline accounting and every profile under profiles/ is built on) then
-        depends on what the other stream happens to run, and a profiler perturbs exactly that."""
+        depends on what the other stream happens to run, and a profiler perturbs exactly that.
+        ``graphs``: replay the geometry and feature stages as hipGraphs (see _StageGraphs): ``"auto"`` for batches of at most
+        GRAPH_MAX_POINTS points (launch-bound: +45-80 % at one scene per batch), True / False to force."""
         self.score_net, self.region_net, self.with_region = score_net, region_net, with_region
+        self.graphs = graphs
+        self._stage_graphs = None         # _StageGraphs of the shape the last batches had
+        self.graph_replays = 0            # feature stages served by a replay (bench.py reports it)
+        self._graph_sig = None
         self.fps_group = int(fps_group)   # batches whose level-1 sampling shares one launch; 0 = as many as give 64 scenes (<= 8)
         self.first_launch_groups = max(1, int(first_launch_groups))
         self.geometry_ahead = max(1, int(geometry_ahead))
@@ -159,8 +228,67 @@ class ForwardPipeline:
     def _plan(self, pc, ctr):
         return self.score_net.plan(pc, ctr)
 
+    def _graphs_for(self, pc):
+        """The shape's _StageGraphs when this batch should replay graphs, else None."""
+        want = self.graphs
+        if want == "auto":
+            want = pc.shape[0] * pc.shape[1] <= GRAPH_MAX_POINTS
+        from . import fused
+        if not want or not fused.ENABLED or len(self.s_mlps) != 1 or self.score_net.training:
+            return None
+        g = self._stage_graphs
+        return g if g is not None and g.key == _graph_key(pc) else None
+
+    def _capture(self, item):
+        """Build the graphs for this batch's shape (once per shape and weight version; needs the batch's sampled
+        centroids, so it runs when the first batch reaches the geometry stage -- a device-wide synchronisation)."""
+        item["fps_done"].synchronize()
+        self._stage_graphs = None
+        if self._graph_sig is None:
+            self._graph_sig = _graph_signature(self.score_net)
+        self._stage_graphs = _StageGraphs(self, item["pc"], item["ctr"], self._graph_sig, slots=self.geometry_ahead + 2)
+
+    def _geometry_replay(self, item, graphs):
+        slot = graphs.take()
+        with torch.cuda.stream(self.s_geo), torch.no_grad():
+            self.s_geo.wait_event(item["fps_done"])
+            if slot["free"] is not None:
+                self.s_geo.wait_event(slot["free"])     # the features that last read this slot's plan and points
+            slot["pc"].copy_(item["pc"], non_blocking=True)
+            for dst, src in zip(slot["ctr"], item["ctr"]):
+                dst.copy_(src, non_blocking=True)
+            slot["g_geo"].replay()
+            done = torch.cuda.Event()
+            done.record(self.s_geo)
+        item.update(slot=slot, geo_done=done)
+        return item
+
+    def _features_replay(self, item):
+        slot = item.pop("slot")
+        s_mlp = self.s_mlp
+        self._n_featured += 1
+        self.graph_replays += 1
+        with torch.cuda.stream(s_mlp), torch.no_grad():
+            s_mlp.wait_event(item["geo_done"])
+            slot["g_feat"].replay()
+            all_feature, score = slot["all_feature"].clone(), slot["score"].clone()
+            done = torch.cuda.Event()
+            done.record(s_mlp)
+            slot["free"] = done
+        all_feature.record_stream(self.s_reg)
+        score.record_stream(self.s_reg)
+        item.update(all_feature=all_feature, score=score, mlp_done=done, tail_done=[])
+        item.pop("ctr")
+        return item
+
     def _geometry(self, item):
         from . import fused
+        graphs = self._graphs_for(item["pc"])
+        if graphs is None and self._wants_graphs(item["pc"]):
+            self._capture(item)
+            graphs = self._graphs_for(item["pc"])
+        if graphs is not None:
+            return self._geometry_replay(item, graphs)
         with torch.cuda.stream(self.s_geo), torch.no_grad():
             self.s_geo.wait_event(item["fps_done"])
             plan = self._plan(item["pc"], item["ctr"])
@@ -172,7 +300,16 @@ class ForwardPipeline:
         item.update(plan=plan, geo_done=done)
         return item
 
+    def _wants_graphs(self, pc):
+        want = self.graphs
+        if want == "auto":
+            want = pc.shape[0] * pc.shape[1] <= GRAPH_MAX_POINTS
+        from . import fused
+        return bool(want) and fused.ENABLED and len(self.s_mlps) == 1 and not self.score_net.training and pc.is_cuda
+
     def _features(self, item):
+        if "slot" in item:
+            return self._features_replay(item)
         s_mlp = self.s_mlps[self._n_featured % len(self.s_mlps)]
         self._n_featured += 1
         from . import fused
@@ -239,6 +376,9 @@ class ForwardPipeline:
         cur = torch.cuda.current_stream(self.device)
         with torch.no_grad():
             fused.prepack(self.score_net, self.region_net)   # packed-weight caches: built on `cur`, before the streams fork
+        self._graph_sig = _graph_signature(self.score_net)
+        if self._stage_graphs is not None and self._stage_graphs.signature != self._graph_sig:
+            self._stage_graphs = None                        # weights or switches changed: the captured addresses are stale
         streams = tuple(self.s_fps) + tuple(self.s_mlps) + (self.s_geo, self.s_reg)
         for s in streams:
             s.wait_stream(cur)

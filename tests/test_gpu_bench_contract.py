@@ -52,9 +52,22 @@ def test_bench_line_carries_the_round3_fields():
                "--no-lookahead-steps", "4", "--train-steps", "2"])
     assert d["config"]["sampling_lookahead_batches"] == 6          # all six batches of the run were sampled by the first launch
     assert d["value_no_lookahead"] > 0 and "fps-group 1" in d["value_no_lookahead_note"]
+    assert d["config"]["hip_graphs"] is False                       # 8 x 25 600 is not a launch-bound shape: one launch per kernel
     t = d["train"]
     assert t["scenes_per_s"] > 0 and t["ms_per_step"] > 0 and t["roofline"]["kernel"] == "tgemm_kernel"
     assert t["allreduce_ms"] is None                                # one rank: no collective
+
+
+def test_bench_small_batch_replays_graphs_and_says_so():
+    """One scene per batch: the geometry + feature stages are hipGraph replays (pipeline._StageGraphs); the line says so and
+    takes its per-kernel accounting from extra launch-by-launch steps outside the timed region."""
+    d = _line([sys.executable, "bench.py", "--batch", "1", "--steps", "12", "--warmup", "3", "--cpu-scenes", "1", "--latency-runs", "0",
+               "--no-lookahead-steps", "0", "--train-steps", "0"])
+    assert d["config"]["hip_graphs"] is True and d["config"]["batch_per_gpu"] == 1 and d["value"] > 0
+    r = d["roofline"]
+    assert "hipGraphs" in r["accounting_note"] and 0 < r["frac"] < 1 and r["kernel"]
+    p = d["parity"]
+    assert p["region_indices_equal"] is True and p["score_max_abs_err"] <= 1e-4
 
 
 def test_bench_two_ranks_over_gloo_on_one_device():

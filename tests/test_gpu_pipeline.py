@@ -46,3 +46,49 @@ def test_plan_then_forward_equals_forward():
         plan = score_net.plan(pc)
         f1, s1, _ = score_net(pc, plan=plan)
     assert torch.equal(f0, f1) and torch.equal(s0, s1)
+
+
+def _same_outputs(got, want):
+    assert len(got) == len(want)
+    for g, w in zip(got, want):
+        for key in ("score", "all_feature", "center_pc_index", "pc_group_index", "pc_group_more_index", "next_grasp"):
+            assert torch.equal(g[key], w[key]), key
+
+
+def test_stage_graphs_replay_the_same_bits_and_follow_weight_and_shape_changes():
+    """ForwardPipeline(graphs=True): the geometry and feature stages replayed as hipGraphs (pipeline._StageGraphs) give the
+    bits of the launch-by-launch pipeline; results handed out stay valid while later batches reuse the slot; a second run
+    reuses the graphs; an in-place weight update or another batch shape re-captures."""
+    from regnet_for_3d_grasping_amd import pipeline, synthetic
+    score_net, region_net = pipeline.build_models(DEV)
+    batches = [synthetic.make_batch(3300 + 10 * i, 2, 6144, device=DEV) for i in range(7)]
+    synthetic.calibrate_score_head(score_net, batches[0])
+
+    def run(pipe, items, seed=5):
+        np.random.seed(seed)
+        out = list(pipe.run(iter(items)))
+        torch.cuda.synchronize()
+        return out
+
+    eager = pipeline.ForwardPipeline(score_net, region_net, graphs=False)
+    want = run(eager, batches)
+    assert eager.graph_replays == 0
+    pipe = pipeline.ForwardPipeline(score_net, region_net, graphs=True)
+    got = run(pipe, batches)
+    assert pipe.graph_replays == len(batches)        # the capture happens in front of the first batch's geometry
+    _same_outputs(got, want)                         # (all 7 results compared AFTER the run: slots were reused 2-3 times)
+    graphs = pipe._stage_graphs
+    got = run(pipe, batches[:3])
+    assert pipe._stage_graphs is graphs and pipe.graph_replays == len(batches) + 3
+    _same_outputs(got, want[:3])
+    # in-place weight update (what an optimizer step or load_state_dict does): stale packed weights must not be replayed
+    with torch.no_grad():
+        score_net.extrat_featurePN2.sa_modules[1].mlp[1].conv.weight.mul_(1.01)
+    want2 = run(eager, batches[:3])
+    got2 = run(pipe, batches[:3])
+    assert pipe._stage_graphs is not graphs
+    assert not torch.equal(want2[0]["score"], want[0]["score"])
+    _same_outputs(got2, want2)
+    # another batch shape in the same run
+    mixed = [batches[0], batches[1][:1].contiguous(), batches[2][:1].contiguous(), batches[3]]
+    _same_outputs(run(pipe, mixed), run(eager, mixed))
