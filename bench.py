@@ -72,7 +72,7 @@ def parse():
     ap.add_argument("--lookahead", type=int, default=3, help="batches whose region stage may be pending (pipeline depth)")
     ap.add_argument("--geometry-ahead", type=int, default=1, help="batches whose ball-query / 3-NN geometry is queued ahead of the feature stage")
     ap.add_argument("--graphs", choices=("auto", "on", "off"), default="auto",
-                    help="replay the geometry + feature stages of a batch as hipGraphs: auto = batches of at most 3 x 25 600 "
+                    help="replay the geometry + feature stages of a batch as hipGraphs: auto = batches of at most 4 x 25 600 "
                          "points (launch-bound shapes; the default workload, 8 x 25 600, is not one of them)")
     ap.add_argument("--set", action="append", default=[], metavar="module.NAME=0|1",
                     help="A/B measurement only: flip a module-level switch of the package before the run, e.g. "

@@ -250,6 +250,15 @@ int regnet_gather_max_arg_f32(const float* feat, int64_t num_rows, int64_t F, co
                               float* out, int64_t* arg, void* stream);
 int regnet_rowsum_neg_f32(const float* x, int64_t rows, int64_t K, float* out, void* stream);
 
+/* regnet_gripper_frame_f32: grasp (n, ld >= 7) rows [centre | closing axis | theta | ...] -> centre (n,3), rot (n,3,3) with rows
+ * [approach; axis_y; minor_normal] -- the frame maths of get_gripper_region_transform (gripper_region_network.py:447-506) in
+ * one launch.  regnet_crop_pick: the drawn candidate positions of a box crop resolved to group positions and scene indices
+ * (index / index_inall (n,R) int64; -1 rows for grasps whose crop is invalid; :540-548). */
+int regnet_gripper_frame_f32(const float* grasp, int64_t ld, int64_t n, float* centre, float* rot, void* stream);
+int regnet_crop_pick(const int32_t* cand, int64_t G, const int64_t* pos, int64_t R, const uint8_t* valid,
+                     const int64_t* group_index, int64_t gi_stride, int64_t n, int64_t* index, int64_t* index_inall,
+                     void* stream);
+
 /* regnet_resample_groups_f32: the gather half of get_regiondataset.py:331-352 (_get_group_pc).  cand (B,Nc,cap) int32: the
  * ascending member lists of regnet_radius_group_f32; pos (B,Nc,G) int64: positions into them drawn on the host with numpy's
  * RNG stream (-1 in every slot of a centre without candidates); pc (B,N,C) rows with element strides (pb, pn), channels

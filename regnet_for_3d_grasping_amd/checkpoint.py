@@ -65,8 +65,18 @@ def reference_class_paths():
 
 def save_model(model, path):
     """``torch.save(model, path)`` as train.py:467-468 does, class paths as in the reference."""
-    with reference_class_paths():
-        torch.save(model, path)
+    # the fused forward caches packed weights on the modules (``_regnet_*`` attributes: this package's own classes and a
+    # second copy of every weight): they are not part of the model and the reference could not unpickle them
+    stripped = []
+    for m in model.modules():
+        for k in [k for k in m.__dict__ if k.startswith("_regnet_")]:
+            stripped.append((m, k, m.__dict__.pop(k)))
+    try:
+        with reference_class_paths():
+            torch.save(model, path)
+    finally:
+        for m, k, v in stripped:
+            m.__dict__[k] = v
 
 
 def load_state_dict(path, map_location="cpu"):

@@ -126,7 +126,23 @@ def _pack(conv, bn, relu, col_order=None):
 
 
 def _signature(module):
-    return tuple((t.data_ptr(), t._version) for t in list(module.parameters()) + list(module.buffers()))
+    """(address, version) of every parameter and buffer: changes with any in-place update (optimizer step, load_state_dict,
+    .to()).  The LIST of tensors is cached on the module -- walking ``parameters()`` / ``buffers()`` is ~15 us per call and a
+    forward asks ~30 times -- and re-read by ``prepack`` (every ``ForwardPipeline.run``) or ``forget``: replacing a Parameter
+    OBJECT or a sub-module of a network that has already run needs one of the two."""
+    tensors = module.__dict__.get("_regnet_sig_tensors")
+    if tensors is None:
+        tensors = list(module.parameters()) + list(module.buffers())
+        module.__dict__["_regnet_sig_tensors"] = tensors
+    return tuple((t.data_ptr(), t._version) for t in tensors)
+
+
+def forget(*nets):
+    """Drop the cached tensor lists of ``_signature`` below these networks (after structural surgery on a network)."""
+    for net in nets:
+        if net is not None:
+            for m in net.modules():
+                m.__dict__.pop("_regnet_sig_tensors", None)
 
 
 def _packed_stack(owner, stack, first_col_order=None):
@@ -818,6 +834,7 @@ def prepack(score_net, region_net=None):
     filled lazily by whichever stream first runs a block; with several feature-stage streams
     (``ForwardPipeline(mlp_streams=2)``) a second stream could then read a cache whose packing kernels, enqueued on
     the first stream, have not finished.  ``ForwardPipeline.run`` calls this before its streams start."""
+    forget(score_net, region_net)
     seg = getattr(score_net, "extrat_featurePN2", score_net)
     dev = next(seg.parameters()).device
     for sa in seg.sa_modules:

@@ -105,8 +105,9 @@ class GripperRegionNetwork(nn.Module):
             gmask = torch.nonzero(ground.view(-1, ground.shape[2])[:, -1] != -1).view(-1).to(dev)
         else:
             gmask = torch.arange(0, n, device=dev)
-        anchors = anchors[gmask].detach()
-        first_grasp, first_cls = first_grasp[gmask], first_cls[gmask]
+        if ground is not None:      # (without labels gmask is the identity: no gathers)
+            anchors, first_grasp, first_cls = anchors[gmask], first_grasp[gmask], first_cls[gmask]
+        anchors = anchors.detach()
         m, A = first_cls.shape
         rows = torch.arange(m, device=dev)
 
@@ -225,7 +226,7 @@ class GripperRegionNetwork(nn.Module):
         N_C, N_G_M = pc_group_more_index.shape[1], pc_group_more_index.shape[2]
         _, _, index_inall, gripper_mask = get_gripper_region_transform(
             pc_group_more_xyz[true_mask], pc_group_more_index.view(-1, N_G_M)[true_mask], next_grasp,
-            self.gripper_number, gripper_params)
+            self.gripper_number, gripper_params, points_too=False)
         out = [None, None, None, None, None, (None, None), (None, None), next_gt]
         if len(gripper_mask) >= 2:
             scene = torch.arange(B, device=true_mask.device).view(-1, 1).repeat(1, N_C).view(-1)[true_mask]
@@ -322,7 +323,7 @@ def _half_extent(value, n, device):
     return torch.full((n,), value / 2, dtype=torch.float32, device=device)
 
 
-def get_gripper_region_transform(group_points, group_index, grasp, region_num, gripper_params):
+def get_gripper_region_transform(group_points, group_index, grasp, region_num, gripper_params, points_too=True):
     """Points of every group that fall inside the predicted gripper's closing box, resampled to
     ``region_num`` per grasp (gripper_region_network.py:436-550).
 
@@ -330,25 +331,33 @@ def get_gripper_region_transform(group_points, group_index, grasp, region_num, g
     gripper_pc (n,region_num,C) int64 (the reference's truncating ``torch.full(..., -1)`` quirk),
     gripper_pc_index (n,region_num), gripper_pc_index_inall (n,region_num), valid grasp ids.
     A grasp is valid when more than 5 points are in the box; sampling is without replacement
-    when more than ``region_num`` candidates exist, else with replacement."""
+    when more than ``region_num`` candidates exist, else with replacement.
+    ``points_too=False`` (the network's own call, which uses the scene indices only): the first two results are None."""
     widths, height, depths = gripper_params
     n, G, C = group_points.shape
     dev = group_points.device
-    center, rot = gripper_frame(grasp.to(dev))
+    native = group_points.is_cuda and grasp.dtype == torch.float32
+    center, rot = region_ops.gripper_frame(grasp.to(dev)) if native else gripper_frame(grasp.to(dev))
     xlim, ylim = _half_extent(depths, n, dev), _half_extent(widths, n, dev)
     cand, count = region_ops.box_candidates(group_points, center, rot, xlim, ylim, height / 2)
 
     # numpy-stream-compatible draws in grasp order, on the device (no synchronisation):
     # > region_num candidates: without replacement; 6..region_num: with replacement; <= 5: invalid
     from . import get_regiondataset as _grd
+    valid_ids = None
     if _grd.DEVICE_DRAWS and count.is_cuda:
         pos_t, valid_t = np_random.choice_rows_device(count.int(), region_num, 1, G)
     else:
         np_random.flush()
         pos, valid = np_random.choice_rows(count.cpu().numpy(), region_num, 1)
         pos_t, valid_t = torch.from_numpy(pos).to(dev), torch.from_numpy(valid).to(dev)
-    valid_ids = torch.nonzero(valid_t).view(-1)     # data-dependent length: the one synchronisation of the crop
+        valid_ids = torch.from_numpy(np.nonzero(valid)[0]).to(dev)    # (the host knows which crops are valid: no device nonzero)
+    if valid_ids is None:
+        valid_ids = torch.nonzero(valid_t).view(-1)     # data-dependent length: the one synchronisation of the crop
 
+    if native and not points_too and group_index.dtype == torch.int64:
+        _, index_inall = region_ops.crop_pick(cand, pos_t, valid_t, group_index)
+        return None, None, index_inall, valid_ids
     # positions inside the group; rows without a valid crop hold unwritten candidate slots -> 0
     index = torch.where(valid_t.view(n, 1), torch.gather(cand, 1, pos_t).long(), torch.zeros_like(pos_t))
     index_inall = torch.gather(group_index.long(), 1, index)

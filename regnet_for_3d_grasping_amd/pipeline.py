@@ -59,7 +59,7 @@ def sampling_workgroups_per_scene(num_points):
     return max(1, -(-int(num_points) // SINGLE_CU_POINTS))
 
 
-GRAPH_MAX_POINTS = 3 * 25600   # graphs="auto": batches of at most this many points replay hipGraphs (they are launch-bound; at 4 x 25 600 it is a wash)
+GRAPH_MAX_POINTS = 4 * 25600   # graphs="auto": batches of at most this many points replay hipGraphs (launch-bound shapes)
 
 
 class _StageGraphs:
@@ -161,7 +161,7 @@ class ForwardPipeline:
         a launch's duration (the quantity the roofline accounting and every profile under profiles/ is built on) then
         depends on what the other stream happens to run, and a profiler perturbs exactly that.
         ``graphs``: replay the geometry and feature stages as hipGraphs (see _StageGraphs): ``"auto"`` for batches of at most
-        GRAPH_MAX_POINTS points (launch-bound: +45-80 % at one scene per batch), True / False to force."""
+        GRAPH_MAX_POINTS points (launch-bound: +40 % at one scene per batch, steadier at 3-4), True / False to force."""
         self.score_net, self.region_net, self.with_region = score_net, region_net, with_region
         self.graphs = graphs
         self._stage_graphs = None         # _StageGraphs of the shape the last batches had

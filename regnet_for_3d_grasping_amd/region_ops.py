@@ -174,6 +174,35 @@ def box_candidates(group_points, centre, rot, xlim, ylim, zlim):
     return cand, count
 
 
+def gripper_frame(grasp):
+    """grasp (n, >= 7) float32 GPU -> centre (n,3), rot (n,3,3) with rows [approach; axis_y; minor_normal]."""
+    _need_f32(grasp, "grasp")
+    g = grasp if grasp.stride(1) == 1 else grasp.contiguous()
+    n = g.shape[0]
+    with torch.cuda.device(g.device):
+        centre = torch.empty((n, 3), dtype=torch.float32, device=g.device)
+        rot = torch.empty((n, 3, 3), dtype=torch.float32, device=g.device)
+        _check(_L.regnet_gripper_frame_f32(g.data_ptr(), g.stride(0) if n else 7, n, centre.data_ptr(), rot.data_ptr(),
+                                           _stream(g)), "gripper_frame")
+    return centre, rot
+
+
+def crop_pick(cand, pos, valid, group_index):
+    """cand (n,G) int32, pos (n,R) int64, valid (n) bool, group_index (n,G) int64 -> index, index_inall (n,R) int64."""
+    n, G = cand.shape
+    R = pos.shape[1]
+    cand, pos = cand.contiguous(), pos.contiguous()
+    valid8 = valid.contiguous().view(torch.uint8)
+    gi = group_index if group_index.stride(1) == 1 else group_index.contiguous()
+    _need_i64(gi, "group_index")
+    with torch.cuda.device(cand.device):
+        index = torch.empty((n, R), dtype=torch.int64, device=cand.device)
+        index_inall = torch.empty((n, R), dtype=torch.int64, device=cand.device)
+        _check(_L.regnet_crop_pick(cand.data_ptr(), G, pos.data_ptr(), R, valid8.data_ptr(), gi.data_ptr(),
+                                   gi.stride(0) if n else G, n, index.data_ptr(), index_inall.data_ptr(), _stream(cand)), "crop_pick")
+    return index, index_inall
+
+
 def gather_max(feature_rows, rows):
     """feature_rows (R_all,F) contiguous, rows (R,G) int64 global row ids -> (R,F) max over G."""
     _need_f32(feature_rows, "feature_rows")

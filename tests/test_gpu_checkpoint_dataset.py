@@ -157,3 +157,32 @@ def test_dataset_item_on_the_gpu_equals_the_host_item(tmp_path):
             np.testing.assert_allclose(score[k].cpu().numpy(), w[1], rtol=0, atol=1e-6)
             np.testing.assert_array_equal(label_g[k].cpu().numpy(), w[2])
             assert paths[k] == w[3]
+
+
+def test_model_saved_after_a_fused_forward_holds_no_package_objects(tmp_path):
+    """checkpoint.save_model of a network that has already run the fused forward (packed-weight caches and signature lists
+    hang on its modules then): the pickle still names only the reference's class paths, the caches survive the save, and the
+    file is not inflated by a second copy of the weights."""
+    import pickletools
+    import zipfile
+    from regnet_for_3d_grasping_amd import checkpoint, pipeline, synthetic
+    score_net, region_net = pipeline.build_models(DEV)
+    pc = synthetic.make_batch(4100, 1, 6144, device=DEV)
+    np.random.seed(4)
+    want = pipeline.forward_scenes(score_net, region_net, pc)
+    assert any(k.startswith("_regnet_") for m in score_net.modules() for k in m.__dict__)
+    sizes = []
+    for net, name in ((score_net, "score_0.model"), (region_net, "region_0.model")):
+        path = os.path.join(str(tmp_path), name)
+        checkpoint.save_model(net, path)
+        with zipfile.ZipFile(path) as z:
+            data = z.read([n for n in z.namelist() if n.endswith("data.pkl")][0])
+        strings = [arg for op, arg, _ in pickletools.genops(data) if isinstance(arg, str)]
+        assert not any("regnet_for_3d_grasping_amd" in s for s in strings)
+        sizes.append((os.path.getsize(path), sum(v.numel() * v.element_size() for v in net.state_dict().values())))
+    for on_disk, state in sizes:
+        assert on_disk < 1.2 * state + 1_000_000
+    assert any(k.startswith("_regnet_") for m in score_net.modules() for k in m.__dict__)     # caches restored
+    np.random.seed(4)
+    got = pipeline.forward_scenes(score_net, region_net, pc)
+    assert torch.equal(got["score"], want["score"]) and torch.equal(got["next_grasp"], want["next_grasp"])

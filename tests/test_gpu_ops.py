@@ -470,3 +470,41 @@ def test_fps_small_scene_kernels_deterministic_under_load():
         got = pn2_ext.farthest_point_sample(x, M)
         assert torch.equal(got.cpu(), want), "repeat %d differs from the oracle" % rep
     torch.cuda.synchronize()
+
+
+def test_gripper_frame_and_crop_pick_match_the_torch_expressions():
+    """region_ops.gripper_frame (one launch) against gripper_region_network.gripper_frame (the reference's frame maths as ~35
+    torch launches: gripper_region_network.py:447-506) incl. zero-axis fallbacks, and region_ops.crop_pick against the
+    gather / where expressions of get_gripper_region_transform (:540-548)."""
+    from regnet_for_3d_grasping_amd import region_ops
+    from regnet_for_3d_grasping_amd.gripper_region_network import gripper_frame
+    g = torch.Generator().manual_seed(21)
+    grasp = torch.randn(700, 10, generator=g)
+    grasp[:, 6] = (torch.rand(700, generator=g) - 0.5) * 6.5
+    grasp[0, 3:6] = 0.0                                   # zero closing axis -> fallback [0, 1, 0]
+    grasp[1, 3:6] = torch.tensor([0.0, 0.0, 1.0])         # axis_x degenerate -> fallback [1, 0, 0]
+    grasp[2, 3:6] = torch.tensor([0.0, 0.0, -2.0])
+    grasp = grasp.to(DEV)
+    c0, r0 = gripper_frame(grasp)
+    c1, r1 = region_ops.gripper_frame(grasp)
+    assert torch.equal(c0, c1)
+    torch.testing.assert_close(r1, r0, rtol=0.0, atol=5e-7)      # (torch's norm / bmm may contract; this kernel does not)
+    assert torch.isfinite(r1).all()
+    c2, r2 = region_ops.gripper_frame(grasp[:, :8][5:300])       # strided rows
+    assert torch.equal(c2, c1[5:300]) and torch.equal(r2, r1[5:300])
+
+    n, G, R = 300, 1024, 64
+    count = torch.randint(0, G + 1, (n,), generator=g)
+    cand = torch.full((n, G), 12345, dtype=torch.int32)          # slots beyond count: never-written garbage
+    for i in range(n):
+        cand[i, :count[i]] = torch.sort(torch.randperm(G, generator=g)[:count[i]])[0].int()
+    valid = count > 5
+    pos = torch.stack([torch.randint(0, max(int(count[i]), 1), (R,), generator=g) for i in range(n)])
+    gi = torch.randint(0, 25600, (n, G), generator=g)
+    cand, valid, pos, gi = cand.to(DEV), valid.to(DEV), pos.to(DEV), gi.to(DEV)
+    index = torch.where(valid.view(n, 1), torch.gather(cand, 1, pos).long(), torch.zeros_like(pos))
+    inall = torch.gather(gi, 1, index)
+    minus1 = torch.full((1, 1), -1, dtype=torch.int64, device=DEV)
+    index, inall = torch.where(valid.view(n, 1), index, minus1), torch.where(valid.view(n, 1), inall, minus1)
+    i1, a1 = region_ops.crop_pick(cand, pos, valid, gi)
+    assert torch.equal(i1, index) and torch.equal(a1, inall)
