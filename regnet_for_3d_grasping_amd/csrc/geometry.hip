@@ -215,7 +215,47 @@ __device__ __forceinline__ float dist_at(const float (&d)[PPT], int s) {  // reg
   return v;
 }
 
-template <int PPT>
+// max(a, b) / median(a, b, c) for non-NaN operands as ONE instruction each
+__device__ __forceinline__ float vmax_f32(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float vmed3_f32(float a, float b, float c) {
+  float r;
+  asm("v_med3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+// maximum over the lane's 16-lane DPP row, left in every lane of the row
+__device__ __forceinline__ float row_max_f32(float v) {
+  DPP_MAX_STEP(v, 0xB1);
+  DPP_MAX_STEP(v, 0x4E);
+  DPP_MAX_STEP(v, 0x141);
+  DPP_MAX_STEP(v, 0x140);
+  return v;
+}
+__device__ __forceinline__ float readlane_f32(float v, int lane) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+
+#ifndef FPS_PICKS
+#define FPS_PICKS 4   // picks one round of fps_sorted_kernel may emit (1: the one-pick-per-round loop of rounds 1-2)
+#endif
+
+// KP > 1 -- SEVERAL PICKS PER ROUND, exactly.  Furthest point sampling is 5119 DEPENDENT argmax rounds, but the dependence is
+// local: the point picked in round i only lowers the running distance of points closer to it than their current value.  If
+// the runner-up q2 of round i's argmax is not one of them (|q2 - p1|^2 >= dist[q2]) it keeps its value while nothing else
+// can rise, so it IS round i+1's argmax -- provided it beats everything else strictly (ties go to the exact path).  One
+// round therefore (1) updates the distances against ALL centroids accepted in the previous round, (2) keeps, per 16-lane row of
+// the workgroup (400 spatially compact points), the row's best point and an upper bound v2 on every OTHER point of the row
+// (the other lanes' maxima and the owner lane's own second-best), (3) lets wave 0 extract the best rows in order and accept
+// candidate j while  v_j > v_(j+1),  v_j > max(v2 of the rows extracted so far)  and  |c_j - a|^2 >= v_j for every centroid a
+// accepted before it in this round -- exactly the conditions under which c_j is the unique maximum of the updated field.
+// Anything else (equal maxima anywhere near the top, all distances zero) takes the one-pick path with the reference's tie
+// order, so the output is bit-identical to the one-pick kernel by construction; on the synthetic scenes 3.7 of 4 candidates are
+// accepted per round (5 of 6, 5.9 of 8).  The accepted centroids' coordinates travel through LDS with the candidate
+// records: no global load in the round.
+template <int PPT, int KP>
 __global__ __launch_bounds__(1024) void fps_sorted_kernel(const float* __restrict__ xyz, int64_t sb, int64_t sc,
                                                           int64_t sn, int N, int M, int rb_log2,
                                                           int64_t* __restrict__ index) {
@@ -347,6 +387,161 @@ __global__ __launch_bounds__(1024) void fps_sorted_kernel(const float* __restric
   const float R = sqrtf(r2) * 1.0001f + 1e-12f;         // conservative cluster radius
   float tmax = 0.f;
   float thr = has_points ? __builtin_inff() : -1.f;      // update needed while |q - c|^2 < thr
+
+  if constexpr (KP > 1) {
+    __shared__ float4 rrec_a[64];      // per row: (best value, bound on every other point of the row, best point's x, y)
+    __shared__ float2 rrec_b[64];      //          (z, sorted position of the best point)
+    __shared__ float4 accb[KP];        // centroids accepted in the last round: (x, y, z, original index)
+    __shared__ int acc_n;              // how many; 0 = "take the exact one-pick path"
+    __shared__ float fb_mx;            // the block maximum, for that path
+    if (tid == 0) {
+      accb[0] = make_float4(base[0], base[sc], base[2 * sc], __int_as_float(0));
+      acc_n = 1;
+    }
+    if (tid < 64) {
+      rrec_a[tid] = make_float4(-1.f, -1.f, 0.f, 0.f);
+      rrec_b[tid] = make_float2(0.f, 0.f);
+    }
+    __syncthreads();
+    int i = 1, last = 0;
+#if FPS_ABLATE == 9
+    const int tstamp_tid = 0;
+    unsigned long long tprev = __builtin_readcyclecounter();
+#endif
+    while (i < M) {
+      FPS_T(0);
+#if FPS_ABLATE == 9
+      if (blockIdx.x == 0 && tid == 0) atomicAdd(&fps_dbg[7], 1ull);
+#endif
+      const int n = __builtin_amdgcn_readfirstlane(acc_n);
+      bool scanned = false;
+      for (int c = 0; c < n; ++c) {
+        const float4 a = accb[c];
+        const float cx = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a.x)));
+        const float cy = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a.y)));
+        const float cz = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a.z)));
+        const bool need = sqdist3(qx, qy, qz, cx, cy, cz) < thr;
+        if (__ballot(need) != 0ull) {
+#pragma unroll
+          for (int s = 0; s < PPT; ++s) dist[s] = vmin_f32(dist[s], sqdist3(px[s], py[s], pz[s], cx, cy, cz));
+          scanned = true;
+        }
+      }
+      FPS_T(1);
+      if (scanned) {   // wave-uniform: this wave's rows get new records
+        float t1 = dist[0], t2 = -1.f;
+#pragma unroll
+        for (int s = 1; s < PPT; ++s) {
+          t2 = vmed3_f32(t1, t2, dist[s]);      // second largest so far (t1 >= t2)
+          t1 = vmax_f32(t1, dist[s]);
+        }
+        tmax = t1;
+        const float reach = R + sqrtf(fmaxf(t1, 0.f)) * 1.0001f;
+        thr = has_points ? reach * reach * 1.0001f + 1e-30f : -1.f;
+        float sx = px[0], sy = py[0], sz = pz[0];
+        int slot = 0;
+#pragma unroll
+        for (int s = 1; s < PPT; ++s) {
+          const bool hit = dist[s] == t1;
+          sx = hit ? px[s] : sx;
+          sy = hit ? py[s] : sy;
+          sz = hit ? pz[s] : sz;
+          slot = hit ? s : slot;
+        }
+        const float rmax = row_max_f32(t1);
+        const bool hit = t1 == rmax;
+        const unsigned seg = (unsigned)(__ballot(hit) >> (lane & 48)) & 0xffffu;
+        const bool owner = hit && (seg & ((1u << (lane & 15)) - 1u)) == 0u;     // the row's first lane holding its maximum
+        const float r2 = row_max_f32(owner ? t2 : t1);    // everything in the row but the owner's best point
+        if (owner) {
+          const int row = wave * 4 + (lane >> 4);
+          rrec_a[row] = make_float4(rmax, r2, sx, sy);
+          rrec_b[row] = make_float2(sz, __int_as_float(tid * PPT + slot));
+        }
+      }
+      FPS_T(2);
+      __syncthreads();
+      FPS_T(3);
+      if (wave == 0) {
+        const float4 ra = rrec_a[lane];
+        const float2 rb = rrec_b[lane];
+        float v = ra.x;
+        const float m0 = wave_max_f32(v);
+        unsigned long long mk = __ballot(v == m0);
+        int lj = __builtin_amdgcn_readfirstlane(__ffsll((long long)mk) - 1);
+        float bmax = readlane_f32(ra.y, lj);
+        bool ok = m0 > 0.f && __popcll(mk) == 1 && m0 > bmax;
+        v = lane == lj ? -2.f : v;
+        float mnext = wave_max_f32(v);
+        ok = ok && m0 > mnext;
+        int cnt = 0;
+        float ax = 0.f, ay = 0.f, az = 0.f;
+        int aq = 0;                      // lane t < cnt: the t-th centroid accepted in this round
+        if (ok) {
+          float mj = m0;
+          for (;;) {
+            const float cjx = readlane_f32(ra.z, lj), cjy = readlane_f32(ra.w, lj), cjz = readlane_f32(rb.x, lj);
+            const int cq = __builtin_amdgcn_readlane(__float_as_int(rb.y), lj);
+            if (cnt > 0) {               // is the candidate untouched by the centroids accepted before it?
+              const float d = sqdist3(cjx, cjy, cjz, ax, ay, az);
+              if (__ballot(lane < cnt && d < mj) != 0ull) break;
+            }
+            if (lane == cnt) { ax = cjx; ay = cjy; az = cjz; aq = cq; }
+            ++cnt;
+            if (cnt == KP || i + cnt >= M) break;
+            mj = mnext;
+            if (!(mj > 0.f)) break;
+            mk = __ballot(v == mj);
+            if (__popcll(mk) != 1) break;
+            lj = __builtin_amdgcn_readfirstlane(__ffsll((long long)mk) - 1);
+            bmax = fmaxf(bmax, readlane_f32(ra.y, lj));
+            v = lane == lj ? -2.f : v;
+            mnext = wave_max_f32(v);
+            if (!(mj > mnext && mj > bmax)) break;
+          }
+        }
+        if (lane < cnt) {
+          const int idx = (int)perm[aq];
+          accb[lane] = make_float4(ax, ay, az, __int_as_float(idx));
+          out[i + lane] = idx;
+        }
+        if (lane == 0) { acc_n = cnt; fb_mx = m0; }
+      }
+      FPS_T(4);
+      __syncthreads();
+      FPS_T(5);
+      const int got = __builtin_amdgcn_readfirstlane(acc_n);
+      if (got > 0) {
+        last = __builtin_amdgcn_readfirstlane(__float_as_int(accb[got - 1].w));
+        i += got;
+        continue;
+      }
+      // ---- exact one-pick path (equal maxima / all distances zero): the reference's tie order through the keys ----------
+      const float mx = fb_mx;
+      if (mx > 0.f && tmax == mx) {
+        unsigned kmin = 0xffffffffu;
+#pragma unroll     // (static slots: a rolled loop would make the compiler keep a scratch copy of dist[] alive in the hot loop)
+        for (int s = 0; s < PPT; ++s)
+          if (dist[s] == mx) kmin = min(kmin, fps_key((int)perm[tid * PPT + s], rb_log2));
+        atomicMin(&win_key[0], kmin);
+      }
+      __syncthreads();
+      const unsigned key = win_key[0];
+      const int cur1 = key != 0xffffffffu ? fps_unkey(key, rb_log2) : last;   // all distances 0: the reference repeats cur
+      __syncthreads();
+      if (tid == 0) {
+        win_key[0] = 0xffffffffu;
+        accb[0] = make_float4(base[(int64_t)cur1 * sn], base[sc + (int64_t)cur1 * sn], base[2 * sc + (int64_t)cur1 * sn],
+                              __int_as_float(cur1));
+        acc_n = 1;
+        out[i] = cur1;
+      }
+      last = cur1;
+      i += 1;
+      __syncthreads();
+    }
+    return;
+  }
 
   int cur = 0;
 #if FPS_ABLATE == 9
@@ -667,8 +862,8 @@ extern "C" int64_t regnet_fps_workspace_bytes(int64_t B, int64_t N, int64_t M) {
   hipLaunchKernelGGL((fps_resident_kernel<T, PPT>), dim3((unsigned)B), dim3(T), 0, st, xyz, sb, sc, sn, \
                      (int)N, (int)M, rbl, index)
 
-#define FPS_SORTED_CASE(PPT)                                                                          \
-  hipLaunchKernelGGL((fps_sorted_kernel<PPT>), dim3((unsigned)B), dim3(1024), 0, st, xyz, sb, sc, sn, \
+#define FPS_SORTED_CASE(PPT)                                                                                     \
+  hipLaunchKernelGGL((fps_sorted_kernel<PPT, FPS_PICKS>), dim3((unsigned)B), dim3(1024), 0, st, xyz, sb, sc, sn, \
                      (int)N, (int)M, rbl, index)
 
 extern "C" int regnet_fps_f32(const float* xyz, int64_t sb, int64_t sc, int64_t sn, int64_t B, int64_t N, int64_t M,

@@ -33,6 +33,12 @@ int main(int argc, char** argv) {
   hipMemcpyFromSymbol(dbg, HIP_SYMBOL(fps_dbg), sizeof(dbg));
   const char* names[8] = {"loop-top(after unkey/store)", "centroid load+test", "scan", "wave reduce+lds write", "barrier1", "read partials+stage2", "barrier2", ""};
   double rounds = 4.0 * (M - 1);
+#if FPS_PICKS > 1
+  const char* names2[8] = {"after barrier 2 -> loop top", "centroid tests + scans", "top-2 / slot / row records", "barrier 1", "selection + acceptance (wave 0)", "barrier 2", "", ""};
+  for (int k = 0; k < 8; ++k) names[k] = names2[k];
+  rounds = (double)dbg[7];
+  printf("  %.0f rounds for %d picks x 4 launches: %.2f picks per round\n", rounds, M - 1, 4.0 * (M - 1) / rounds);
+#endif
   for (int k = 0; k < 7; ++k) printf("  phase %d %-28s %8.1f cycles/round (thread 0 of block 0)\n", k, names[k], dbg[k] / rounds);
 #endif
   printf("ABLATE=%d N=%d M=%d: %.3f ms  %.3f us/round  checksum %lld\n", FPS_ABLATE, N, M, ms / 3, ms / 3 * 1e3 / (M - 1), cs);
