@@ -664,6 +664,355 @@ __global__ __launch_bounds__(1024) void fps_sorted_kernel(const float* __restric
   }
 }
 
+// ---- cluster layout -----------------------------------------------------------------------------------------------------
+// fps_sorted_kernel prunes per WAVE: a wave whose 1600 spatially compact points might be touched by a centroid updates all 25
+// of its slots (225 instructions), although the centroid changes a handful of points -- and with several centroids per round
+// the workgroup is bound by the VALU issue rate of its one CU (~9 800 wave-instructions per round at 8 candidates, 64 % of them
+// such scans; scripts/ablate/fps_ablate.cpp).  Here the pruning unit is what the hardware executes as a unit: ONE slot of ONE
+// wave = a CLUSTER of 64 consecutive points of the Morton order (cluster g lives in slot g / 16 of wave g % 16: neighbouring
+// clusters sit in different waves).  Lane s of a wave keeps the bounding sphere and the current maximum of the wave's cluster
+// s, so one vector comparison tests a centroid against all 25 clusters of the wave; a flagged cluster costs 9 instructions for
+// the distances plus two wave reductions for its record (best value, bound on the rest, the best point's coordinates straight
+// from the slot's registers -- no search), and ~11 of the 400 clusters are flagged per centroid.  Wave 0 folds the 400 records
+// into 64 lane records and runs the ordered acceptance of fps_sorted_kernel<.., KP> on them.  Same picks, bit for bit.
+__device__ __forceinline__ float wave_min_f32(float v) { return -wave_max_f32(-v); }
+
+// wave maximum of non-NaN values with one instruction per DPP step (fmaxf() costs a canonicalising v_max and two moves per
+// step); the s_nop covers the VALU-write -> DPP-read hazard the assembler does not see inside inline asm
+__device__ __forceinline__ float wave_max_fast(float v) {
+  asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1"
+      : "+v"(v));
+  const int b = __builtin_bit_cast(int, v);
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0));
+  const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32));
+  const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+  return vmax_f32(vmax_f32(r0, r1), vmax_f32(r2, r3));
+}
+
+template <int PPT>
+__device__ __forceinline__ void fps_morton_perm(const float* __restrict__ base, int64_t sc, int64_t sn, int N, unsigned* perm,
+                                                unsigned* hist, float (*red)[16], unsigned* wsum) {
+  // counting sort of the points by the Morton code of a 16^3 grid over the bounding box: perm[sorted position] = original index
+  constexpr int T = 1024, W = 16, CELLS = 4096;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
+  float hi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+  float px[PPT], py[PPT], pz[PPT];
+#pragma unroll
+  for (int s = 0; s < PPT; ++s) {
+    const int j = s * T + tid;
+    px[s] = py[s] = pz[s] = 0.f;
+    if (j < N) {
+      px[s] = base[(int64_t)j * sn];
+      py[s] = base[sc + (int64_t)j * sn];
+      pz[s] = base[2 * sc + (int64_t)j * sn];
+      lo[0] = fminf(lo[0], px[s]); hi[0] = fmaxf(hi[0], px[s]);
+      lo[1] = fminf(lo[1], py[s]); hi[1] = fmaxf(hi[1], py[s]);
+      lo[2] = fminf(lo[2], pz[s]); hi[2] = fmaxf(hi[2], pz[s]);
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      lo[a] = fminf(lo[a], __shfl_xor(lo[a], off, 64));
+      hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], off, 64));
+    }
+    if (lane == 0) { red[a][wave] = lo[a]; red[3 + a][wave] = hi[a]; }
+  }
+  for (int c = tid; c < CELLS; c += T) hist[c] = 0;
+  __syncthreads();
+  float scale[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    float l = red[a][0], h = red[3 + a][0];
+#pragma unroll
+    for (int w = 1; w < W; ++w) { l = fminf(l, red[a][w]); h = fmaxf(h, red[3 + a][w]); }
+    lo[a] = l;
+    const float ext = h - l;
+    scale[a] = ext > 0.f ? 16.0f / ext : 0.f;
+  }
+  unsigned short cell[PPT], rank[PPT];
+#pragma unroll
+  for (int s = 0; s < PPT; ++s) {
+    const int j = s * T + tid;
+    cell[s] = 0; rank[s] = 0;
+    if (j < N) {
+      const unsigned qx = min(15u, (unsigned)((px[s] - lo[0]) * scale[0]));
+      const unsigned qy = min(15u, (unsigned)((py[s] - lo[1]) * scale[1]));
+      const unsigned qz = min(15u, (unsigned)((pz[s] - lo[2]) * scale[2]));
+      const unsigned c = spread4(qx) | (spread4(qy) << 1) | (spread4(qz) << 2);
+      cell[s] = (unsigned short)c;
+      rank[s] = (unsigned short)atomicAdd(&hist[c], 1u);
+    }
+  }
+  __syncthreads();
+  {
+    unsigned h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
+    const unsigned local = h0 + h1 + h2 + h3;
+    unsigned incl = local;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const unsigned o = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += o;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    unsigned wbase = 0;
+#pragma unroll
+    for (int w = 0; w < W; ++w) wbase += (w < wave) ? wsum[w] : 0u;
+    unsigned o = wbase + incl - local;
+    hist[4 * tid] = o; o += h0;
+    hist[4 * tid + 1] = o; o += h1;
+    hist[4 * tid + 2] = o; o += h2;
+    hist[4 * tid + 3] = o;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < PPT; ++s) {
+    const int j = s * T + tid;
+    if (j < N) perm[hist[cell[s]] + rank[s]] = (unsigned)j;
+  }
+  __threadfence_block();   // perm may live in global memory (read back by other waves of this workgroup)
+  __syncthreads();
+}
+
+// The per-slot state is 25 x 4 NAMED scalars, not arrays: with arrays the compiler sinks the identical stores of the 25 switch
+// cases into one indexed store, turns the arrays into 16-/25-register tuples and spills them (700 spill instructions).
+#define FPS_SLOTS(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) \
+  X(19) X(20) X(21) X(22) X(23) X(24)
+#define FPS_SLOT_DECL(S) float px##S = 0.f, py##S = 0.f, dist##S = -1.f;   // z lives in LDS (pzl): 128 registers per lane
+// load slot S (sorted position (S * 16 + wave) * 64 + lane) and give lane S the bounding sphere of the wave's cluster S
+#define FPS_SLOT_LOAD(S)                                                                                               \
+  if constexpr (S < PPT) {                                                                                             \
+    const int q = (S * 16 + wave) * 64 + lane;                                                                         \
+    const bool valid = q < N;                                                                                          \
+    float pz_ = 0.f;                                                                                                   \
+    if (valid) {                                                                                                       \
+      const int64_t j = perm[q];                                                                                       \
+      px##S = base[j * sn];                                                                                            \
+      py##S = base[sc + j * sn];                                                                                       \
+      pz_ = base[2 * sc + j * sn];                                                                                     \
+      dist##S = __builtin_inff();                                                                                      \
+    }                                                                                                                  \
+    pzl[q] = pz_;                                                                                                      \
+    const float inf = __builtin_inff();                                                                                \
+    const float lx = wave_min_f32(valid ? px##S : inf), hx = wave_max_f32(valid ? px##S : -inf);                       \
+    const float ly = wave_min_f32(valid ? py##S : inf), hy = wave_max_f32(valid ? py##S : -inf);                       \
+    const float lz = wave_min_f32(valid ? pz_ : inf), hz = wave_max_f32(valid ? pz_ : -inf);                           \
+    const bool any = __ballot(valid) != 0ull;                                                                          \
+    const float mx_ = 0.5f * (lx + hx), my_ = 0.5f * (ly + hy), mz_ = 0.5f * (lz + hz);                                \
+    const float r2 = wave_max_f32(valid ? sqdist3(px##S, py##S, pz_, mx_, my_, mz_) : 0.f);                            \
+    if (lane == S && any) {                                                                                            \
+      cqx = mx_; cqy = my_; cqz = mz_;                                                                                 \
+      cR = sqrtf(r2) * 1.0001f + 1e-12f; /* conservative cluster radius */                                             \
+      cthr = __builtin_inff();           /* update needed while |q - c|^2 < cthr */                                    \
+    }                                                                                                                  \
+  }
+// one flagged cluster: distances, then (if any changed) the cluster's record and its maximum for the sphere test
+#define FPS_CLUSTER_UPDATE(S)                                                                                          \
+  case S:                                                                                                              \
+    if constexpr (S < PPT) {                                                                                           \
+      const float od = dist##S;                                                                                        \
+      float cx_ = cx, cy_ = cy, cz_ = cz; /* opaque: or all 25 slots' distances are hoisted in front of the switch, */  \
+      int t_ = tid;                       /* and 25 x 3 loop-invariant addresses / values live in registers         */  \
+      asm volatile("" : "+v"(cx_), "+v"(cy_), "+v"(cz_), "+v"(t_));                                                    \
+      const float pz_ = pzl[S * 1024 + t_];                                                                            \
+      const float nd = vmin_f32(od, sqdist3(px##S, py##S, pz_, cx_, cy_, cz_));                                        \
+      dist##S = nd;                                                                                                    \
+      if (__ballot(nd < od) != 0ull) {                                                                                 \
+        const float m = wave_max_fast(nd);                                                                             \
+        const int own = __builtin_amdgcn_readfirstlane(__ffsll((long long)__ballot(nd == m)) - 1);                     \
+        const float m2 = wave_max_fast(lane == own ? -1.f : nd);                                                       \
+        if (lane == own) {                                                                                             \
+          rec_a[S * 16 + (t_ >> 6)] = make_float4(m, m2, px##S, py##S);                                                \
+          rec_b[S * 16 + (t_ >> 6)] = make_float2(pz_, __int_as_float(S * 1024 + t_));                                \
+        }                                                                                                              \
+        cmax = lane == S ? m : cmax;                                                                                   \
+        touched = true;                                                                                                \
+      }                                                                                                                \
+    }                                                                                                                  \
+    break;
+#define FPS_SLOT_FALLBACK(S)                                                                                           \
+  if constexpr (S < PPT) {                                                                                             \
+    if (dist##S == mx) kmin = min(kmin, fps_key((int)perm[S * 1024 + tid], rb_log2));                                  \
+  }
+
+template <int PPT, int KP>
+__global__ __launch_bounds__(1024) void fps_cluster_kernel(const float* __restrict__ xyz, int64_t sb, int64_t sc,
+                                                           int64_t sn, int N, int M, int rb_log2,
+                                                           unsigned* __restrict__ perm_ws, int64_t* __restrict__ index) {
+  static_assert(PPT <= 25 && KP >= 1 && KP <= 15, "one lane per cluster of a wave, one DPP row of candidates");
+  constexpr int T = 1024, W = 16, CELLS = 4096, C = PPT * 16;
+  __shared__ float pzl[T * PPT];     // z of sorted position q (x, y and the running distance are registers)
+  unsigned* hist = reinterpret_cast<unsigned*>(pzl);   // the sort's histogram: dead before pzl is filled
+  static_assert(T * PPT >= CELLS, "histogram aliases pzl");
+  unsigned* perm = perm_ws + (int64_t)blockIdx.x * N;  // sorted position -> original index: N words of workspace per scene
+  __shared__ float red[6][W];
+  __shared__ unsigned wsum[W];
+  __shared__ unsigned win_key;
+  __shared__ float4 rec_a[C];        // per cluster: (best value, bound on its other points, best point's x, y)
+  __shared__ float2 rec_b[C];        //              (z, sorted position)
+  __shared__ float4 accb[KP];
+  __shared__ int acc_n;
+  __shared__ float fb_mx;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* base = xyz + (int64_t)blockIdx.x * sb;
+  int64_t* out = index + (int64_t)blockIdx.x * M;
+  fps_morton_perm<PPT>(base, sc, sn, N, perm, hist, red, wsum);
+
+  FPS_SLOTS(FPS_SLOT_DECL)
+  float cqx = 0.f, cqy = 0.f, cqz = 0.f, cR = 0.f, cthr = -1.f, cmax = __builtin_inff();   // lane s: cluster s * 16 + wave
+  FPS_SLOTS(FPS_SLOT_LOAD)
+  for (int g = tid; g < C; g += T) {
+    rec_a[g] = make_float4(-1.f, -1.f, 0.f, 0.f);
+    rec_b[g] = make_float2(0.f, 0.f);
+  }
+  if (tid == 0) {
+    accb[0] = make_float4(base[0], base[sc], base[2 * sc], __int_as_float(-1));
+    acc_n = 1;
+    win_key = 0xffffffffu;
+    out[0] = 0;
+  }
+  __syncthreads();
+  int i = 1, last_q = -1, last_idx = 0;       // the last pick as a sorted position (or, from the one-pick path, an index)
+  int pend_n = 0, pend_i = 0, pend_idx = 0;   // wave 0: picks whose original index is still in flight
+#if FPS_ABLATE == 9
+  const int tstamp_tid = 0;
+  unsigned long long tprev = __builtin_readcyclecounter();
+#endif
+  while (i < M) {
+    FPS_T(0);
+#if FPS_ABLATE == 9
+    if (blockIdx.x == 0 && tid == 0) atomicAdd(&fps_dbg[7], 1ull);
+#endif
+    const int n = __builtin_amdgcn_readfirstlane(acc_n);
+    bool touched = false;
+    for (int c = 0; c < n; ++c) {
+      const float4 a = accb[c];
+      const float cx = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a.x)));
+      const float cy = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a.y)));
+      const float cz = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a.z)));
+      unsigned mask = (unsigned)__ballot(sqdist3(cqx, cqy, cqz, cx, cy, cz) < cthr);    // lanes >= PPT: cthr = -1
+      while (mask) {
+        const int s = __builtin_ctz(mask);
+        mask &= mask - 1;
+        switch (s) {
+          FPS_SLOTS(FPS_CLUSTER_UPDATE)
+          default: break;
+        }
+      }
+    }
+    FPS_T(1);
+    if (touched) {
+      const float reach = cR + sqrtf(fmaxf(cmax, 0.f)) * 1.0001f;
+      cthr = cthr >= 0.f ? reach * reach * 1.0001f + 1e-30f : -1.f;
+    }
+    FPS_T(2);
+    __syncthreads();
+    FPS_T(3);
+    if (wave == 0) {
+      // 64 lane records out of the C cluster records: the lane's best cluster and a bound on everything else it looked at
+      float v = -1.f, v2 = -1.f, y1 = -1.f;
+      int gb = lane;
+#pragma unroll
+      for (int g0 = 0; g0 < C; g0 += 64) {
+        const int g = g0 + lane;
+        if (g < C) {
+          const float4 r = rec_a[g];
+          const bool better = r.x > v;
+          v2 = fmaxf(v2, better ? v : r.x);
+          y1 = better ? r.y : y1;
+          gb = better ? g : gb;
+          v = better ? r.x : v;
+        }
+      }
+      v2 = fmaxf(v2, y1);
+      const float4 ra = rec_a[gb];
+      const float2 rb = rec_b[gb];
+      const float m0 = wave_max_f32(v);
+      unsigned long long mk = __ballot(v == m0);
+      int lj = __builtin_amdgcn_readfirstlane(__ffsll((long long)mk) - 1);
+      float bmax = readlane_f32(v2, lj);
+      bool ok = m0 > 0.f && __popcll(mk) == 1 && m0 > bmax;
+      v = lane == lj ? -2.f : v;
+      float mnext = wave_max_f32(v);
+      ok = ok && m0 > mnext;
+      int cnt = 0;
+      float ax = 0.f, ay = 0.f, az = 0.f;
+      int aq = 0;
+      if (ok) {
+        float mj = m0;
+        for (;;) {
+          const float cjx = readlane_f32(ra.z, lj), cjy = readlane_f32(ra.w, lj), cjz = readlane_f32(rb.x, lj);
+          const int cq = __builtin_amdgcn_readlane(__float_as_int(rb.y), lj);
+          if (cnt > 0) {
+            const float d = sqdist3(cjx, cjy, cjz, ax, ay, az);
+            if (__ballot(lane < cnt && d < mj) != 0ull) break;
+          }
+          if (lane == cnt) { ax = cjx; ay = cjy; az = cjz; aq = cq; }
+          ++cnt;
+          if (cnt == KP || i + cnt >= M) break;
+          mj = mnext;
+          if (!(mj > 0.f)) break;
+          mk = __ballot(v == mj);
+          if (__popcll(mk) != 1) break;
+          lj = __builtin_amdgcn_readfirstlane(__ffsll((long long)mk) - 1);
+          bmax = fmaxf(bmax, readlane_f32(v2, lj));
+          v = lane == lj ? -2.f : v;
+          mnext = wave_max_f32(v);
+          if (!(mj > mnext && mj > bmax)) break;
+        }
+      }
+      if (pend_n > 0 && lane < pend_n) out[pend_i + lane] = pend_idx;   // last round's picks (their lookup had a round to land)
+      pend_n = cnt;
+      pend_i = i;
+      if (lane < cnt) {
+        accb[lane] = make_float4(ax, ay, az, __int_as_float(aq));
+        pend_idx = (int)perm[aq];          // original index: a global load, consumed one round later
+      }
+      if (lane == 0) { acc_n = cnt; fb_mx = m0; }
+    }
+    FPS_T(4);
+    __syncthreads();
+    FPS_T(5);
+    const int got = __builtin_amdgcn_readfirstlane(acc_n);
+    if (got > 0) {
+      last_q = __builtin_amdgcn_readfirstlane(__float_as_int(accb[got - 1].w));
+      i += got;
+      continue;
+    }
+    // ---- exact one-pick path (equal maxima / all distances zero): the reference's tie order through the keys ------------
+    const float mx = fb_mx;
+    if (mx > 0.f) {
+      unsigned kmin = 0xffffffffu;
+      FPS_SLOTS(FPS_SLOT_FALLBACK)
+      if (kmin != 0xffffffffu) atomicMin(&win_key, kmin);
+    }
+    __syncthreads();
+    const unsigned key = win_key;
+    // all distances 0: the reference repeats its last pick
+    const int cur1 = key != 0xffffffffu ? fps_unkey(key, rb_log2) : (last_q >= 0 ? (int)perm[last_q] : last_idx);
+    __syncthreads();
+    if (tid == 0) {
+      win_key = 0xffffffffu;
+      accb[0] = make_float4(base[(int64_t)cur1 * sn], base[sc + (int64_t)cur1 * sn], base[2 * sc + (int64_t)cur1 * sn],
+                            __int_as_float(-1));
+      acc_n = 1;
+      out[i] = cur1;
+    }
+    last_q = -1;
+    last_idx = cur1;
+    i += 1;
+    __syncthreads();
+  }
+  if (wave == 0 && pend_n > 0 && lane < pend_n) out[pend_i + lane] = pend_idx;
+}
+
 // Fallback for scenes too large to keep resident: min-distances live in a caller-provided
 // (B,N) workspace, xyz is re-read (L2) each round.  Same tie order.
 template <int T>
@@ -846,12 +1195,23 @@ static int fps_num_cus() {
   return n;
 }
 
+#ifndef FPS_CLUSTERS
+#define FPS_CLUSTERS 1   // 1: fps_cluster_kernel (pruning per 64-point cluster); 0: fps_sorted_kernel (per wave)
+#endif
+#ifndef FPS_CLUSTER_PICKS
+#define FPS_CLUSTER_PICKS 8
+#endif
+
+// 8 192 < N <= 25 600 with M >= 1024 (fps_cluster_kernel): N words per scene for the sort's permutation.
 // N > 25 600: 64 bytes of exchange slots per scene for the multi-workgroup kernel, or (scenes that do not fit it) a (B,N)
 // float array of running distances for the streaming kernel.  The callee initialises the workspace.
 extern "C" int64_t regnet_fps_workspace_bytes(int64_t B, int64_t N, int64_t M) {
   (void)M;
 #ifdef FPS_FORCE_MULTI
   if (N > 8192 && N <= FPS_RESIDENT_MAX) return B * 64;
+#endif
+#if FPS_CLUSTERS
+  if (N > 8192 && N <= FPS_RESIDENT_MAX && M >= 1024) return B * N * (int64_t)sizeof(unsigned);   // fps_cluster_kernel: the sort's permutation
 #endif
   if (N <= FPS_RESIDENT_MAX) return 0;
   const int64_t stream_bytes = B * N * (int64_t)sizeof(float), slot_bytes = B * 64;
@@ -862,9 +1222,15 @@ extern "C" int64_t regnet_fps_workspace_bytes(int64_t B, int64_t N, int64_t M) {
   hipLaunchKernelGGL((fps_resident_kernel<T, PPT>), dim3((unsigned)B), dim3(T), 0, st, xyz, sb, sc, sn, \
                      (int)N, (int)M, rbl, index)
 
+#if FPS_CLUSTERS
+#define FPS_SORTED_CASE(PPT)                                                                                          \
+  hipLaunchKernelGGL((fps_cluster_kernel<PPT, FPS_CLUSTER_PICKS>), dim3((unsigned)B), dim3(1024), 0, st, xyz, sb, sc, \
+                     sn, (int)N, (int)M, rbl, reinterpret_cast<unsigned*>(workspace), index)
+#else
 #define FPS_SORTED_CASE(PPT)                                                                                     \
   hipLaunchKernelGGL((fps_sorted_kernel<PPT, FPS_PICKS>), dim3((unsigned)B), dim3(1024), 0, st, xyz, sb, sc, sn, \
                      (int)N, (int)M, rbl, index)
+#endif
 
 extern "C" int regnet_fps_f32(const float* xyz, int64_t sb, int64_t sc, int64_t sn, int64_t B, int64_t N, int64_t M,
                               int64_t* index, float* workspace, void* stream) {
@@ -890,6 +1256,7 @@ extern "C" int regnet_fps_f32(const float* xyz, int64_t sb, int64_t sc, int64_t 
     return REGNET_OK;
   }
 #endif
+  if (regnet_fps_workspace_bytes(B, N, M) > 0 && !workspace) return REGNET_ERR_NULL;
   if (N <= 64) FPS_CASE(64, 1);
   else if (N <= 128) FPS_CASE(128, 1);
   else if (N <= 256) FPS_CASE(256, 1);

@@ -19,10 +19,13 @@ int main(int argc, char** argv) {
   hipMalloc(&d, h.size() * 4); hipMalloc(&idx, (size_t)B * M * 8);
   hipMemcpy(d, h.data(), h.size() * 4, hipMemcpyHostToDevice);
   hipEvent_t s, e; hipEventCreate(&s); hipEventCreate(&e);
-  regnet_fps_f32(d, (int64_t)N * 3, 1, 3, B, N, M, idx, nullptr, nullptr);
+  float* ws = nullptr;
+  const int64_t wsb = regnet_fps_workspace_bytes(B, N, M);
+  if (wsb) hipMalloc(&ws, wsb);
+  regnet_fps_f32(d, (int64_t)N * 3, 1, 3, B, N, M, idx, ws, nullptr);
   hipDeviceSynchronize();
   hipEventRecord(s);
-  for (int r = 0; r < 3; ++r) regnet_fps_f32(d, (int64_t)N * 3, 1, 3, B, N, M, idx, nullptr, nullptr);
+  for (int r = 0; r < 3; ++r) regnet_fps_f32(d, (int64_t)N * 3, 1, 3, B, N, M, idx, ws, nullptr);
   hipEventRecord(e); hipEventSynchronize(e);
   float ms; hipEventElapsedTime(&ms, s, e);
   std::vector<int64_t> out((size_t)B * M);
@@ -33,7 +36,7 @@ int main(int argc, char** argv) {
   hipMemcpyFromSymbol(dbg, HIP_SYMBOL(fps_dbg), sizeof(dbg));
   const char* names[8] = {"loop-top(after unkey/store)", "centroid load+test", "scan", "wave reduce+lds write", "barrier1", "read partials+stage2", "barrier2", ""};
   double rounds = 4.0 * (M - 1);
-#if FPS_PICKS > 1
+#if FPS_PICKS > 1 || FPS_CLUSTERS
   const char* names2[8] = {"after barrier 2 -> loop top", "centroid tests + scans", "top-2 / slot / row records", "barrier 1", "selection + acceptance (wave 0)", "barrier 2", "", ""};
   for (int k = 0; k < 8; ++k) names[k] = names2[k];
   rounds = (double)dbg[7];
