@@ -726,26 +726,47 @@ __device__ __forceinline__ void fps_morton_perm(const float* __restrict__ base, 
   }
   for (int c = tid; c < CELLS; c += T) hist[c] = 0;
   __syncthreads();
-  float scale[3];
+  // 12 key bits, dealt one at a time to the axis whose cells are currently the longest: the cells come out as close to cubes
+  // as 4096 of them can be (a table-top scene is a slab: 16 x 16 x 16 would spend a third of the bits on a few centimetres of
+  // depth and leave flat, wide cells -- and clusters three times the radius).  Bits are interleaved in the order dealt.
+  float scale[3], ext[3];
+  int nb[3] = {0, 0, 0};
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
     float l = red[a][0], h = red[3 + a][0];
 #pragma unroll
     for (int w = 1; w < W; ++w) { l = fminf(l, red[a][w]); h = fmaxf(h, red[3 + a][w]); }
     lo[a] = l;
-    const float ext = h - l;
-    scale[a] = ext > 0.f ? 16.0f / ext : 0.f;
+    ext[a] = h - l;
   }
+  unsigned order = 0;   // 2 bits per key bit, most significant key bit first: which axis it came from
+#pragma unroll
+  for (int k = 0; k < 12; ++k) {
+    const float e0 = ext[0] / (float)(1 << nb[0]), e1 = ext[1] / (float)(1 << nb[1]), e2 = ext[2] / (float)(1 << nb[2]);
+    const int a = (e0 >= e1 && e0 >= e2) ? 0 : (e1 >= e2 ? 1 : 2);
+    nb[a] += 1;
+    order = (order << 2) | (unsigned)a;
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) scale[a] = ext[a] > 0.f ? (float)(1 << nb[a]) / ext[a] : 0.f;
   unsigned short cell[PPT], rank[PPT];
 #pragma unroll
   for (int s = 0; s < PPT; ++s) {
     const int j = s * T + tid;
     cell[s] = 0; rank[s] = 0;
     if (j < N) {
-      const unsigned qx = min(15u, (unsigned)((px[s] - lo[0]) * scale[0]));
-      const unsigned qy = min(15u, (unsigned)((py[s] - lo[1]) * scale[1]));
-      const unsigned qz = min(15u, (unsigned)((pz[s] - lo[2]) * scale[2]));
-      const unsigned c = spread4(qx) | (spread4(qy) << 1) | (spread4(qz) << 2);
+      unsigned q[3];
+      q[0] = min((1u << nb[0]) - 1u, (unsigned)((px[s] - lo[0]) * scale[0]));
+      q[1] = min((1u << nb[1]) - 1u, (unsigned)((py[s] - lo[1]) * scale[1]));
+      q[2] = min((1u << nb[2]) - 1u, (unsigned)((pz[s] - lo[2]) * scale[2]));
+      int left[3] = {nb[0], nb[1], nb[2]};
+      unsigned c = 0;
+#pragma unroll
+      for (int k = 11; k >= 0; --k) {
+        const int a = (order >> (2 * k)) & 3;
+        left[a] -= 1;
+        c = (c << 1) | ((q[a] >> left[a]) & 1u);
+      }
       cell[s] = (unsigned short)c;
       rank[s] = (unsigned short)atomicAdd(&hist[c], 1u);
     }
@@ -813,6 +834,7 @@ __device__ __forceinline__ void fps_morton_perm(const float* __restrict__ base, 
       cthr = __builtin_inff();           /* update needed while |q - c|^2 < cthr */                                    \
     }                                                                                                                  \
   }
+#define FPS_CLUSTER_MAX_PICKS 8192   // picks of one launch kept in LDS (32 KB); longer runs take fps_sorted_kernel
 // one flagged cluster: distances, then (if any changed) the cluster's record and its maximum for the sphere test
 #define FPS_CLUSTER_UPDATE(S)                                                                                          \
   case S:                                                                                                              \
@@ -829,8 +851,8 @@ __device__ __forceinline__ void fps_morton_perm(const float* __restrict__ base, 
         const int own = __builtin_amdgcn_readfirstlane(__ffsll((long long)__ballot(nd == m)) - 1);                     \
         const float m2 = wave_max_fast(lane == own ? -1.f : nd);                                                       \
         if (lane == own) {                                                                                             \
-          rec_a[S * 16 + (t_ >> 6)] = make_float4(m, m2, px##S, py##S);                                                \
-          rec_b[S * 16 + (t_ >> 6)] = make_float2(pz_, __int_as_float(S * 1024 + t_));                                \
+          rec_v[S * 16 + (t_ >> 6)] = make_float2(m, m2);                                                              \
+          rec_p[S * 16 + (t_ >> 6)] = make_float4(px##S, py##S, pz_, __int_as_float(S * 1024 + t_));                   \
         }                                                                                                              \
         cmax = lane == S ? m : cmax;                                                                                   \
         touched = true;                                                                                                \
@@ -855,11 +877,13 @@ __global__ __launch_bounds__(1024) void fps_cluster_kernel(const float* __restri
   __shared__ float red[6][W];
   __shared__ unsigned wsum[W];
   __shared__ unsigned win_key;
-  __shared__ float4 rec_a[C];        // per cluster: (best value, bound on its other points, best point's x, y)
-  __shared__ float2 rec_b[C];        //              (z, sorted position)
+  constexpr int CP = (C + 63) / 64 * 64;
+  __shared__ float2 rec_v[CP];       // per cluster: (best value, bound on its other points); padded with -1 to whole waves
+  __shared__ float4 rec_p[C];        //              the best point's (x, y, z, sorted position)
   __shared__ float4 accb[KP];
   __shared__ int acc_n;
   __shared__ float fb_mx;
+  __shared__ int picks[FPS_CLUSTER_MAX_PICKS];   // M <= FPS_CLUSTER_MAX_PICKS (the launcher checks)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* base = xyz + (int64_t)blockIdx.x * sb;
   int64_t* out = index + (int64_t)blockIdx.x * M;
@@ -868,9 +892,9 @@ __global__ __launch_bounds__(1024) void fps_cluster_kernel(const float* __restri
   FPS_SLOTS(FPS_SLOT_DECL)
   float cqx = 0.f, cqy = 0.f, cqz = 0.f, cR = 0.f, cthr = -1.f, cmax = __builtin_inff();   // lane s: cluster s * 16 + wave
   FPS_SLOTS(FPS_SLOT_LOAD)
-  for (int g = tid; g < C; g += T) {
-    rec_a[g] = make_float4(-1.f, -1.f, 0.f, 0.f);
-    rec_b[g] = make_float2(0.f, 0.f);
+  for (int g = tid; g < CP; g += T) {
+    rec_v[g] = make_float2(-1.f, -1.f);
+    if (g < C) rec_p[g] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   if (tid == 0) {
     accb[0] = make_float4(base[0], base[sc], base[2 * sc], __int_as_float(-1));
@@ -880,7 +904,7 @@ __global__ __launch_bounds__(1024) void fps_cluster_kernel(const float* __restri
   }
   __syncthreads();
   int i = 1, last_q = -1, last_idx = 0;       // the last pick as a sorted position (or, from the one-pick path, an index)
-  int pend_n = 0, pend_i = 0, pend_idx = 0;   // wave 0: picks whose original index is still in flight
+  float rho = 0.5f;                           // wave 0: candidate threshold as a fraction of the maximum (adaptive)
 #if FPS_ABLATE == 9
   const int tstamp_tid = 0;
   unsigned long long tprev = __builtin_readcyclecounter();
@@ -898,6 +922,9 @@ __global__ __launch_bounds__(1024) void fps_cluster_kernel(const float* __restri
       const float cy = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a.y)));
       const float cz = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a.z)));
       unsigned mask = (unsigned)__ballot(sqdist3(cqx, cqy, cqz, cx, cy, cz) < cthr);    // lanes >= PPT: cthr = -1
+#if FPS_ABLATE == 9
+      if (blockIdx.x == 0 && lane == 0) atomicAdd(&fps_dbg[6], (unsigned long long)__popc(mask));
+#endif
       while (mask) {
         const int s = __builtin_ctz(mask);
         mask &= mask - 1;
@@ -917,65 +944,62 @@ __global__ __launch_bounds__(1024) void fps_cluster_kernel(const float* __restri
     FPS_T(3);
     if (wave == 0) {
       // 64 lane records out of the C cluster records: the lane's best cluster and a bound on everything else it looked at
+      int l_ = lane;                       // opaque: addresses derived from it are recomputed here, not kept (spilled) across the loop
+      asm volatile("" : "+v"(l_));
       float v = -1.f, v2 = -1.f, y1 = -1.f;
-      int gb = lane;
+      int gb = l_;
+      float2 rr[CP / 64];
 #pragma unroll
-      for (int g0 = 0; g0 < C; g0 += 64) {
-        const int g = g0 + lane;
-        if (g < C) {
-          const float4 r = rec_a[g];
-          const bool better = r.x > v;
-          v2 = fmaxf(v2, better ? v : r.x);
-          y1 = better ? r.y : y1;
-          gb = better ? g : gb;
-          v = better ? r.x : v;
-        }
+      for (int k = 0; k < CP / 64; ++k) rr[k] = rec_v[k * 64 + l_];      // all loads in flight together (no guards: padded)
+#pragma unroll
+      for (int k = 0; k < CP / 64; ++k) {
+        const bool better = rr[k].x > v;
+        v2 = vmax_f32(v2, better ? v : rr[k].x);
+        y1 = better ? rr[k].y : y1;
+        gb = better ? k * 64 + l_ : gb;
+        v = better ? rr[k].x : v;
       }
-      v2 = fmaxf(v2, y1);
-      const float4 ra = rec_a[gb];
-      const float2 rb = rec_b[gb];
-      const float m0 = wave_max_f32(v);
-      unsigned long long mk = __ballot(v == m0);
-      int lj = __builtin_amdgcn_readfirstlane(__ffsll((long long)mk) - 1);
-      float bmax = readlane_f32(v2, lj);
-      bool ok = m0 > 0.f && __popcll(mk) == 1 && m0 > bmax;
-      v = lane == lj ? -2.f : v;
-      float mnext = wave_max_f32(v);
-      ok = ok && m0 > mnext;
-      int cnt = 0;
-      float ax = 0.f, ay = 0.f, az = 0.f;
-      int aq = 0;
-      if (ok) {
-        float mj = m0;
-        for (;;) {
-          const float cjx = readlane_f32(ra.z, lj), cjy = readlane_f32(ra.w, lj), cjz = readlane_f32(rb.x, lj);
-          const int cq = __builtin_amdgcn_readlane(__float_as_int(rb.y), lj);
-          if (cnt > 0) {
-            const float d = sqdist3(cjx, cjy, cjz, ax, ay, az);
-            if (__ballot(lane < cnt && d < mj) != 0ull) break;
-          }
-          if (lane == cnt) { ax = cjx; ay = cjy; az = cjz; aq = cq; }
-          ++cnt;
-          if (cnt == KP || i + cnt >= M) break;
-          mj = mnext;
-          if (!(mj > 0.f)) break;
-          mk = __ballot(v == mj);
-          if (__popcll(mk) != 1) break;
-          lj = __builtin_amdgcn_readfirstlane(__ffsll((long long)mk) - 1);
-          bmax = fmaxf(bmax, readlane_f32(v2, lj));
-          v = lane == lj ? -2.f : v;
-          mnext = wave_max_f32(v);
-          if (!(mj > mnext && mj > bmax)) break;
-        }
+      v2 = vmax_f32(v2, y1);
+      const float4 rp = rec_p[gb];
+      // Candidates: the lanes above a threshold tau (adaptive: any tau is correct, it only decides how many there are).
+      // B bounds every point that is NOT a surviving candidate: the other lanes' best values, the candidates' own second
+      // bests, and the candidates that do not beat it.  The survivors A, taken in descending order, are the next picks for as
+      // long as each is untouched by the ones before it (and no two are equal) -- all lanes evaluate that in parallel.
+      const float m0 = wave_max_fast(v);
+      float tau = m0 * rho;
+      unsigned long long cm = __ballot(v > tau);
+      int ncand = (int)__popcll(cm);
+#pragma unroll 1
+      for (int t = 0; t < 4 && ncand > 16; ++t) {
+        tau = 0.5f * (tau + m0);
+        cm = __ballot(v > tau);
+        ncand = (int)__popcll(cm);
       }
-      if (pend_n > 0 && lane < pend_n) out[pend_i + lane] = pend_idx;   // last round's picks (their lookup had a round to land)
-      pend_n = cnt;
-      pend_i = i;
-      if (lane < cnt) {
-        accb[lane] = make_float4(ax, ay, az, __int_as_float(aq));
-        pend_idx = (int)perm[aq];          // original index: a global load, consumed one round later
+      if (ncand > 16) cm = __ballot(v == m0);
+      rho = ncand > 16 ? 0.5f * (1.f + rho) : (ncand < KP ? fmaxf(rho * rho, 0.25f) : rho);
+      rho = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, rho)));   // uniform: an SGPR
+      const bool cand = (cm >> l_) & 1ull;
+      const float B = wave_max_fast(cand ? v2 : v);
+      const unsigned long long am = m0 > 0.f ? __ballot(cand && v > B) : 0ull;
+      int rank = 0;
+      bool bad = false;
+      for (unsigned long long it = am; it != 0ull; it &= it - 1ull) {
+        const int li = __builtin_amdgcn_readfirstlane(__ffsll((long long)it) - 1);
+        const float vi = readlane_f32(v, li);
+        const float xi = readlane_f32(rp.x, li), yi = readlane_f32(rp.y, li), zi = readlane_f32(rp.z, li);
+        const bool higher = vi > v;                         // candidate li is picked before this lane's
+        rank += higher ? 1 : 0;
+        bad = bad || (li != l_ && vi == v) || (higher && sqdist3(rp.x, rp.y, rp.z, xi, yi, zi) < v);
       }
-      if (lane == 0) { acc_n = cnt; fb_mx = m0; }
+      const bool in_a = (am >> l_) & 1ull;
+      const int bad_rank = (int)-wave_max_fast(in_a && bad ? -(float)rank : -99.f);
+      int cnt = min(min((int)__popcll(am), bad_rank), min(KP, M - i));
+      const bool accepted = in_a && rank < cnt;
+      if (accepted) {
+        accb[rank] = make_float4(rp.x, rp.y, rp.z, rp.w);
+        picks[i + rank] = __float_as_int(rp.w);          // sorted position; translated to the original index after the loop
+      }
+      if (l_ == 0) { acc_n = cnt; fb_mx = m0; }
     }
     FPS_T(4);
     __syncthreads();
@@ -1003,14 +1027,19 @@ __global__ __launch_bounds__(1024) void fps_cluster_kernel(const float* __restri
       accb[0] = make_float4(base[(int64_t)cur1 * sn], base[sc + (int64_t)cur1 * sn], base[2 * sc + (int64_t)cur1 * sn],
                             __int_as_float(-1));
       acc_n = 1;
-      out[i] = cur1;
+      picks[i] = -cur1 - 1;               // already an original index
     }
     last_q = -1;
     last_idx = cur1;
     i += 1;
     __syncthreads();
   }
-  if (wave == 0 && pend_n > 0 && lane < pend_n) out[pend_i + lane] = pend_idx;
+  // the round loop touches no global memory (a store in front of a barrier costs its acknowledgement, ~1 us per round): the
+  // picks wait in LDS as sorted positions and are translated here
+  for (int k = 1 + tid; k < M; k += T) {
+    const int v = picks[k];
+    out[k] = v >= 0 ? (int64_t)perm[v] : (int64_t)(-v - 1);
+  }
 }
 
 // Fallback for scenes too large to keep resident: min-distances live in a caller-provided
@@ -1199,7 +1228,7 @@ static int fps_num_cus() {
 #define FPS_CLUSTERS 1   // 1: fps_cluster_kernel (pruning per 64-point cluster); 0: fps_sorted_kernel (per wave)
 #endif
 #ifndef FPS_CLUSTER_PICKS
-#define FPS_CLUSTER_PICKS 8
+#define FPS_CLUSTER_PICKS 12
 #endif
 
 // 8 192 < N <= 25 600 with M >= 1024 (fps_cluster_kernel): N words per scene for the sort's permutation.
@@ -1211,7 +1240,8 @@ extern "C" int64_t regnet_fps_workspace_bytes(int64_t B, int64_t N, int64_t M) {
   if (N > 8192 && N <= FPS_RESIDENT_MAX) return B * 64;
 #endif
 #if FPS_CLUSTERS
-  if (N > 8192 && N <= FPS_RESIDENT_MAX && M >= 1024) return B * N * (int64_t)sizeof(unsigned);   // fps_cluster_kernel: the sort's permutation
+  if (N > 8192 && N <= FPS_RESIDENT_MAX && M >= 1024 && M <= FPS_CLUSTER_MAX_PICKS)
+    return B * N * (int64_t)sizeof(unsigned);   // fps_cluster_kernel: the sort's permutation
 #endif
   if (N <= FPS_RESIDENT_MAX) return 0;
   const int64_t stream_bytes = B * N * (int64_t)sizeof(float), slot_bytes = B * 64;
@@ -1222,14 +1252,17 @@ extern "C" int64_t regnet_fps_workspace_bytes(int64_t B, int64_t N, int64_t M) {
   hipLaunchKernelGGL((fps_resident_kernel<T, PPT>), dim3((unsigned)B), dim3(T), 0, st, xyz, sb, sc, sn, \
                      (int)N, (int)M, rbl, index)
 
+#define FPS_WAVE_CASE(PPT)                                                                                       \
+  hipLaunchKernelGGL((fps_sorted_kernel<PPT, FPS_PICKS>), dim3((unsigned)B), dim3(1024), 0, st, xyz, sb, sc, sn, \
+                     (int)N, (int)M, rbl, index)
 #if FPS_CLUSTERS
+#define FPS_CLUSTER_LIMIT FPS_CLUSTER_MAX_PICKS
 #define FPS_SORTED_CASE(PPT)                                                                                          \
   hipLaunchKernelGGL((fps_cluster_kernel<PPT, FPS_CLUSTER_PICKS>), dim3((unsigned)B), dim3(1024), 0, st, xyz, sb, sc, \
                      sn, (int)N, (int)M, rbl, reinterpret_cast<unsigned*>(workspace), index)
 #else
-#define FPS_SORTED_CASE(PPT)                                                                                     \
-  hipLaunchKernelGGL((fps_sorted_kernel<PPT, FPS_PICKS>), dim3((unsigned)B), dim3(1024), 0, st, xyz, sb, sc, sn, \
-                     (int)N, (int)M, rbl, index)
+#define FPS_CLUSTER_LIMIT (1 << 30)
+#define FPS_SORTED_CASE(PPT) FPS_WAVE_CASE(PPT)
 #endif
 
 extern "C" int regnet_fps_f32(const float* xyz, int64_t sb, int64_t sc, int64_t sn, int64_t B, int64_t N, int64_t M,
@@ -1271,10 +1304,14 @@ extern "C" int regnet_fps_f32(const float* xyz, int64_t sb, int64_t sc, int64_t 
   else if (M < 1024 && N <= 16384) FPS_CASE(1024, 16);
   else if (M < 1024 && N <= 20480) FPS_CASE(1024, 20);
   else if (M < 1024 && N <= FPS_RESIDENT_MAX) FPS_CASE(1024, 25);
-  else if (N <= 12288) FPS_SORTED_CASE(12);
-  else if (N <= 16384) FPS_SORTED_CASE(16);
-  else if (N <= 20480) FPS_SORTED_CASE(20);
-  else if (N <= FPS_RESIDENT_MAX) FPS_SORTED_CASE(25);
+  else if (N <= 12288 && M <= FPS_CLUSTER_LIMIT) FPS_SORTED_CASE(12);
+  else if (N <= 16384 && M <= FPS_CLUSTER_LIMIT) FPS_SORTED_CASE(16);
+  else if (N <= 20480 && M <= FPS_CLUSTER_LIMIT) FPS_SORTED_CASE(20);
+  else if (N <= FPS_RESIDENT_MAX && M <= FPS_CLUSTER_LIMIT) FPS_SORTED_CASE(25);
+  else if (N <= 12288) FPS_WAVE_CASE(12);
+  else if (N <= 16384) FPS_WAVE_CASE(16);
+  else if (N <= 20480) FPS_WAVE_CASE(20);
+  else if (N <= FPS_RESIDENT_MAX) FPS_WAVE_CASE(25);
   else if (N <= FPS_MULTI_MAX && M < 32768 /* 15-bit round tag */ &&
            ((N + FPS_RESIDENT_MAX - 1) / FPS_RESIDENT_MAX) * B <= fps_num_cus()) {
     if (!workspace) return REGNET_ERR_NULL;

@@ -41,6 +41,10 @@ int main(int argc, char** argv) {
   for (int k = 0; k < 8; ++k) names[k] = names2[k];
   rounds = (double)dbg[7];
   printf("  %.0f rounds for %d picks x 4 launches: %.2f picks per round\n", rounds, M - 1, 4.0 * (M - 1) / rounds);
+#if FPS_CLUSTERS
+  printf("  clusters flagged per centroid: %.1f of %d\n", (double)dbg[6] / (4.0 * (M - 1)), (N + 63) / 64);
+  dbg[6] = 0;
+#endif
 #endif
   for (int k = 0; k < 7; ++k) printf("  phase %d %-28s %8.1f cycles/round (thread 0 of block 0)\n", k, names[k], dbg[k] / rounds);
 #endif
