@@ -884,6 +884,9 @@ __global__ __launch_bounds__(1024) void fps_cluster_kernel(const float* __restri
   __shared__ int acc_n;
   __shared__ float fb_mx;
   __shared__ int picks[FPS_CLUSTER_MAX_PICKS];   // M <= FPS_CLUSTER_MAX_PICKS (the launcher checks)
+  __shared__ float4 cand_p[16];      // wave 0's selection: the surviving candidates (x, y, z, value) ...
+  __shared__ int cand_q[16];         // ... their sorted positions ...
+  __shared__ int rank_buf[64];       // ... and the partial ranks of the pairwise pass
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* base = xyz + (int64_t)blockIdx.x * sb;
   int64_t* out = index + (int64_t)blockIdx.x * M;
@@ -981,23 +984,38 @@ __global__ __launch_bounds__(1024) void fps_cluster_kernel(const float* __restri
       const bool cand = (cm >> l_) & 1ull;
       const float B = wave_max_fast(cand ? v2 : v);
       const unsigned long long am = m0 > 0.f ? __ballot(cand && v > B) : 0ull;
-      int rank = 0;
-      bool bad = false;
-      for (unsigned long long it = am; it != 0ull; it &= it - 1ull) {
-        const int li = __builtin_amdgcn_readfirstlane(__ffsll((long long)it) - 1);
-        const float vi = readlane_f32(v, li);
-        const float xi = readlane_f32(rp.x, li), yi = readlane_f32(rp.y, li), zi = readlane_f32(rp.z, li);
-        const bool higher = vi > v;                         // candidate li is picked before this lane's
-        rank += higher ? 1 : 0;
-        bad = bad || (li != l_ && vi == v) || (higher && sqdist3(rp.x, rp.y, rp.z, xi, yi, zi) < v);
-      }
+      // pairwise: the survivors are compacted into LDS (at most 16), lane l looks at the pairs (j = l % 16, i = l / 16 + 4 t):
+      // how many survivors precede j (rank), does one of them touch it or equal it (bad)
+      const int n_a = (int)__popcll(am);
       const bool in_a = (am >> l_) & 1ull;
-      const int bad_rank = (int)-wave_max_fast(in_a && bad ? -(float)rank : -99.f);
-      int cnt = min(min((int)__popcll(am), bad_rank), min(KP, M - i));
-      const bool accepted = in_a && rank < cnt;
-      if (accepted) {
-        accb[rank] = make_float4(rp.x, rp.y, rp.z, rp.w);
-        picks[i + rank] = __float_as_int(rp.w);          // sorted position; translated to the original index after the loop
+      const int pos = (int)__popcll(am & ((1ull << l_) - 1ull));
+      if (in_a) {
+        cand_p[pos] = make_float4(rp.x, rp.y, rp.z, v);
+        cand_q[pos] = __float_as_int(rp.w);
+      }
+      const int j = l_ & 15, ig = l_ >> 4;
+      const float4 cj = cand_p[j];
+      int rank_part = 0;
+      bool bad_part = false;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int i2 = ig + 4 * t;
+        const float4 ci = cand_p[i2];
+        const bool live = i2 < n_a && j < n_a && i2 != j;
+        const bool higher = ci.w > cj.w;                      // survivor i2 is picked before j
+        rank_part += live && higher ? 1 : 0;
+        bad_part = bad_part || (live && (ci.w == cj.w || (higher && sqdist3(cj.x, cj.y, cj.z, ci.x, ci.y, ci.z) < cj.w)));
+      }
+      rank_buf[l_] = rank_part;
+      const unsigned long long bm = __ballot(bad_part);
+      const bool bad = (((bm | (bm >> 16) | (bm >> 32) | (bm >> 48)) >> j) & 1ull) != 0ull;
+      const int rank = rank_buf[j] + rank_buf[j + 16] + rank_buf[j + 32] + rank_buf[j + 48];     // lanes 0..15: survivor j
+      const bool mine = l_ < n_a;                             // from here on lane j < n_a speaks for survivor j
+      const int bad_rank = (int)-wave_max_fast(mine && bad ? -(float)rank : -99.f);
+      const int cnt = min(min(n_a, bad_rank), min(KP, M - i));
+      if (mine && rank < cnt) {
+        accb[rank] = make_float4(cj.x, cj.y, cj.z, __int_as_float(cand_q[l_]));
+        picks[i + rank] = cand_q[l_];                    // sorted position; translated to the original index after the loop
       }
       if (l_ == 0) { acc_n = cnt; fb_mx = m0; }
     }
