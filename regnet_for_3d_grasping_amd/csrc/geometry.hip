@@ -1245,6 +1245,9 @@ static int fps_num_cus() {
 #ifndef FPS_CLUSTERS
 #define FPS_CLUSTERS 1   // 1: fps_cluster_kernel (pruning per 64-point cluster); 0: fps_sorted_kernel (per wave)
 #endif
+#ifndef FPS_CLUSTER_MIN_PICKS_SMALL
+#define FPS_CLUSTER_MIN_PICKS_SMALL 512   // 4096 < N <= 8192: runs at least this long take the cluster kernel too
+#endif
 #ifndef FPS_CLUSTER_PICKS
 #define FPS_CLUSTER_PICKS 12
 #endif
@@ -1260,6 +1263,7 @@ extern "C" int64_t regnet_fps_workspace_bytes(int64_t B, int64_t N, int64_t M) {
 #if FPS_CLUSTERS
   if (N > 8192 && N <= FPS_RESIDENT_MAX && M >= 1024 && M <= FPS_CLUSTER_MAX_PICKS)
     return B * N * (int64_t)sizeof(unsigned);   // fps_cluster_kernel: the sort's permutation
+  if (N > 4096 && N <= 8192 && M >= FPS_CLUSTER_MIN_PICKS_SMALL) return B * N * (int64_t)sizeof(unsigned);
 #endif
   if (N <= FPS_RESIDENT_MAX) return 0;
   const int64_t stream_bytes = B * N * (int64_t)sizeof(float), slot_bytes = B * 64;
@@ -1315,8 +1319,10 @@ extern "C" int regnet_fps_f32(const float* xyz, int64_t sb, int64_t sc, int64_t 
   else if (N <= 1024) FPS_CASE(512, 2);
   else if (N <= 2048) FPS_CASE(512, 4);
   else if (N <= 4096) FPS_CASE(512, 8);
-  else if (N <= 6144) FPS_CASE(1024, 6);
-  else if (N <= 8192) FPS_CASE(1024, 8);
+  else if (N <= 6144 && (M < FPS_CLUSTER_MIN_PICKS_SMALL || !FPS_CLUSTERS)) FPS_CASE(1024, 6);
+  else if (N <= 8192 && (M < FPS_CLUSTER_MIN_PICKS_SMALL || !FPS_CLUSTERS)) FPS_CASE(1024, 8);
+  else if (N <= 6144) FPS_SORTED_CASE(6);      // level 2 of the network: 1024 picks of 5120 points
+  else if (N <= 8192) FPS_SORTED_CASE(8);
   // the counting-sort prologue of the sorted kernel costs ~0.7 ms: only worth it for long runs
   else if (M < 1024 && N <= 12288) FPS_CASE(1024, 12);
   else if (M < 1024 && N <= 16384) FPS_CASE(1024, 16);

@@ -42,7 +42,8 @@ def test_argument_checks_without_gpu():
     assert L.regnet_three_nn_f32(None, 0, 0, 0, None, 0, 0, 0, 1, 5, 2, None, None, None) == -1
     assert L.regnet_ball_query_f32(None, 0, 0, 0, None, 0, 0, 0, 1, 5, 5, 0.1, 0, None, None, None) == -1
     assert L.regnet_fps_workspace_bytes(4, 25600, 64) == 0                  # short run: register-resident kernel
-    assert L.regnet_fps_workspace_bytes(4, 8192, 5120) == 0
+    assert L.regnet_fps_workspace_bytes(4, 4096, 2048) == 0
+    assert L.regnet_fps_workspace_bytes(4, 5120, 1024) == 4 * 5120 * 4         # level-2 shape: the cluster kernel as well
     assert L.regnet_fps_workspace_bytes(4, 25600, 5120) == 4 * 25600 * 4       # long run: the Morton permutation
     assert L.regnet_fps_f32(1, 3 * 25600, 25600, 1, 1, 25600, 5120, 1, None, None) == -2   # ... which must be provided
     assert L.regnet_fps_workspace_bytes(4, 51200, 5120) == 4 * 51200 * 4
