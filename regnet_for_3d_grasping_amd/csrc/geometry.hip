@@ -1249,7 +1249,7 @@ static int fps_num_cus() {
 #define FPS_CLUSTER_MIN_PICKS_SMALL 512   // 4096 < N <= 8192: runs at least this long take the cluster kernel too
 #endif
 #ifndef FPS_CLUSTER_PICKS
-#define FPS_CLUSTER_PICKS 12
+#define FPS_CLUSTER_PICKS 8
 #endif
 
 // 8 192 < N <= 25 600 with M >= 1024 (fps_cluster_kernel): N words per scene for the sort's permutation.

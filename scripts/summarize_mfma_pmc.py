@@ -8,7 +8,7 @@ import sys
 
 FAMILY = [("gemm2_kernel<256, 128, 4, 2, 3, 2, true>", "gemm2_kernel<256,128,pool>"), ("gemm2_kernel<256, 128, 4, 2, 3, 2, false>", "gemm2_kernel<256,128>"),
           ("gemm2_kernel<128, 128", "gemm2_kernel<128,128>"), ("sa3_premul_chain_kernel", "sa3_premul_chain_kernel"), ("sa_premul_chain_kernel", "sa_premul_chain_kernel"), ("gemm2_kernel<64, 128", "gemm2_kernel<64,128>"), ("mlp_gemm_kernel<3", "mlp_gemm_kernel<3>"), ("mlp_gemm_kernel<0", "mlp_gemm_kernel<0>"), ("mlp_gemm_kernel", "mlp_gemm_kernel"), ("fp_head_chain_kernel", "fp_head_chain_kernel"),
-          ("sa_chain_kernel", "sa_chain_kernel"), ("fps_sorted_kernel", "fps_sorted_kernel"),
+          ("sa_chain_kernel", "sa_chain_kernel"), ("fps_cluster_kernel", "fps_cluster_kernel"), ("fps_sorted_kernel", "fps_sorted_kernel"),
           ("fps_resident_kernel", "fps_resident_kernel"), ("interp_affine_kernel", "interp_affine_kernel"),
           ("ball_query_grid_kernel", "ball_query_grid_kernel"), ("three_nn_grid_kernel", "three_nn_grid_kernel"),
           ("radius_group_kernel", "radius_group_kernel"), ("gather_max_kernel", "gather_max_kernel"), ("probe<", "mfma_peak_probe")]
