@@ -70,6 +70,42 @@ def test_fps_bit_exact(ext, orc, B, N, M, dup, grid):
         assert torch.equal(got.cpu(), want), "FPS mismatch (N=%d M=%d)" % (N, M)
 
 
+FPS_CLUSTER_CASES = [  # (B, N, M, dup, grid): long runs = fps_cluster_kernel (several exact picks per round, csrc/geometry.hip)
+    (2, 25600, 1500, 0.5, 0.01),     # heavy duplicates + lattice ties: the exact one-pick path in between batched rounds
+    (1, 10000, 1024, 0, 0.2),        # 125 distinct points, 1024 picks: all distances zero after 125 -> the reference repeats its pick
+    (1, 12001, 1100, 0.1, None),     # N not a multiple of the 64-point cluster
+    (1, 8193, 1024, 0, None), (1, 4097, 512, 0.2, 0.03), (2, 8192, 2048, 0, None),
+    (1, 16000, 1200, 0, None), (1, 20000, 8192, 0.05, None),   # 16 / 20 slots per lane; M at the LDS pick buffer's capacity
+    (1, 20480, 8193, 0, None),       # one more: the per-wave kernel (fps_sorted_kernel<20, 4>) takes over
+    (3, 25600, 5120, 0, None),
+]
+
+
+@pytest.mark.parametrize("B,N,M,dup,grid", FPS_CLUSTER_CASES)
+def test_fps_cluster_kernel_bit_exact(ext, orc, B, N, M, dup, grid):
+    x = cloud(900 + N + M, B, N, dup, grid)
+    want = orc.farthest_point_sample(x, M)
+    got = ext.farthest_point_sample(x.to(DEV), M).cpu()
+    assert torch.equal(got, want), "FPS mismatch (N=%d M=%d): first difference at %s" % (
+        N, M, (got != want).nonzero()[:1].tolist())
+    got2 = ext.farthest_point_sample(layouts(x)[2].to(DEV), M).cpu()       # the strided view ScoreNet passes
+    assert torch.equal(got2, want)
+
+
+def test_fps_cluster_kernel_flat_and_collinear_scenes(ext, orc):
+    """Degenerate extents for the extent-driven Morton key (all 12 bits go to one or two axes) at long-run sizes."""
+    rng = np.random.default_rng(19)
+    p = rng.uniform(-1, 1, (1, 14000, 3)).astype(np.float32)
+    p[:, :, 2] = 0.75
+    x = torch.from_numpy(p).transpose(1, 2)
+    assert torch.equal(ext.farthest_point_sample(x.to(DEV), 1500).cpu(), orc.farthest_point_sample(x, 1500))
+    p[:, :, 1] = -0.2
+    x = torch.from_numpy(p).transpose(1, 2)
+    assert torch.equal(ext.farthest_point_sample(x.to(DEV), 1500).cpu(), orc.farthest_point_sample(x, 1500))
+    x = torch.ones(1, 3, 9000) * 0.25                      # zero extent everywhere, every distance zero from the start
+    assert torch.equal(ext.farthest_point_sample(x.to(DEV), 1024).cpu(), orc.farthest_point_sample(x, 1024))
+
+
 def test_fps_all_identical_points(ext, orc):
     x = torch.ones(2, 3, 130) * 0.25
     assert torch.equal(ext.farthest_point_sample(x.to(DEV), 40).cpu(), orc.farthest_point_sample(x, 40))
