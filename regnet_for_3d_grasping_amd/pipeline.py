@@ -59,6 +59,7 @@ def sampling_workgroups_per_scene(num_points):
     return max(1, -(-int(num_points) // SINGLE_CU_POINTS))
 
 
+LEVEL_EVENTS = True            # ForwardPipeline default: per-level readiness events between sampling, geometry and features
 GRAPH_MAX_POINTS = 4 * 25600   # graphs="auto": batches of at most this many points replay hipGraphs (launch-bound shapes)
 
 
@@ -170,6 +171,7 @@ class ForwardPipeline:
         self.fps_group = int(fps_group)   # batches whose level-1 sampling shares one launch; 0 = as many as give 64 scenes (<= 8)
         self.first_launch_groups = max(1, int(first_launch_groups))
         self.geometry_ahead = max(1, int(geometry_ahead))
+        self.level_events = LEVEL_EVENTS  # geometry and features synchronise per network level (see _geometry)
         self.split_chain_tail = True      # see _features   # batches whose ball-query / 3-NN geometry runs ahead of the features
         self.first_launch_batches = None  # what the first sampling launch of the last ``run`` really took (bench.py reports it)
         self._one_sampling_stream = False
@@ -207,7 +209,18 @@ class ForwardPipeline:
         with torch.cuda.stream(stream), torch.no_grad():
             # all three sampling levels: the level-2 / level-3 launches hold a CU per scene too (1.3 + 0.5 ms)
             big = pcs[0] if len(pcs) == 1 else torch.cat(pcs, 0)
-            ctr = self._sample(big)
+            level1_done = None
+            if self.level_events and "_sample" not in self.__dict__:
+                marks = {}
+
+                def after_level(i):
+                    if i == 0:
+                        marks[0] = torch.cuda.Event()
+                        marks[0].record(stream)
+                ctr = self.score_net.sample_levels(big, after_level)
+                level1_done = marks.get(0)
+            else:
+                ctr = self._sample(big)
             done = torch.cuda.Event()
             done.record(stream)
         for c in ctr:
@@ -216,7 +229,8 @@ class ForwardPipeline:
                 c.record_stream(m)
         items, at = [], 0
         for pc in pcs:
-            items.append({"pc": pc, "ctr": [c[at:at + pc.shape[0]] for c in ctr], "fps_done": done})
+            items.append({"pc": pc, "ctr": [c[at:at + pc.shape[0]] for c in ctr], "fps_done": done,
+                          "fps1_done": level1_done})
             at += pc.shape[0]
         return items
 
@@ -290,10 +304,25 @@ class ForwardPipeline:
         if graphs is not None:
             return self._geometry_replay(item, graphs)
         with torch.cuda.stream(self.s_geo), torch.no_grad():
-            self.s_geo.wait_event(item["fps_done"])
-            plan = self._plan(item["pc"], item["ctr"])
-            done = torch.cuda.Event()
-            done.record(self.s_geo)
+            if self.level_events and item.get("fps1_done") is not None and "_plan" not in self.__dict__:
+                # level by level: level 1's ball query needs level 1's sampling only, and every level's geometry carries its own
+                # completion event (PointNet2Seg.forward waits per level) -- the first batch of a run starts its level-1 block
+                # ~2.5 ms earlier (levels 2-3 sampling, their ball queries and the three 3-NN searches run beside it)
+                s_geo = self.s_geo
+
+                def on_level(kind, i, geo):
+                    if geo is None:
+                        s_geo.wait_event(item["fps1_done"] if (kind, i) == ("sa", 0) else item["fps_done"])
+                    else:
+                        geo["ready"] = torch.cuda.Event()
+                        geo["ready"].record(s_geo)
+                plan = self.score_net.plan(item["pc"], item["ctr"], on_level)
+                done = plan["sa"][0]["ready"]
+            else:
+                self.s_geo.wait_event(item["fps_done"])
+                plan = self._plan(item["pc"], item["ctr"])
+                done = torch.cuda.Event()
+                done.record(self.s_geo)
         for t in fused.plan_tensors(plan):
             for m in self.s_mlps:
                 t.record_stream(m)

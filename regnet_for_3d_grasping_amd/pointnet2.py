@@ -62,7 +62,7 @@ class PointNet2Seg(nn.Module):
         with torch.no_grad():
             return fused.sa_sample(self.sa_modules[0], xyz)
 
-    def sample_levels(self, points):
+    def sample_levels(self, points, after_level=None):
         """Furthest point sampling of ALL set-abstraction levels (each level samples the previous level's centroids): the
         part of the geometry whose launches hold whole CUs, separable so that a pipeline can run it for many batches in
         one launch per level.  -> list of (B, M_level) index tensors; pass it to ``plan`` as ``level1_ctr``."""
@@ -75,10 +75,12 @@ class PointNet2Seg(nn.Module):
             for sa in self.sa_modules:
                 ctr = fused.sa_sample(sa, xyz)
                 ctrs.append(ctr)
+                if after_level is not None:
+                    after_level(len(ctrs) - 1)     # (a pipeline records an event here: level 1 is usable before levels 2-3 exist)
                 xyz = torch.gather(xyz, 2, ctr[:, None, :].expand(xyz.shape[0], 3, ctr.shape[1]))
         return ctrs
 
-    def plan(self, points, level1_ctr=None):
+    def plan(self, points, level1_ctr=None, on_level=None):
         """Geometry of a forward pass -- FPS / ball-query / 3-NN indices of every level (``level1_ctr``: the level-1
         sampling from ``sample_level1``, or the list of all levels' from ``sample_levels``, when already computed).  Depends on
         xyz only, so it can be computed ahead of (and concurrently with) the feature pass; hand the
@@ -89,20 +91,29 @@ class PointNet2Seg(nn.Module):
         if not (fused.ENABLED and xyz.is_cuda):
             raise RuntimeError("PointNet2Seg.plan needs GPU tensors")
         with torch.no_grad():
-            return self._plan(xyz, level1_ctr)
+            return self._plan(xyz, level1_ctr, on_level)
 
-    def _plan(self, xyz, level1_ctr):
+    def _plan(self, xyz, level1_ctr, on_level=None):
+        """``on_level(kind, i, geo)`` (kind "sa" / "fp"; geo None before the level's launches, the level's dict after them):
+        where a pipeline waits for a level's sampling and marks the level's geometry ready (geo["ready"], honoured by
+        ``forward(plan=...)``), so that the first set-abstraction block need not wait for the deeper levels' geometry."""
         from . import fused
         levels, sa_geo = [xyz], []
         ctrs = list(level1_ctr) if isinstance(level1_ctr, (list, tuple)) else [level1_ctr]
         for i, sa in enumerate(self.sa_modules):
+            if on_level is not None:
+                on_level("sa", i, None)
             geo = fused.sa_geometry(sa, levels[-1], ctrs[i] if i < len(ctrs) else None)
+            if on_level is not None:
+                on_level("sa", i, geo)
             sa_geo.append(geo)
             levels.append(geo["new_xyz"])
         fp_geo, sparse = [], levels[-1]
         for level, fp in enumerate(self.fp_modules):
             dense = levels[-2 - level]
             fp_geo.append(fused.fp_geometry(fp, dense, sparse))
+            if on_level is not None:
+                on_level("fp", level, fp_geo[-1])
             sparse = dense
         return {"sa": sa_geo, "fp": fp_geo}
 
@@ -111,6 +122,7 @@ class PointNet2Seg(nn.Module):
         xyz_stack, feat_stack = [points[:, :3, :]], [points[:, 3:6, :]]
         for level, sa in enumerate(self.sa_modules):
             if plan is not None:
+                _wait_ready(plan["sa"][level])
                 xyz, feat = sa(xyz_stack[-1], feat_stack[-1], geo=plan["sa"][level])
             else:
                 xyz, feat = sa(xyz_stack[-1], feat_stack[-1])
@@ -121,6 +133,8 @@ class PointNet2Seg(nn.Module):
         sparse_xyz, sparse_feature = xyz_stack[-1], feat_stack[-1]
         for level, fp in enumerate(self.fp_modules):
             dense_xyz = xyz_stack[-2 - level]
+            if plan is not None:
+                _wait_ready(plan["fp"][level])
             if (level == len(self.fp_modules) - 1 and add_channel1 is None and fused.usable(self, dense_xyz)
                     and fused.usable(fp, dense_xyz) and fused.supports_fp(fp, sparse_feature)):
                 # last FP block + head as one chained kernel (csrc/rowchain.hip)
@@ -144,6 +158,13 @@ class PointNet2Seg(nn.Module):
         x = self.bn_score(self.conv_score(self.mlp(sparse_feature)))
         score = self.sigmoid(x.transpose(2, 1).contiguous()).view(B, N)
         return sparse_feature, score
+
+
+def _wait_ready(geo):
+    """A plan level computed on another stream carries the event that marks it complete (pipeline.ForwardPipeline)."""
+    ready = geo.get("ready")
+    if ready is not None:
+        torch.cuda.current_stream().wait_event(ready)
 
 
 def _head_layer(conv, bn, x, relu):

@@ -23,13 +23,13 @@ class ScoreNetwork(nn.Module):
         """Level-1 FPS indices for ``pc``; see PointNet2Seg.sample_level1."""
         return self.extrat_featurePN2.sample_level1(pc[:, :, :6].permute(0, 2, 1))
 
-    def sample_levels(self, pc):
+    def sample_levels(self, pc, after_level=None):
         """FPS indices of every set-abstraction level for ``pc``; see PointNet2Seg.sample_levels."""
-        return self.extrat_featurePN2.sample_levels(pc[:, :, :6].permute(0, 2, 1))
+        return self.extrat_featurePN2.sample_levels(pc[:, :, :6].permute(0, 2, 1), after_level)
 
-    def plan(self, pc, level1_ctr=None):
+    def plan(self, pc, level1_ctr=None, on_level=None):
         """Geometry plan (sampling / grouping / 3-NN indices) for ``pc``; see PointNet2Seg.plan."""
-        return self.extrat_featurePN2.plan(pc[:, :, :6].permute(0, 2, 1), level1_ctr)
+        return self.extrat_featurePN2.plan(pc[:, :, :6].permute(0, 2, 1), level1_ctr, on_level)
 
     def forward(self, pc, pc_score=None, pc_label=None, plan=None):
         points = pc[:, :, :6].permute(0, 2, 1)
