@@ -91,6 +91,18 @@ class _StageGraphs:
             plan = pipe._plan(pc, ctr)
             pipe.score_net(pc, plan=plan)
             cur.synchronize()
+            self._capture_slots(pipe, pc, ctr, slots, fused)
+            torch.cuda.synchronize(dev)
+
+    def _capture_slots(self, pipe, pc, ctr, slots, fused):
+        # No destructor of a stale CUDAGraph may run while a stream captures (hipGraphDestroy is "not permitted when stream is
+        # capturing"; raised from a destructor it terminates the process): garbage graphs -- an earlier pipeline caught in a
+        # reference cycle -- are collected NOW, and the cyclic collector stays off until the last capture has ended.
+        import gc
+        gc.collect()
+        gc_was_enabled = gc.isenabled()
+        gc.disable()
+        try:
             for _ in range(slots):
                 slot = {"pc": pc.clone(), "ctr": [c.clone() for c in ctr]}
                 slot["g_geo"], slot["g_feat"] = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
@@ -105,7 +117,9 @@ class _StageGraphs:
                     fused.TAIL_SINK = old_sink
                 slot["free"] = None     # event: the slot's last feature replay and the copies of its outputs are done
                 self.slots.append(slot)
-            torch.cuda.synchronize(dev)
+        finally:
+            if gc_was_enabled:
+                gc.enable()
 
     def take(self):
         slot = self.slots[self.next % len(self.slots)]

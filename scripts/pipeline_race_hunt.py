@@ -29,11 +29,12 @@ def flat(plan):
 
 bad = 0
 for trial in range(int(os.environ.get("TRIALS", "200"))):
-    pipe = pipeline.ForwardPipeline(net, region_net, with_region=False)
+    # GRAPHS=1: the hipGraph replays of the geometry + feature stages (outputs only); default: launch by launch, plans kept
+    pipe = pipeline.ForwardPipeline(net, region_net, with_region=False, graphs=os.environ.get("GRAPHS", "0") == "1")
     stash = []
     orig_features = pipe._features
     def feat(item, _o=orig_features):
-        stash.append({k: v for k, v in flat(item["plan"]).items()})   # references keep the tensors alive
+        stash.append({k: v for k, v in flat(item["plan"]).items()} if "plan" in item else {})   # references keep the tensors alive
         return _o(item)
     pipe._features = feat
     outs = list(pipe.run(iter(batches)))

@@ -92,3 +92,28 @@ def test_stage_graphs_replay_the_same_bits_and_follow_weight_and_shape_changes()
     # another batch shape in the same run
     mixed = [batches[0], batches[1][:1].contiguous(), batches[2][:1].contiguous(), batches[3]]
     _same_outputs(run(pipe, mixed), run(eager, mixed))
+
+
+def test_stage_graph_capture_survives_stale_graphs_in_reference_cycles():
+    """Pipelines (and their captured graphs) that ended up in reference cycles are destroyed by the cyclic collector at an
+    arbitrary allocation -- if that were in the middle of the next pipeline's stream capture, the graph destructor's
+    hipGraphDestroy would be refused and the exception from a destructor would end the process.  _StageGraphs collects
+    first and keeps the collector off while it captures; here the collector is made eager to provoke the overlap."""
+    import gc
+    from regnet_for_3d_grasping_amd import pipeline, synthetic
+    score_net, region_net = pipeline.build_models(DEV)
+    batches = [synthetic.make_batch(3500 + i, 1, 6144, device=DEV) for i in range(3)]
+    old = gc.get_threshold()
+    gc.set_threshold(20, 2, 2)
+    try:
+        outs = []
+        for trial in range(5):
+            pipe = pipeline.ForwardPipeline(score_net, region_net, with_region=False, graphs=True)
+            pipe.myself = pipe                                   # a cycle: only the cyclic collector can free pipe and its graphs
+            outs.append([o["score"].clone() for o in pipe.run(iter(batches))])
+            torch.cuda.synchronize()
+            assert pipe.graph_replays == len(batches)
+    finally:
+        gc.set_threshold(*old)
+    for o in outs[1:]:
+        assert all(torch.equal(a, b) for a, b in zip(o, outs[0]))
