@@ -983,7 +983,8 @@ __global__ __launch_bounds__(1024) void fps_cluster_kernel(const float* __restri
       rho = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, rho)));   // uniform: an SGPR
       const bool cand = (cm >> l_) & 1ull;
       const float B = wave_max_fast(cand ? v2 : v);
-      const unsigned long long am = m0 > 0.f ? __ballot(cand && v > B) : 0ull;
+      unsigned long long am = m0 > 0.f ? __ballot(cand && v > B) : 0ull;
+      if (__popcll(am) > 16) am = 0ull;   // (more than 16 lanes tied at the maximum: the exact one-pick path; cand_p holds 16)
       // pairwise: the survivors are compacted into LDS (at most 16), lane l looks at the pairs (j = l % 16, i = l / 16 + 4 t):
       // how many survivors precede j (rank), does one of them touch it or equal it (bad)
       const int n_a = (int)__popcll(am);

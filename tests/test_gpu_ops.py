@@ -104,6 +104,11 @@ def test_fps_cluster_kernel_flat_and_collinear_scenes(ext, orc):
     assert torch.equal(ext.farthest_point_sample(x.to(DEV), 1500).cpu(), orc.farthest_point_sample(x, 1500))
     x = torch.ones(1, 3, 9000) * 0.25                      # zero extent everywhere, every distance zero from the start
     assert torch.equal(ext.farthest_point_sample(x.to(DEV), 1024).cpu(), orc.farthest_point_sample(x, 1024))
+    # many EQUAL maxima in different clusters at once (more than the 16 candidates the batched round can hold): a coarse lattice
+    # whose points are all at the same distance from the first pick's neighbours, each lattice site repeated ~6 times
+    g = torch.stack(torch.meshgrid(torch.arange(12.), torch.arange(12.), torch.arange(12.), indexing="ij"), -1).view(-1, 3) * 0.1
+    x = g.repeat(6, 1)[torch.randperm(6 * 1728, generator=torch.Generator().manual_seed(5))].t().contiguous().view(1, 3, -1)
+    assert torch.equal(ext.farthest_point_sample(x.to(DEV), 1500).cpu(), orc.farthest_point_sample(x, 1500))
 
 
 def test_fps_all_identical_points(ext, orc):
