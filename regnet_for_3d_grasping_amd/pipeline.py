@@ -141,13 +141,13 @@ class ForwardPipeline:
     """Software pipeline over a stream of scene batches (inference).
 
     Scenes are independent, and inside one batch the sampling / grouping geometry depends on xyz
-    only.  Level-1 furthest point sampling is a latency-bound chain of 5119 dependent rounds that
-    keeps one CU per scene busy for ~10 ms, while the shared-MLP contraction wants the other ~250
+    only.  Level-1 furthest point sampling is a latency-bound chain of dependent argmax rounds (~880 rounds of
+    ~6 picks since round 3) that keeps one CU per scene busy for ~4 ms (10 ms in rounds 1-2), while the shared-MLP contraction wants the other ~250
     CUs and region grouping needs the host for numpy's RNG.  So four stages run concurrently on five
     (or more) HIP streams, each on a different batch:
 
         s_fps : sample(batches i+2 ..) level-1 FPS of the NEXT GROUP of batches (up to 64 scenes) in one launch, groups
-                                      alternating between two streams: a launch is a ~10 ms latency chain on ONE CU per
+                                      alternating between two streams: a launch is a ~4-5 ms latency chain on ONE CU per
                                       scene, and what it costs the matrix kernels does not grow with its size up to one or
                                       two CUs per shader engine (see _sample_group), so it pays to run it rarely
         s_geo : geometry(batch i+1)   FPS levels 2-3, ball query x3, 3-NN x3
@@ -161,7 +161,7 @@ class ForwardPipeline:
 
     def __init__(self, score_net, region_net, with_region=True, fps_streams=2, mlp_streams=1, fps_group=0,
                  first_launch_groups=1, geometry_ahead=1, graphs="auto"):
-        """``fps_streams``: level-1 sampling launches in flight (each ~10 ms on one CU per scene, whatever the batch
+        """``fps_streams``: level-1 sampling launches in flight (each ~4-5 ms on one CU per scene, whatever the batch
         size).  ``fps_group``: consecutive batches whose level-1 sampling shares one launch (0: as many as give 64 scenes,
         at most 8): +6 % at 8 scenes per batch, +12-15 % at 1 and 4, at the price of reading that many batches ahead.
         ``first_launch_groups``: the FIRST sampling launch of a ``run`` finds the chip idle (nothing can start before its
@@ -211,7 +211,7 @@ class ForwardPipeline:
     def _sample_group(self, pcs):
         """Level-1 sampling of several consecutive batches in ONE launch -> one item per batch.
 
-        A sampling workgroup owns a whole CU for ~10 ms.  The hardware deals the workgroups of every launch to the XCDs and
+        A sampling workgroup owns a whole CU for ~4-5 ms (10 ms when this was measured).  The hardware deals the workgroups of every launch to the XCDs and
         their shader engines in a fixed rotation, in order, so an engine that has lost a CU paces all the others: 8 held
         CUs (one per XCD) cost the matrix kernels as much as 32 (one per engine) -- 12.5 %, measured (DESIGN.md par. 10).
         So the sampling of up to 64 scenes (two per engine) goes into one launch: the same cost while it runs, but it runs
@@ -467,7 +467,7 @@ class ForwardPipeline:
             self.first_launch_batches = None
             while True:
                 # keep the sampling ahead: a new group launch when at most one group's worth of sampled batches is left (a
-                # launch is a ~10 ms latency chain, longer than a step: with one batch per launch two must be in flight).
+                # launch is a latency chain of about half a step (longer than one in rounds 1-2): with one batch per launch two must be in flight).
                 # Cooperative launches (scenes beyond 25 600 points) share one stream, so two of THEM never overlap.
                 while not exhausted and (first_want <= 0 or len(sampled) <= group):
                     pcs = []

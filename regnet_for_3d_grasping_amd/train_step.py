@@ -239,7 +239,7 @@ class ScoreTrainer:
 
 class GeometryPrefetcher:
     """Computes the geometry plan of a batch (every FPS / ball-query / 3-NN index of ScoreNet: functions of xyz only,
-    no gradients) on a side HIP stream, so that the NEXT batch's ~9 ms level-1 sampling chain -- one CU per scene --
+    no gradients) on a side HIP stream, so that the NEXT batch's ~4 ms level-1 sampling chain -- one CU per scene --
     runs underneath the current iteration's forward/backward instead of at the head of its own."""
 
     def __init__(self, score_net):
