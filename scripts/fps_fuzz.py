@@ -1,0 +1,47 @@
+"""Randomised bit-equality of furthest point sampling (all long-run kernels) against the CPU oracle:
+python scripts/fps_fuzz.py [cases] [seed]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from regnet_for_3d_grasping_amd import pn2_ext
+from oracle import pn2_ext_oracle as orc
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+dev = torch.device("cuda:0")
+bad = 0
+for k in range(cases):
+    N = int(rng.integers(4097, 25601))
+    lo = 512 if N <= 8192 else 1024
+    M = int(rng.integers(lo, min(N, 9000) + 1))
+    kind = ["cube", "slab", "blobs", "line", "lattice", "dups", "tiny", "sheet"][k % 8]
+    if kind == "cube":
+        p = rng.uniform(-1, 1, (N, 3))
+    elif kind == "slab":
+        p = rng.uniform(-1, 1, (N, 3)) * np.array([0.4, 0.35, 0.004]) + np.array([0, 0, 0.75])
+    elif kind == "blobs":
+        c = rng.uniform(-1, 1, (12, 3))
+        p = c[rng.integers(0, 12, N)] + rng.normal(0, 0.03, (N, 3))
+    elif kind == "line":
+        t = rng.uniform(0, 1, (N, 1))
+        p = t * np.array([[1.0, 0.5, -0.25]]) + rng.normal(0, 1e-4, (N, 3))
+    elif kind == "lattice":
+        p = np.round(rng.uniform(-0.4, 0.4, (N, 3)) / 0.04) * 0.04
+    elif kind == "dups":
+        p = rng.uniform(-1, 1, (N, 3))
+        d = rng.choice(N, N // 2, replace=False)
+        p[d] = p[rng.integers(0, N, N // 2)]
+    elif kind == "tiny":
+        p = rng.uniform(0, 1e-3, (N, 3)) + 5.0          # millimetre extent far from the origin: coarse float grid
+    else:
+        u = rng.uniform(-1, 1, (N, 2))
+        p = np.stack([u[:, 0], u[:, 1], 0.1 * np.sin(4 * u[:, 0]) * np.cos(3 * u[:, 1])], 1)
+    x = torch.from_numpy(p.astype(np.float32)).t().contiguous().view(1, 3, N)
+    want = orc.farthest_point_sample(x, M)
+    got = pn2_ext.farthest_point_sample(x.to(dev), M).cpu()
+    ok = torch.equal(got, want)
+    bad += 0 if ok else 1
+    print("%-8s N=%5d M=%4d %s" % (kind, N, M, "ok" if ok else "MISMATCH at %s" % (got != want).nonzero()[:1].tolist()), flush=True)
+print("mismatching cases: %d of %d" % (bad, cases))
+sys.exit(1 if bad else 0)
