@@ -906,6 +906,9 @@ __global__ __launch_bounds__(1024) void fps_cluster_kernel(const float* __restri
     out[0] = 0;
   }
   __syncthreads();
+#if FPS_ABLATE == 10
+  return;                                     // measurement build: the prologue alone (sort, loads, cluster spheres)
+#endif
   int i = 1, last_q = -1, last_idx = 0;       // the last pick as a sorted position (or, from the one-pick path, an index)
   float rho = 0.5f;                           // wave 0: candidate threshold as a fraction of the maximum (adaptive)
 #if FPS_ABLATE == 9
