@@ -29,10 +29,23 @@ def get_grasp_allobj(pc, predict_score, params, data_paths, use_theta=True):
     (center_num, score_thre, group_num, r_time_group, group_num_more, r_time_group_more,
      width, height, depth) = params
     center_pc, center_pc_index = _select_score_center(pc, predict_score, center_num, score_thre)
-    pc_group_index, pc_group = _get_group_pc(pc, center_pc, center_pc_index, group_num, width, height, depth,
-                                             r_time_group)
-    pc_group_more_index, pc_group_more = _get_group_pc(pc, center_pc, center_pc_index, group_num_more, width,
-                                                       height, depth, r_time_group_more)
+    if DEVICE_DRAWS and pc.is_cuda:
+        pc_group_index, pc_group = _get_group_pc(pc, center_pc, center_pc_index, group_num, width, height, depth,
+                                                 r_time_group)
+        pc_group_more_index, pc_group_more = _get_group_pc(pc, center_pc, center_pc_index, group_num_more, width,
+                                                           height, depth, r_time_group_more)
+    else:
+        # host draws: BOTH candidate searches first, ONE device->host read for both count tables, then the draws in the
+        # reference's order (all small groups, then all large ones) -- the first resampling runs on the device while the
+        # host draws for the second (one synchronisation and ~0.3 ms of waiting less per batch than group by group)
+        cand_s, count_s = region_ops.radius_candidates(pc, center_pc, group_radius(width, height, depth, r_time_group))
+        cand_m, count_m = region_ops.radius_candidates(pc, center_pc, group_radius(width, height, depth, r_time_group_more))
+        np_random.flush()
+        counts = torch.stack((count_s, count_m)).cpu().numpy()
+        pos = torch.from_numpy(np_random.choice_rows(counts[0], group_num, 0)[0]).to(pc.device)
+        pc_group_index, pc_group = region_ops.resample_groups(pc, cand_s, pos)
+        pos = torch.from_numpy(np_random.choice_rows(counts[1], group_num_more, 0)[0]).to(pc.device)
+        pc_group_more_index, pc_group_more = region_ops.resample_groups(pc, cand_m, pos)
     grasp_labels = None
     if len(data_paths) > 0:
         grasp_labels = _get_center_grasp(center_pc_index, center_pc, data_paths, depth, use_theta)
