@@ -62,9 +62,9 @@ def parse():
     ap.add_argument("--first-launch-groups", type=int, default=4,
                     help="sampling groups the FIRST sampling launch of a run takes (it finds the chip idle); the line reports "
                          "the resulting look-ahead (config.sampling_lookahead_batches) and value_no_lookahead beside the headline")
-    ap.add_argument("--train-steps", type=int, default=5,
+    ap.add_argument("--train-steps", type=int, default=8,
                     help="forward bench only: training iterations (configs[3] shapes, batch --train-batch) timed AFTER the timed "
-                         "region for the line's \"train\" object (3 warm-up iterations first); 0 = skip")
+                         "region for the line's \"train\" object (5 warm-up iterations first); 0 = skip")
     ap.add_argument("--train-batch", type=int, default=8)
     ap.add_argument("--no-lookahead-steps", type=int, default=20,
                     help="steps of the extra pass AFTER the timed region with one sampling launch per batch and no enlarged "
@@ -587,7 +587,7 @@ def main():
         # configs[3]'s training iteration on the same box, after the timed region (every rank takes part: the gradient
         # all-reduce is a collective)
         try:
-            train_line = measure_train(args, rank, world, dev, args.train_steps, 3, args.train_batch)
+            train_line = measure_train(args, rank, world, dev, args.train_steps, 5, args.train_batch)
         except Exception as exc:   # the headline line must survive a failure of this side measurement (all ranks raise alike)
             train_line = {"error": repr(exc)}
 

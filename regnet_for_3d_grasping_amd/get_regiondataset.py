@@ -29,7 +29,9 @@ def get_grasp_allobj(pc, predict_score, params, data_paths, use_theta=True):
     (center_num, score_thre, group_num, r_time_group, group_num_more, r_time_group_more,
      width, height, depth) = params
     center_pc, center_pc_index = _select_score_center(pc, predict_score, center_num, score_thre)
-    if DEVICE_DRAWS and pc.is_cuda:
+    if pc.is_cuda and (DEVICE_DRAWS or pc.shape[0] * pc.shape[1] > BATCHED_SEARCH_MAX_POINTS):
+        # (large batches are throughput-bound: two candidate searches back to back at the start of the stage take CUs from the
+        # next batch's first chain kernel -- same step time, but that launch read 4 % longer; they keep one search per group)
         pc_group_index, pc_group = _get_group_pc(pc, center_pc, center_pc_index, group_num, width, height, depth,
                                                  r_time_group)
         pc_group_more_index, pc_group_more = _get_group_pc(pc, center_pc, center_pc_index, group_num_more, width,
@@ -230,6 +232,7 @@ def group_radius(width, height, depth, r_time):
 # costs 0.83 + 2.37 ms per batch on one workgroup against 1.2 ms of native host draws, so the host path stays the default;
 # the device path is bit-identical (tests/test_gpu_np_random.py) and is what a host-bound deployment would switch on.
 DEVICE_DRAWS = False
+BATCHED_SEARCH_MAX_POINTS = 4 * 25600   # up to here get_grasp_allobj runs both candidate searches before its one read of the counts
 
 
 def _draw_positions(counts, group_num, max_count):

@@ -59,7 +59,12 @@ def sampling_workgroups_per_scene(num_points):
     return max(1, -(-int(num_points) // SINGLE_CU_POINTS))
 
 
-LEVEL_EVENTS = True            # ForwardPipeline default: per-level readiness events between sampling, geometry and features
+# ForwardPipeline default for per-level readiness events between sampling, geometry and features.  On: the first batch of a run
+# starts its level-1 block ~2.5 ms earlier (+0.3-1 % over a 20-step run) -- beside the level-2/3 sampling of every batch of the
+# first launch, which holds up to 160 CUs for 0.8 ms: that one launch of the dominant kernel then takes ~3 ms instead of 1.9 and
+# the run's average launch duration (what `roofline` is computed from) reads 3 % longer.  Off by default: per-kernel durations
+# stay a property of the kernel; a latency-minded caller switches it on.
+LEVEL_EVENTS = False
 GRAPH_MAX_POINTS = 4 * 25600   # graphs="auto": batches of at most this many points replay hipGraphs (launch-bound shapes)
 
 
