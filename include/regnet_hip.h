@@ -47,9 +47,10 @@ int regnet_fps_f32(const float* xyz, int64_t sb, int64_t sc, int64_t sn, int64_t
                    int64_t M, int64_t* index, float* workspace, void* stream);
 /* Scratch bytes regnet_fps_f32 needs for (B,N,M): 0 for N <= 4096 and for short runs (register-resident kernels);
  * B*N*4 for long runs (M >= 512 over 4096 < N <= 8192 points, 1024 <= M <= 8192 over 8192 < N <= 25600 points:
- * fps_cluster_kernel keeps the permutation of its in-kernel Morton sort there) and beyond 25600 points (the
- * reference's `temp` tensor, sampling_kernel.cu:142, or the exchange slots of the multi-workgroup kernel).  The
- * callee initialises it; `workspace` may be NULL when this returns 0.                            */
+ * fps_cluster_kernel keeps the permutation of its in-kernel Morton sort there); beyond 25600 points B*N*4 (rounded
+ * up to 16 bytes: the permutation, or the reference's `temp` tensor, sampling_kernel.cu:142) + 16640 bytes per scene
+ * through which the 2-4 cooperating workgroups of a scene exchange their candidate records.  The callee
+ * initialises it; `workspace` may be NULL when this returns 0.                                   */
 int64_t regnet_fps_workspace_bytes(int64_t B, int64_t N, int64_t M);
 
 /* ---- pn2_ext.ball_query  (csrc/ball_query.h:7-11, ball_query_kernel.cu:87-131) ---------------

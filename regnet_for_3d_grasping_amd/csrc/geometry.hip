@@ -811,13 +811,13 @@ __device__ __forceinline__ void fps_morton_perm(const float* __restrict__ base, 
 #define FPS_SLOT_LOAD(S)                                                                                               \
   if constexpr (S < PPT) {                                                                                             \
     const int q = (S * 16 + wave) * 64 + lane;                                                                         \
-    const bool valid = q < N;                                                                                          \
+    const bool valid = q < Nl;                                                                                         \
     float pz_ = 0.f;                                                                                                   \
     if (valid) {                                                                                                       \
       const int64_t j = perm[q];                                                                                       \
-      px##S = base[j * sn];                                                                                            \
-      py##S = base[sc + j * sn];                                                                                       \
-      pz_ = base[2 * sc + j * sn];                                                                                     \
+      px##S = lbase[j * sn];                                                                                           \
+      py##S = lbase[sc + j * sn];                                                                                      \
+      pz_ = lbase[2 * sc + j * sn];                                                                                    \
       dist##S = __builtin_inff();                                                                                      \
     }                                                                                                                  \
     pzl[q] = pz_;                                                                                                      \
@@ -861,19 +861,37 @@ __device__ __forceinline__ void fps_morton_perm(const float* __restrict__ base, 
     break;
 #define FPS_SLOT_FALLBACK(S)                                                                                           \
   if constexpr (S < PPT) {                                                                                             \
-    if (dist##S == mx) kmin = min(kmin, fps_key((int)perm[S * 1024 + tid], rb_log2));                                  \
+    if (dist##S == mx) kmin = min(kmin, fps_key(n0 + (int)perm[S * 1024 + tid], rb_log2));                             \
   }
 
-template <int PPT, int KP>
+// MULTI: G = 2..4 cooperating workgroups per scene (scenes beyond one CU's registers: 25 600 < N <= 102 400).  Workgroup h owns
+// the slice [h Nh, (h + 1) Nh) of the scene -- its own Morton sort, clusters and records -- and the selection is REPLICATED: per
+// round every workgroup publishes its 64 lane records (2 KB) to global memory behind a round tag, reads the others', merges them
+// in workgroup order and runs the same acceptance on the same values, so all of them accept the same centroids without a second
+// exchange.  One exchange per ROUND (~6 picks) where fps_multi_kernel pays one per pick.  The exact one-pick path exchanges
+// the workgroups' smallest tie-break keys the same way.  Every workgroup of a scene must be resident (the launcher checks
+// G x B against the CU count; a poll gives up after 2^22 tries instead of hanging the device).
+#define FPS_XCHG_FLOATS (2 * 4 * 64 * 8)             // [parity][workgroup][lane][8] per scene
+#define FPS_XCHG_BYTES (FPS_XCHG_FLOATS * 4 + 256)   // + round tags [4] and key words [parity][4]
+template <int PPT, int KP, bool MULTI>
 __global__ __launch_bounds__(1024) void fps_cluster_kernel(const float* __restrict__ xyz, int64_t sb, int64_t sc,
                                                            int64_t sn, int N, int M, int rb_log2,
-                                                           unsigned* __restrict__ perm_ws, int64_t* __restrict__ index) {
+                                                           unsigned* __restrict__ perm_ws, int64_t* __restrict__ index,
+                                                           int G, int B, int Bpad, float* __restrict__ xchg_ws) {
   static_assert(PPT <= 25 && KP >= 1 && KP <= 15, "one lane per cluster of a wave, one DPP row of candidates");
   constexpr int T = 1024, W = 16, CELLS = 4096, C = PPT * 16;
   __shared__ float pzl[T * PPT];     // z of sorted position q (x, y and the running distance are registers)
   unsigned* hist = reinterpret_cast<unsigned*>(pzl);   // the sort's histogram: dead before pzl is filled
   static_assert(T * PPT >= CELLS, "histogram aliases pzl");
-  unsigned* perm = perm_ws + (int64_t)blockIdx.x * N;  // sorted position -> original index: N words of workspace per scene
+  int b = (int)blockIdx.x, h = 0;
+  if constexpr (MULTI) {
+    b = (int)(blockIdx.x % (unsigned)Bpad);           // a scene's workgroups: blockIdx b + h Bpad (one XCD when Bpad % 8 == 0)
+    h = (int)(blockIdx.x / (unsigned)Bpad);
+    if (b >= B) return;
+  }
+  const int Nh = MULTI ? (N + G - 1) / G : N;          // slice length; this workgroup's slice is [n0, n0 + Nl)
+  const int n0 = h * Nh, Nl = min(N - n0, Nh);
+  unsigned* perm = perm_ws + (int64_t)b * N + n0;      // sorted position -> index inside the slice: N words of workspace per scene
   __shared__ float red[6][W];
   __shared__ unsigned wsum[W];
   __shared__ unsigned win_key;
@@ -888,9 +906,13 @@ __global__ __launch_bounds__(1024) void fps_cluster_kernel(const float* __restri
   __shared__ int cand_q[16];         // ... their sorted positions ...
   __shared__ int rank_buf[64];       // ... and the partial ranks of the pairwise pass
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const float* base = xyz + (int64_t)blockIdx.x * sb;
-  int64_t* out = index + (int64_t)blockIdx.x * M;
-  fps_morton_perm<PPT>(base, sc, sn, N, perm, hist, red, wsum);
+  const float* base = xyz + (int64_t)b * sb;
+  const float* lbase = base + (int64_t)n0 * sn;
+  int64_t* out = index + (int64_t)b * M;
+  float* const xch = MULTI ? xchg_ws + (int64_t)b * (FPS_XCHG_BYTES / 4) : nullptr;
+  unsigned* const tags = reinterpret_cast<unsigned*>(xch + FPS_XCHG_FLOATS);                            // [4]
+  unsigned long long* const keyw = reinterpret_cast<unsigned long long*>(xch + FPS_XCHG_FLOATS + 16);   // [2 parities][4]
+  fps_morton_perm<PPT>(lbase, sc, sn, Nl, perm, hist, red, wsum);
 
   FPS_SLOTS(FPS_SLOT_DECL)
   float cqx = 0.f, cqy = 0.f, cqz = 0.f, cR = 0.f, cthr = -1.f, cmax = __builtin_inff();   // lane s: cluster s * 16 + wave
@@ -903,13 +925,14 @@ __global__ __launch_bounds__(1024) void fps_cluster_kernel(const float* __restri
     accb[0] = make_float4(base[0], base[sc], base[2 * sc], __int_as_float(-1));
     acc_n = 1;
     win_key = 0xffffffffu;
-    out[0] = 0;
+    picks[0] = -1;                            // entries < 0: -(original index + 1); >= 0: workgroup << 24 | sorted position
   }
   __syncthreads();
 #if FPS_ABLATE == 10
   return;                                     // measurement build: the prologue alone (sort, loads, cluster spheres)
 #endif
-  int i = 1, last_q = -1, last_idx = 0;       // the last pick as a sorted position (or, from the one-pick path, an index)
+  int i = 1;
+  unsigned round = 0;                         // MULTI: exchange tag (every workgroup of the scene runs the same rounds)
   float rho = 0.5f;                           // wave 0: candidate threshold as a fraction of the maximum (adaptive)
 #if FPS_ABLATE == 9
   const int tstamp_tid = 0;
@@ -966,7 +989,45 @@ __global__ __launch_bounds__(1024) void fps_cluster_kernel(const float* __restri
         v = better ? rr[k].x : v;
       }
       v2 = vmax_f32(v2, y1);
-      const float4 rp = rec_p[gb];
+      float4 rp = rec_p[gb];
+      rp.w = __int_as_float((h << 24) | __float_as_int(rp.w));     // pick code: workgroup << 24 | sorted position
+      if constexpr (MULTI) {
+        // publish this workgroup's 64 lane records, fetch the others', merge in workgroup order (identical in every workgroup)
+        round += 1;
+        float* const slot0 = xch + ((round & 1u) * 4u) * 512u;
+        float* const mine = slot0 + h * 512 + l_ * 8;
+        reinterpret_cast<float4*>(mine)[0] = make_float4(v, v2, rp.x, rp.y);
+        reinterpret_cast<float4*>(mine)[1] = make_float4(rp.z, rp.w, 0.f, 0.f);
+        __threadfence();                                            // the records before the tag
+        if (l_ == 0) __hip_atomic_store(&tags[h], round, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        float bv = -3.f, bv2 = -3.f, rest = -3.f;
+        float4 brp = rp;
+        for (int o = 0; o < G; ++o) {
+          float ov = v, ov2 = v2;
+          float4 orp = rp;
+          if (o != h) {
+            int budget = 1 << 22;
+            while (__hip_atomic_load(&tags[o], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < round && --budget > 0)
+              __builtin_amdgcn_s_sleep(1);
+            const unsigned long long* theirs = reinterpret_cast<const unsigned long long*>(slot0 + o * 512 + l_ * 8);
+            const unsigned long long w0 = __hip_atomic_load(theirs + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long w1 = __hip_atomic_load(theirs + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long w2 = __hip_atomic_load(theirs + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ov = __uint_as_float((unsigned)w0); ov2 = __uint_as_float((unsigned)(w0 >> 32));
+            orp = make_float4(__uint_as_float((unsigned)w1), __uint_as_float((unsigned)(w1 >> 32)),
+                              __uint_as_float((unsigned)w2), __uint_as_float((unsigned)(w2 >> 32)));
+          }
+          const bool better = ov > bv;
+          rest = vmax_f32(rest, better ? bv : ov);
+          bv2 = better ? ov2 : bv2;
+          brp.x = better ? orp.x : brp.x; brp.y = better ? orp.y : brp.y;
+          brp.z = better ? orp.z : brp.z; brp.w = better ? orp.w : brp.w;
+          bv = better ? ov : bv;
+        }
+        v = bv;
+        v2 = vmax_f32(rest, bv2);
+        rp = brp;
+      }
       // Candidates: the lanes above a threshold tau (adaptive: any tau is correct, it only decides how many there are).
       // B bounds every point that is NOT a surviving candidate: the other lanes' best values, the candidates' own second
       // bests, and the candidates that do not beat it.  The survivors A, taken in descending order, are the next picks for as
@@ -1028,7 +1089,6 @@ __global__ __launch_bounds__(1024) void fps_cluster_kernel(const float* __restri
     FPS_T(5);
     const int got = __builtin_amdgcn_readfirstlane(acc_n);
     if (got > 0) {
-      last_q = __builtin_amdgcn_readfirstlane(__float_as_int(accb[got - 1].w));
       i += got;
       continue;
     }
@@ -1040,27 +1100,53 @@ __global__ __launch_bounds__(1024) void fps_cluster_kernel(const float* __restri
       if (kmin != 0xffffffffu) atomicMin(&win_key, kmin);
     }
     __syncthreads();
+    if constexpr (MULTI) {
+      // the smallest key of all workgroups: one 64-bit word each (round << 32 | key), same tag discipline as the records
+      if (tid == 0) {
+        unsigned long long* const kslot = keyw + (round & 1u) * 4u;
+        __hip_atomic_store(&kslot[h], ((unsigned long long)round << 32) | win_key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned kall = win_key;
+        for (int o = 0; o < G; ++o) {
+          if (o == h) continue;
+          unsigned long long wv = 0;
+          int budget = 1 << 22;
+          do {
+            wv = __hip_atomic_load(&kslot[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((unsigned)(wv >> 32) == round) break;
+            __builtin_amdgcn_s_sleep(1);
+          } while (--budget > 0);
+          kall = min(kall, (unsigned)wv);
+        }
+        win_key = kall;
+      }
+      __syncthreads();
+    }
     const unsigned key = win_key;
-    // all distances 0: the reference repeats its last pick
-    const int cur1 = key != 0xffffffffu ? fps_unkey(key, rb_log2) : (last_q >= 0 ? (int)perm[last_q] : last_idx);
     __syncthreads();
     if (tid == 0) {
       win_key = 0xffffffffu;
-      accb[0] = make_float4(base[(int64_t)cur1 * sn], base[sc + (int64_t)cur1 * sn], base[2 * sc + (int64_t)cur1 * sn],
-                            __int_as_float(-1));
+      if (key != 0xffffffffu) {
+        const int cur1 = fps_unkey(key, rb_log2);
+        accb[0] = make_float4(base[(int64_t)cur1 * sn], base[sc + (int64_t)cur1 * sn], base[2 * sc + (int64_t)cur1 * sn],
+                              __int_as_float(-1));
+        picks[i] = -cur1 - 1;             // already an original index
+      } else {
+        picks[i] = picks[i - 1];          // all distances 0: the reference repeats its last pick (accb[0] may stay what it is:
+      }                                   // its distances are all zero already, nothing can change)
       acc_n = 1;
-      picks[i] = -cur1 - 1;               // already an original index
     }
-    last_q = -1;
-    last_idx = cur1;
     i += 1;
     __syncthreads();
   }
-  // the round loop touches no global memory (a store in front of a barrier costs its acknowledgement, ~1 us per round): the
-  // picks wait in LDS as sorted positions and are translated here
-  for (int k = 1 + tid; k < M; k += T) {
+  // the round loop touches no global memory of its own (a store in front of a barrier costs its acknowledgement, ~1 us per
+  // round): the picks wait in LDS as codes and are translated here -- by the workgroup that owns the point
+  for (int k = tid; k < M; k += T) {
     const int v = picks[k];
-    out[k] = v >= 0 ? (int64_t)perm[v] : (int64_t)(-v - 1);
+    if (v < 0) {
+      if (h == 0) out[k] = (int64_t)(-v - 1);
+    } else if ((v >> 24) == h) {
+      out[k] = (int64_t)n0 + (int64_t)perm[v & 0xffffff];
+    }
   }
 }
 
@@ -1249,6 +1335,9 @@ static int fps_num_cus() {
 #ifndef FPS_CLUSTERS
 #define FPS_CLUSTERS 1   // 1: fps_cluster_kernel (pruning per 64-point cluster); 0: fps_sorted_kernel (per wave)
 #endif
+#ifndef FPS_COOP
+#define FPS_COOP 1       // 1: scenes beyond 25 600 points sample with fps_cluster_kernel<.., true> (several picks per exchange)
+#endif
 #ifndef FPS_CLUSTER_MIN_PICKS_SMALL
 #define FPS_CLUSTER_MIN_PICKS_SMALL 512   // 4096 < N <= 8192: runs at least this long take the cluster kernel too
 #endif
@@ -1259,6 +1348,9 @@ static int fps_num_cus() {
 // 8 192 < N <= 25 600 with M >= 1024 (fps_cluster_kernel): N words per scene for the sort's permutation.
 // N > 25 600: 64 bytes of exchange slots per scene for the multi-workgroup kernel, or (scenes that do not fit it) a (B,N)
 // float array of running distances for the streaming kernel.  The callee initialises the workspace.
+static const bool fps_coop_enabled = FPS_CLUSTERS != 0 && FPS_COOP != 0;
+static int64_t fps_xchg_offset_floats(int64_t B, int64_t N) { return (B * N + 3) / 4 * 4; }   // 16-byte aligned behind B x N words
+
 extern "C" int64_t regnet_fps_workspace_bytes(int64_t B, int64_t N, int64_t M) {
   (void)M;
 #ifdef FPS_FORCE_MULTI
@@ -1270,8 +1362,9 @@ extern "C" int64_t regnet_fps_workspace_bytes(int64_t B, int64_t N, int64_t M) {
   if (N > 4096 && N <= 8192 && M >= FPS_CLUSTER_MIN_PICKS_SMALL) return B * N * (int64_t)sizeof(unsigned);
 #endif
   if (N <= FPS_RESIDENT_MAX) return 0;
-  const int64_t stream_bytes = B * N * (int64_t)sizeof(float), slot_bytes = B * 64;
-  return stream_bytes > slot_bytes ? stream_bytes : slot_bytes;
+  // beyond one CU: the streaming kernel's running distances / the cooperative cluster kernel's permutation (B x N words
+  // either way) followed by the cooperative kernels' exchange area
+  return fps_xchg_offset_floats(B, N) * (int64_t)sizeof(float) + B * (int64_t)FPS_XCHG_BYTES;
 }
 
 #define FPS_CASE(T, PPT)                                                                                  \
@@ -1284,8 +1377,14 @@ extern "C" int64_t regnet_fps_workspace_bytes(int64_t B, int64_t N, int64_t M) {
 #if FPS_CLUSTERS
 #define FPS_CLUSTER_LIMIT FPS_CLUSTER_MAX_PICKS
 #define FPS_SORTED_CASE(PPT)                                                                                          \
-  hipLaunchKernelGGL((fps_cluster_kernel<PPT, FPS_CLUSTER_PICKS>), dim3((unsigned)B), dim3(1024), 0, st, xyz, sb, sc, \
-                     sn, (int)N, (int)M, rbl, reinterpret_cast<unsigned*>(workspace), index)
+  hipLaunchKernelGGL((fps_cluster_kernel<PPT, FPS_CLUSTER_PICKS, false>), dim3((unsigned)B), dim3(1024), 0, st, xyz, \
+                     sb, sc, sn, (int)N, (int)M, rbl, reinterpret_cast<unsigned*>(workspace), index, 1, (int)B, (int)B,    \
+                     (float*)nullptr)
+// G cooperating workgroups per scene; the exchange area sits behind the B x N permutation words of the workspace
+#define FPS_COOP_CASE(PPT)                                                                                                \
+  hipLaunchKernelGGL((fps_cluster_kernel<PPT, FPS_CLUSTER_PICKS, true>), dim3((unsigned)(Bpad * G)), dim3(1024), 0, st,   \
+                     xyz, sb, sc, sn, (int)N, (int)M, rbl, reinterpret_cast<unsigned*>(workspace), index, G, (int)B, Bpad, \
+                     workspace + fps_xchg_offset_floats(B, N))
 #else
 #define FPS_CLUSTER_LIMIT (1 << 30)
 #define FPS_SORTED_CASE(PPT) FPS_WAVE_CASE(PPT)
@@ -1340,6 +1439,20 @@ extern "C" int regnet_fps_f32(const float* xyz, int64_t sb, int64_t sc, int64_t 
   else if (N <= 16384) FPS_WAVE_CASE(16);
   else if (N <= 20480) FPS_WAVE_CASE(20);
   else if (N <= FPS_RESIDENT_MAX) FPS_WAVE_CASE(25);
+  else if (fps_coop_enabled && N <= FPS_MULTI_MAX && M >= 1024 && M <= FPS_CLUSTER_MAX_PICKS &&
+           ((N + FPS_RESIDENT_MAX - 1) / FPS_RESIDENT_MAX) * B <= fps_num_cus()) {
+    // several exact picks per round on 2..4 cooperating workgroups per scene (fps_cluster_kernel<.., true>)
+    if (!workspace) return REGNET_ERR_NULL;
+    const int G = (int)((N + FPS_RESIDENT_MAX - 1) / FPS_RESIDENT_MAX);
+    const int Bpad = (int)((B + 7) / 8 * 8);                                       // a scene's workgroups on one XCD
+    const int64_t Nh = (N + G - 1) / G;
+    hipError_t e = hipMemsetAsync(workspace + fps_xchg_offset_floats(B, N), 0, (size_t)B * FPS_XCHG_BYTES, st);   // tags 0 = nothing published
+    if (e != hipSuccess) return (int)e;
+    if (Nh <= 12288) FPS_COOP_CASE(12);
+    else if (Nh <= 16384) FPS_COOP_CASE(16);
+    else if (Nh <= 20480) FPS_COOP_CASE(20);
+    else FPS_COOP_CASE(25);
+  }
   else if (N <= FPS_MULTI_MAX && M < 32768 /* 15-bit round tag */ &&
            ((N + FPS_RESIDENT_MAX - 1) / FPS_RESIDENT_MAX) * B <= fps_num_cus()) {
     if (!workspace) return REGNET_ERR_NULL;

@@ -12,7 +12,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 dev = torch.device("cuda:0")
 bad = 0
 for k in range(cases):
-    N = int(rng.integers(4097, 25601))
+    N = int(rng.integers(4097, 25601)) if k % 3 else int(rng.integers(25601, 102401))    # every third case: 2-4 cooperating workgroups
     lo = 512 if N <= 8192 else 1024
     M = int(rng.integers(lo, min(N, 9000) + 1))
     kind = ["cube", "slab", "blobs", "line", "lattice", "dups", "tiny", "sheet"][k % 8]

@@ -146,6 +146,20 @@ def test_fps_multi_workgroup_path_above_resident_limit(ext, orc, B, N, M):
     assert torch.equal(ext.farthest_point_sample(x.to(DEV), M).cpu(), orc.farthest_point_sample(x, M))
 
 
+@pytest.mark.parametrize("B,N,M,dup,grid", [(2, 51200, 5120, 0, None), (1, 30000, 1500, 0.2, None), (1, 76800, 2048, 0, None),
+                                           (1, 102400, 1024, 0, None), (2, 40000, 1200, 0.4, 0.02), (1, 25601, 1024, 0, None),
+                                           (1, 50000, 1300, 0, 0.25)])
+def test_fps_cooperative_cluster_kernel_bit_exact(ext, orc, B, N, M, dup, grid):
+    """Scenes beyond 25 600 points with long runs: 2..4 cooperating workgroups, several exact picks per exchange
+    (fps_cluster_kernel<.., true>): slices of unequal length, duplicates and lattice ties across the slice boundaries (the
+    exact one-pick path exchanges keys), more picks than distinct points (every distance zero: the reference repeats)."""
+    x = cloud(1900 + N + M, B, N, dup, grid)
+    want = orc.farthest_point_sample(x, M)
+    got = ext.farthest_point_sample(x.to(DEV), M).cpu()
+    assert torch.equal(got, want), "FPS mismatch (N=%d M=%d): first difference at %s" % (
+        N, M, (got != want).nonzero()[:1].tolist())
+
+
 def test_fps_multi_workgroup_ties_and_duplicates(ext, orc):
     """Lattice points (many exactly equal distances) and duplicated points across the workgroup boundary."""
     g = torch.stack(torch.meshgrid(torch.arange(40.), torch.arange(40.), torch.arange(20.), indexing="ij"), -1).view(1, -1, 3)
