@@ -200,6 +200,9 @@ __device__ __forceinline__ unsigned spread4(unsigned v) {  // 4 bits -> every th
   return (v & 1u) | ((v & 2u) << 2) | ((v & 4u) << 4) | ((v & 8u) << 6);
 }
 
+#if FPS_ABLATE == 11
+__device__ unsigned long long fps_dbg[8];
+#endif
 #if FPS_ABLATE == 9
 __device__ unsigned long long fps_dbg[8];
 #define FPS_T(k) do { if (blockIdx.x == 0) { unsigned long long t_ = __builtin_readcyclecounter(); if (tid == tstamp_tid) atomicAdd(&fps_dbg[k], t_ - tprev); tprev = t_; } } while (0)
@@ -933,6 +936,9 @@ __global__ __launch_bounds__(1024) void fps_cluster_kernel(const float* __restri
 #endif
   int i = 1;
   unsigned round = 0;                         // MULTI: exchange tag (every workgroup of the scene runs the same rounds)
+#if FPS_ABLATE == 11
+  const unsigned long long t_loop0 = __builtin_readcyclecounter();
+#endif
   float rho = 0.5f;                           // wave 0: candidate threshold as a fraction of the maximum (adaptive)
 #if FPS_ABLATE == 9
   const int tstamp_tid = 0;
@@ -1088,6 +1094,13 @@ __global__ __launch_bounds__(1024) void fps_cluster_kernel(const float* __restri
     __syncthreads();
     FPS_T(5);
     const int got = __builtin_amdgcn_readfirstlane(acc_n);
+#if FPS_ABLATE == 11   // measurement build: when (cycle counter since the loop began) the run passes 32 / 64 / 128 / 256 / 1024 picks
+    if (blockIdx.x == 0 && tid == 0 && got > 0) {
+      const int marks[5] = {32, 64, 128, 256, 1024};
+      for (int k = 0; k < 5; ++k)
+        if (i < marks[k] && i + got >= marks[k]) fps_dbg[k] = __builtin_readcyclecounter() - t_loop0;
+    }
+#endif
     if (got > 0) {
       i += got;
       continue;

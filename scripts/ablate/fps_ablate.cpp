@@ -31,6 +31,14 @@ int main(int argc, char** argv) {
   std::vector<int64_t> out((size_t)B * M);
   hipMemcpy(out.data(), idx, out.size() * 8, hipMemcpyDeviceToHost);
   long long cs = 0; for (auto v : out) cs += v;
+#if FPS_ABLATE == 11
+  {
+    unsigned long long dbg[8];
+    hipMemcpyFromSymbol(dbg, HIP_SYMBOL(fps_dbg), sizeof(dbg));
+    const int marks[5] = {32, 64, 128, 256, 1024};
+    for (int k = 0; k < 5; ++k) printf("  pick %4d reached after %10.0f counter ticks of the round loop\n", marks[k], (double)dbg[k]);
+  }
+#endif
 #if FPS_ABLATE == 9
   unsigned long long dbg[8];
   hipMemcpyFromSymbol(dbg, HIP_SYMBOL(fps_dbg), sizeof(dbg));
