@@ -125,3 +125,90 @@ def make_grasp_labels(scene, seed, every=20):
     frame[:, :3, 0], frame[:, :3, 1], frame[:, :3, 2], frame[:, :3, 3] = approach, axis_y, axis_z, xyz[obj]
     frame[:, 3, 3] = 1.0
     return {"frame": frame.astype(np.float32), "antipodal_score": rng.uniform(0, 1, G).astype(np.float32)}
+
+
+def _bn_input(bn, y):
+    """Invert an eval-mode BatchNorm: its output ``y`` (rows, channels) -> the convolution output it was fed."""
+    std = torch.sqrt(bn.running_var + bn.eps)
+    return (y - bn.bias) / bn.weight * std + bn.running_mean
+
+
+def _standardise(bn, x, weight, bias, channels=None):
+    """Running statistics := those of ``x`` (rows, channels), affine := (weight, bias), on ``channels`` (default all)."""
+    sel = slice(None) if channels is None else channels
+    with torch.no_grad():
+        bn.running_mean[sel] = x.mean(0)[sel]
+        bn.running_var[sel] = x.var(0, unbiased=False)[sel]
+        bn.weight[sel] = torch.as_tensor(weight, dtype=bn.weight.dtype, device=bn.weight.device).expand_as(bn.weight)[sel]
+        bn.bias[sel] = torch.as_tensor(bias, dtype=bn.bias.dtype, device=bn.bias.device).expand_as(bn.bias)[sel]
+
+
+REGION_CALIBRATION_KEYS = tuple("%s.%s.%s" % (net, bn, leaf)
+                                for net, bn in (("extrat_feature_region", "bn_cls4"), ("extrat_feature_region", "bn_reg4"),
+                                                ("extrat_feature_refine", "bn_formal_cls3"),
+                                                ("extrat_feature_refine", "bn_formal_reg3"))
+                                for leaf in ("weight", "bias", "running_mean", "running_var"))
+
+
+def calibrate_region_head(region_net, run, lift=0.008, spread=(0.12, 0.15, 0.05), refine_spread=0.05):
+    """Make a seeded ``GripperRegionNetwork`` decode to grasps whose closing box actually holds points, so that the
+    refine stage runs (gripper_region_network.py:333: ``if len(gripper_mask) >= 2``) and its class head keeps a share
+    of them.  ``run()`` pushes the calibration batch through ``region_net`` (called twice).
+
+    With purely random weights the decoded grasps point anywhere, no crop has more than 5 points and the third network
+    of BASELINE.json's configs[2] is a no-op.  As ``calibrate_score_head`` does for the scores, only the LAST BatchNorm
+    of each branch is rewritten -- running statistics := the statistics of its input on the calibration batch (read
+    back through the module outputs, so it works on the reference's modules and on the fused heads alike), affine:
+      * anchor class (``bn_cls4``, pointnet2.py:148,181): (1, 0) -> all four anchors get picked;
+      * stage-2 regression (``bn_reg4``, :156,185), per anchor ``a``: centre (ch 0-2) ~ spread[0] around
+        (0, 0, lift / radius) -> the decoded centre floats ~``lift`` metres above its centre point ("up" is +z; a share
+        sinks below the surface and stays invalid, so both branches of :532-544 stay exercised); closing axis (ch 3-5)
+        ~ spread[1] around (1,0,0) - template_a -> horizontal; theta (ch 6) ~ spread[2] around -0.5 -> theta = -pi/2 ->
+        approach = -z (:466-493); the score channels (7+) keep their seeded affine;
+      * refine class (``bn_formal_cls3``, :214,244): (1, 0) -> both classes occur; refine regression
+        (``bn_formal_reg3``, :219,248): (refine_spread, 0).
+    Returns {state_dict key: tensor} of the sixteen tensors it wrote (``REGION_CALIBRATION_KEYS``) -- fixtures store them
+    (tests/golden/make_golden_refine.py) and tests load them instead of re-deriving them from fp32 statistics."""
+    head, refine = region_net.extrat_feature_region, region_net.extrat_feature_refine
+    A, C = region_net.anchor_number, region_net.reg_channel
+    grabbed = {}
+    h1 = head.register_forward_hook(lambda m, i, o: grabbed.__setitem__("region", [t.detach() for t in o[:2]]))
+    h2 = refine.register_forward_hook(lambda m, i, o: grabbed.__setitem__("refine", [t.detach() for t in o[:2]]))
+    try:
+        run()
+        x_cls, x_reg = grabbed["region"]
+        dev = x_cls.device
+        _standardise(head.bn_cls4, _bn_input(head.bn_cls4, x_cls), 1.0, 0.0)
+        # channels 7+ went through a sigmoid on their way out and keep their seeded affine
+        reg_ch = (torch.arange(A * C, device=dev) % C) < 7
+        x_reg = x_reg.reshape(-1, A * C)
+        y = torch.where(reg_ch.view(1, -1), x_reg, torch.zeros_like(x_reg))
+        tmpl = region_net.templates.detach().float().to(dev).view(A, 4)
+        w = torch.zeros(A, C, device=dev)
+        b = torch.zeros(A, C, device=dev)
+        w[:, 0:3], w[:, 3:6], w[:, 6] = spread[0], spread[1], spread[2]
+        b[:, 2] = lift / float(region_net.radius)
+        b[:, 3:6] = torch.tensor([1.0, 0.0, 0.0], device=dev).view(1, 3) - tmpl[:, :3]
+        b[:, 6] = -0.5 - tmpl[:, 3]
+        _standardise(head.bn_reg4, _bn_input(head.bn_reg4, y), w.view(-1), b.view(-1), channels=reg_ch)
+        grabbed.pop("refine", None)
+        run()
+        if "refine" not in grabbed:
+            raise RuntimeError("calibrate_region_head: fewer than 2 valid crops on the calibration batch")
+        r_cls, r_reg = grabbed["refine"]
+        _standardise(refine.bn_formal_cls3, _bn_input(refine.bn_formal_cls3, r_cls), 1.0, 0.0)
+        _standardise(refine.bn_formal_reg3, _bn_input(refine.bn_formal_reg3, r_reg), refine_spread, 0.0)
+    finally:
+        h1.remove()
+        h2.remove()
+    state = region_net.state_dict()
+    return {k: state[k].detach().clone() for k in REGION_CALIBRATION_KEYS}
+
+
+def apply_region_calibration(region_net, constants):
+    """Load what ``calibrate_region_head`` returned (tensors or nested lists, e.g. from a fixture's JSON)."""
+    state = region_net.state_dict()
+    with torch.no_grad():
+        for k in REGION_CALIBRATION_KEYS:
+            state[k].copy_(torch.as_tensor(constants[k], dtype=state[k].dtype).to(state[k].device))
+    return region_net

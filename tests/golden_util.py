@@ -262,3 +262,37 @@ def build_regionnet_full(m, device="cpu"):
                                reg_channel=cfg["reg_channel"])
     net.load_state_dict(synthetic.seeded_state_dict(net, cfg["region_weights_seed"]))
     return net.to(device).eval()
+
+
+# ---- stage S9: configs[2] with the refine stage running (tests/golden/make_golden_refine.py -> s9_*) ----------------
+def meta_refine():
+    with open(os.path.join(GOLDEN, "s9_meta.json")) as f:
+        return json.load(f)
+
+
+def build_regionnet_refine(m7, m9, device="cpu"):
+    """The S7 region network with S9's calibrated last BatchNorms (the constants the generator derived on the REFERENCE's
+    module, loaded -- not re-derived)."""
+    net = build_regionnet_full(m7, "cpu")
+    synthetic.apply_region_calibration(net, m9["region_calibration"])
+    return net.to(device).eval()
+
+
+class CropSpy:
+    """Records what ``get_gripper_region_transform`` returns inside ``GripperRegionNetwork.refine_forward`` and, when
+    ``forced`` holds the reference's stage-2 grasps, teacher-forces the crop with them (as test_s3 does: fp32 noise in
+    ``next_grasp`` must not move a point across a box face); the grasps the network itself decoded are kept in ``own``."""
+
+    def __init__(self, monkeypatch, grn, forced=None):
+        self.calls, self.own, self.forced = [], [], forced
+        orig = grn.get_gripper_region_transform
+
+        def spy(group_points, group_index, grasp, *a, **k):
+            self.own.append(grasp.detach().clone())
+            if self.forced is not None:
+                want = self.forced[len(self.calls)]
+                grasp = torch.as_tensor(want, dtype=grasp.dtype).to(grasp.device)
+            out = orig(group_points, group_index, grasp, *a, **k)
+            self.calls.append({"index_inall": out[2].detach().clone(), "valid": out[3].detach().clone()})
+            return out
+        monkeypatch.setattr(grn, "get_gripper_region_transform", spy)

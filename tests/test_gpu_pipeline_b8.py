@@ -68,8 +68,36 @@ class _Recorder:
                     assert aux_sha == exp["aux_sha256"][scene], "%s %s: count mismatch, scene %d" % (exp["op"], exp["shape"], scene)
 
 
+def _teacher_forced(ref_score, orders, np_seed):
+    """``ForwardPipeline`` whose region stage of batch k sees the REFERENCE's scores of its scenes (the HIP scores, checked
+    separately, are within 1e-4 of them, which moves a few of the 200 000 points across the 0.5 threshold) and a per-batch
+    numpy seed (as the fixture generators)."""
+    from regnet_for_3d_grasping_amd import np_random, pipeline
+
+    class TeacherForced(pipeline.ForwardPipeline):
+        n_region = 0
+        draws = []
+
+        def _region(self, item):
+            k = TeacherForced.n_region
+            TeacherForced.n_region += 1
+            item["hip_score"] = item["score"]
+            with torch.cuda.stream(self.s_reg):
+                self.s_reg.wait_event(item["mlp_done"])
+                item["score"] = ref_score[torch.tensor(orders[k], device=DEV)].contiguous()
+            np.random.seed(np_seed + k)
+            hip_score = item["hip_score"]
+            out = super()._region(item)
+            out["done"].synchronize()
+            np_random.flush()               # the region stages of a run keep numpy's generator on the device
+            TeacherForced.draws.append(int(np.random.randint(0, 2 ** 31 - 1)))
+            out["hip_score"] = hip_score
+            return out
+    return TeacherForced
+
+
 def test_config2_batch8_pipeline_against_reference_fixtures(monkeypatch):
-    from regnet_for_3d_grasping_amd import np_random, pipeline, synthetic
+    from regnet_for_3d_grasping_amd import synthetic
     import regnet_for_3d_grasping_amd.pn2_utils.function as fn
     m7, m8 = gu.meta_full(), _meta8()
     cfg = m8["cfg"]
@@ -81,29 +109,7 @@ def test_config2_batch8_pipeline_against_reference_fixtures(monkeypatch):
     pc = synthetic.make_batch(cfg["scene_seed"], cfg["B"], cfg["N"]).to(DEV)
     rec = _Recorder(monkeypatch, fn.pn2_ext, [s for o in orders for s in o])
 
-    class TeacherForced(pipeline.ForwardPipeline):
-        """The region stage of batch k sees the REFERENCE's scores of its scenes (the HIP scores, checked separately, are
-        within 1e-4 of them, which moves a few of the 200 000 points across the 0.5 threshold) and a per-batch numpy seed
-        (as the fixture generator)."""
-        n_region = 0
-        draws = []
-
-        def _region(self, item):
-            k = TeacherForced.n_region
-            TeacherForced.n_region += 1
-            item["hip_score"] = item["score"]
-            with torch.cuda.stream(self.s_reg):
-                self.s_reg.wait_event(item["mlp_done"])
-                item["score"] = ref_score[torch.tensor(orders[k], device=DEV)].contiguous()
-            np.random.seed(cfg["np_seed"] + k)
-            hip_score = item["hip_score"]
-            out = super()._region(item)
-            out["done"].synchronize()
-            np_random.flush()               # the region stages of a run keep numpy's generator on the device
-            TeacherForced.draws.append(int(np.random.randint(0, 2 ** 31 - 1)))
-            out["hip_score"] = hip_score
-            return out
-
+    TeacherForced = _teacher_forced(ref_score, orders, cfg["np_seed"])
     pipe = TeacherForced(net, rnet)                         # default grouping = the bench path
     outs = list(pipe.run(iter([pc[o].contiguous() for o in orders])))
     torch.cuda.synchronize()
@@ -149,3 +155,52 @@ def test_scores_against_the_float64_evaluation():
     print("HIP vs float64 evaluation: max %.3e mean %.3e (reference vs float64: max %.3e)" % (
         err.max(), err.mean(), float(truth["reference_max_abs_err"].max())))
     assert err.max() <= ATOL
+
+
+def test_config2_refine_stage_runs_against_reference_fixtures(monkeypatch):
+    """configs[2] with its THIRD network running: S9 (tests/golden/make_golden_refine.py) -- the S8 scenes with a calibrated
+    region head, ~450 valid crops of 512 and ~225 class-1 grasps per batch -- through ``ForwardPipeline`` (the bench
+    path; the bench uses the same calibration).  Per batch: scores as S8; centres / groups bit-exact; the stage-2 grasps
+    the HIP heads decoded within 1e-4 of the reference's; then, teacher-forced with the reference's stage-2 grasps (as
+    test_s3: fp32 noise in a decoded frame must not move a point across a box face): valid crop ids, the 64 scene
+    indices of every crop (array + SHA-256), numpy's stream position after the crop draws, ``final_mask`` /
+    ``final_mask_sthre`` (the refine class / score selections), ``select_grasp_class / score`` within 1e-4, keep counts.
+    (gripper_region_network.py:311-359, pointnet2.py:227-254.)"""
+    from regnet_for_3d_grasping_amd import synthetic
+    import regnet_for_3d_grasping_amd.gripper_region_network as grn
+    m7, m9 = gu.meta_full(), gu.meta_refine()
+    cfg = m9["cfg"]
+    exp = gu.load("s9_refine_b8.npz")
+    orders = cfg["orders"]
+    ref_score = torch.from_numpy(gu.load("s8_b8_25600.npz")["score"]).to(DEV)
+    net = gu.build_scorenet_full(m7, DEV)
+    rnet = gu.build_regionnet_refine(m7, m9, DEV)
+    pc = synthetic.make_batch(cfg["scene_seed"], cfg["B"], cfg["N"]).to(DEV)
+    spy = gu.CropSpy(monkeypatch, grn, forced=[exp["b%d_next_grasp" % k] for k in range(len(orders))])
+    TeacherForced = _teacher_forced(ref_score, orders, cfg["np_seed"])
+    pipe = TeacherForced(net, rnet)
+    outs = list(pipe.run(iter([pc[o].contiguous() for o in orders])))
+    torch.cuda.synchronize()
+    assert len(outs) == len(orders) == len(spy.calls)
+    worst = 0.0
+    for k, (o, out) in enumerate(zip(orders, outs)):
+        b, p = m9["batches"][k], "b%d_" % k
+        np.testing.assert_array_equal(out["center_pc_index"].cpu().numpy(), exp[p + "center_pc_index"])
+        assert gu.sha(out["pc_group_index"].long()) == b["pc_group_index_sha256"]
+        assert gu.sha(out["pc_group_more_index"].long()) == b["pc_group_more_index_sha256"]
+        np.testing.assert_array_equal(out["true_mask"].cpu().numpy(), exp[p + "true_mask"])
+        assert [int(v) for v in out["keep_per_scene"]] == b["keep2"]
+        np.testing.assert_allclose(out["next_grasp"].cpu().numpy(), exp[p + "next_grasp"], rtol=0.0, atol=ATOL)
+        np.testing.assert_allclose(spy.own[k].cpu().numpy(), exp[p + "next_grasp"], rtol=0.0, atol=ATOL)
+        worst = max(worst, float(np.abs(spy.own[k].cpu().numpy() - exp[p + "next_grasp"]).max()))
+        call = spy.calls[k]
+        np.testing.assert_array_equal(call["valid"].cpu().numpy(), exp[p + "crop_valid"])
+        np.testing.assert_array_equal(call["index_inall"].cpu().numpy(), exp[p + "crop_index_inall"])
+        assert gu.sha(call["index_inall"].long()) == b["crop_index_inall_sha256"]
+        assert TeacherForced.draws[k] == b["np_draw_after"], "numpy stream position after batch %d" % k
+        assert out["select_grasp_class"] is not None and b["refine_ran"]
+        np.testing.assert_array_equal(out["final_mask"].cpu().numpy(), exp[p + "final_mask"])
+        np.testing.assert_allclose(out["select_grasp_class"].cpu().numpy(), exp[p + "select_grasp_class"], rtol=0.0, atol=ATOL)
+        np.testing.assert_allclose(out["select_grasp_score"].cpu().numpy(), exp[p + "select_grasp_score"], rtol=0.0, atol=ATOL)
+        assert out["select_grasp_class"].shape[0] == sum(b["keep3"]) > 0
+    print("configs[2] B=8 with the refine stage: stage-2 grasps max abs err vs reference %.3e" % worst)
