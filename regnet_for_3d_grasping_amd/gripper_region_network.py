@@ -228,6 +228,7 @@ class GripperRegionNetwork(nn.Module):
             pc_group_more_xyz[true_mask], pc_group_more_index.view(-1, N_G_M)[true_mask], next_grasp,
             self.gripper_number, gripper_params, points_too=False)
         out = [None, None, None, None, None, (None, None), (None, None), next_gt]
+        self.last_valid_crops = int(len(gripper_mask))    # rows of the refine network in this call (host-known, no sync)
         if len(gripper_mask) >= 2:
             scene = torch.arange(B, device=true_mask.device).view(-1, 1).repeat(1, N_C).view(-1)[true_mask]
             rows = (index_inall.long() + scene.view(-1, 1) * N)[gripper_mask]

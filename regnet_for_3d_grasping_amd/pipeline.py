@@ -394,7 +394,8 @@ class ForwardPipeline:
                                           GRIPPER_PARAMS, None, [])
                 out.update(center_pc_index=center_idx, pc_group_index=g_idx, pc_group_more_index=gm_idx,
                            next_grasp=res[0], keep_per_scene=res[1], true_mask=res[2], select_grasp_class=res[6],
-                           select_grasp_score=res[7], final_mask=res[11])
+                           select_grasp_score=res[7], final_mask=res[11],
+                           valid_crops=getattr(self.region_net, "last_valid_crops", None))
             done = torch.cuda.Event()
             done.record(self.s_reg)
         if not self.with_region:
