@@ -677,7 +677,13 @@ def main():
                            "valid_crops_per_step": (None if any(r[1] is None for r in refine_stats) else
                                                     round(sum(r[1] for r in refine_stats) / len(refine_stats), 1)),
                            "class1_grasps_per_step": round(sum(r[2] for r in refine_stats) / len(refine_stats), 1),
-                           "steps_with_refine": sum(1 for r in refine_stats if r[2] > 0 or (r[1] or 0) >= 2)},
+                           "steps_with_refine": sum(1 for r in refine_stats if r[2] > 0 or (r[1] or 0) >= 2),
+                           # launches of the refine network's own kernels in the timed region (their row count -- the
+                           # valid crops of the step -- varies, so the per-shape list below holds one entry per count)
+                           "kernel_calls": {"gather_max G64 (crop features + MaxPool1d(64))":
+                                            sum(c for (n, m), (_, c) in agg.items() if n == "gather_max" and " G64 " in m),
+                                            "mlp_layer K384 N1024 (conv_formal)":
+                                            sum(c for (n, m), (_, c) in agg.items() if n == "mlp_layer" and " K384 N1024" in m)}},
                        "switches": args.set or None,
                        "hip_graphs": bool(graph_replays),
                        "scorenet_gflop_per_scene": SCORENET_GFLOP_PER_SCENE.get(args.points),
