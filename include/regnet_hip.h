@@ -49,9 +49,15 @@ int regnet_fps_f32(const float* xyz, int64_t sb, int64_t sc, int64_t sn, int64_t
  * B*N*4 for long runs (M >= 512 over 4096 < N <= 8192 points, 1024 <= M <= 8192 over 8192 < N <= 25600 points:
  * fps_cluster_kernel keeps the permutation of its in-kernel Morton sort there); beyond 25600 points B*N*4 (rounded
  * up to 16 bytes: the permutation, or the reference's `temp` tensor, sampling_kernel.cu:142) + 16640 bytes per scene
- * through which the 2-4 cooperating workgroups of a scene exchange their candidate records.  The callee
+ * through which the 2-4 cooperating workgroups of a scene exchange their candidate records + 256 bytes (status word).  The callee
  * initialises it; `workspace` may be NULL when this returns 0.                                   */
 int64_t regnet_fps_workspace_bytes(int64_t B, int64_t N, int64_t M);
+/* Byte offset, inside that workspace, of the launch's 32-bit status word, or -1 when the kernel (B,N,M) selects has
+ * none (every single-workgroup kernel).  The cooperative kernels (N > 25600) poll each other's exchange slots with a
+ * bounded budget; a workgroup whose partner never answered ORs bit 0 into the word and stops sampling -- `index` is
+ * then incomplete.  The callee zeroes the word; the caller reads it once the stream has passed the launch (the Python
+ * binding accumulates it into a per-device flag and raises lazily: pn2_ext.raise_if_fps_failed).                      */
+int64_t regnet_fps_status_offset_bytes(int64_t B, int64_t N, int64_t M);
 
 /* ---- pn2_ext.ball_query  (csrc/ball_query.h:7-11, ball_query_kernel.cu:87-131) ---------------
  * xyz (B,3,N1) strided, centroids (B,3,N2) strided -> index (B,N2,K) int64, count (B,N2) int64.

@@ -876,6 +876,9 @@ __device__ __forceinline__ void fps_morton_perm(const float* __restrict__ base, 
 // G x B against the CU count; a poll gives up after 2^22 tries instead of hanging the device).
 #define FPS_XCHG_FLOATS (2 * 4 * 64 * 8)             // [parity][workgroup][lane][8] per scene
 #define FPS_XCHG_BYTES (FPS_XCHG_FLOATS * 4 + 256)   // + round tags [4] and key words [parity][4]
+#define FPS_STATUS_BYTES 256                         // behind the B scenes' areas: ONE status word per launch (bit 0: a poll's
+                                                     // budget ran out -- a partner workgroup was not resident / lost)
+#define FPS_LOST_KEY 0xfffffffeu                     // win_key value that ends the round loop (no point has this key)
 template <int PPT, int KP, bool MULTI>
 __global__ __launch_bounds__(1024) void fps_cluster_kernel(const float* __restrict__ xyz, int64_t sb, int64_t sc,
                                                            int64_t sn, int N, int M, int rb_log2,
@@ -915,6 +918,7 @@ __global__ __launch_bounds__(1024) void fps_cluster_kernel(const float* __restri
   float* const xch = MULTI ? xchg_ws + (int64_t)b * (FPS_XCHG_BYTES / 4) : nullptr;
   unsigned* const tags = reinterpret_cast<unsigned*>(xch + FPS_XCHG_FLOATS);                            // [4]
   unsigned long long* const keyw = reinterpret_cast<unsigned long long*>(xch + FPS_XCHG_FLOATS + 16);   // [2 parities][4]
+  unsigned* const status = MULTI ? reinterpret_cast<unsigned*>(xchg_ws + (int64_t)B * (FPS_XCHG_BYTES / 4)) : nullptr;
   fps_morton_perm<PPT>(lbase, sc, sn, Nl, perm, hist, red, wsum);
 
   FPS_SLOTS(FPS_SLOT_DECL)
@@ -997,6 +1001,7 @@ __global__ __launch_bounds__(1024) void fps_cluster_kernel(const float* __restri
       v2 = vmax_f32(v2, y1);
       float4 rp = rec_p[gb];
       rp.w = __int_as_float((h << 24) | __float_as_int(rp.w));     // pick code: workgroup << 24 | sorted position
+      bool lost = false;
       if constexpr (MULTI) {
         // publish this workgroup's 64 lane records, fetch the others', merge in workgroup order (identical in every workgroup)
         round += 1;
@@ -1015,6 +1020,7 @@ __global__ __launch_bounds__(1024) void fps_cluster_kernel(const float* __restri
             int budget = 1 << 22;
             while (__hip_atomic_load(&tags[o], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < round && --budget > 0)
               __builtin_amdgcn_s_sleep(1);
+            lost = lost || budget <= 0;     // the partner never published this round: its slot holds an older round's records
             const unsigned long long* theirs = reinterpret_cast<const unsigned long long*>(slot0 + o * 512 + l_ * 8);
             const unsigned long long w0 = __hip_atomic_load(theirs + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned long long w1 = __hip_atomic_load(theirs + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1088,7 +1094,15 @@ __global__ __launch_bounds__(1024) void fps_cluster_kernel(const float* __restri
         accb[rank] = make_float4(cj.x, cj.y, cj.z, __int_as_float(cand_q[l_]));
         picks[i + rank] = cand_q[l_];                    // sorted position; translated to the original index after the loop
       }
-      if (l_ == 0) { acc_n = cnt; fb_mx = m0; }
+      if constexpr (MULTI) {
+        // a lost partner: the replicated selection would diverge between the scene's workgroups from here on.  Flag the
+        // launch (the host raises when it next looks: pn2_ext.raise_if_fps_failed) and leave the round loop.
+        if (__any(lost)) {
+          if (l_ == 0) { atomicOr(status, 1u); acc_n = -1; }
+        } else if (l_ == 0) { acc_n = cnt; fb_mx = m0; }
+      } else {
+        if (l_ == 0) { acc_n = cnt; fb_mx = m0; }
+      }
     }
     FPS_T(4);
     __syncthreads();
@@ -1101,6 +1115,7 @@ __global__ __launch_bounds__(1024) void fps_cluster_kernel(const float* __restri
         if (i < marks[k] && i + got >= marks[k]) fps_dbg[k] = __builtin_readcyclecounter() - t_loop0;
     }
 #endif
+    if (MULTI && got < 0) break;            // (uniform: acc_n is the workgroup's)
     if (got > 0) {
       i += got;
       continue;
@@ -1128,6 +1143,7 @@ __global__ __launch_bounds__(1024) void fps_cluster_kernel(const float* __restri
             if ((unsigned)(wv >> 32) == round) break;
             __builtin_amdgcn_s_sleep(1);
           } while (--budget > 0);
+          if (budget <= 0) { atomicOr(status, 1u); kall = FPS_LOST_KEY; break; }
           kall = min(kall, (unsigned)wv);
         }
         win_key = kall;
@@ -1136,6 +1152,7 @@ __global__ __launch_bounds__(1024) void fps_cluster_kernel(const float* __restri
     }
     const unsigned key = win_key;
     __syncthreads();
+    if (MULTI && key == FPS_LOST_KEY) break;
     if (tid == 0) {
       win_key = 0xffffffffu;
       if (key != 0xffffffffu) {
@@ -1377,6 +1394,17 @@ extern "C" int64_t regnet_fps_workspace_bytes(int64_t B, int64_t N, int64_t M) {
   if (N <= FPS_RESIDENT_MAX) return 0;
   // beyond one CU: the streaming kernel's running distances / the cooperative cluster kernel's permutation (B x N words
   // either way) followed by the cooperative kernels' exchange area
+  return fps_xchg_offset_floats(B, N) * (int64_t)sizeof(float) + B * (int64_t)FPS_XCHG_BYTES + FPS_STATUS_BYTES;
+}
+
+// scenes beyond one CU's registers whose sampling runs on 2..4 cooperating workgroups (fps_cluster_kernel<.., true>)
+static bool fps_takes_coop_cluster_kernel(int64_t B, int64_t N, int64_t M) {
+  return fps_coop_enabled && N > FPS_RESIDENT_MAX && N <= FPS_MULTI_MAX && M >= 1024 && M <= FPS_CLUSTER_MAX_PICKS &&
+         ((N + FPS_RESIDENT_MAX - 1) / FPS_RESIDENT_MAX) * B <= fps_num_cus();
+}
+
+extern "C" int64_t regnet_fps_status_offset_bytes(int64_t B, int64_t N, int64_t M) {
+  if (!fps_takes_coop_cluster_kernel(B, N, M)) return -1;
   return fps_xchg_offset_floats(B, N) * (int64_t)sizeof(float) + B * (int64_t)FPS_XCHG_BYTES;
 }
 
@@ -1452,14 +1480,14 @@ extern "C" int regnet_fps_f32(const float* xyz, int64_t sb, int64_t sc, int64_t 
   else if (N <= 16384) FPS_WAVE_CASE(16);
   else if (N <= 20480) FPS_WAVE_CASE(20);
   else if (N <= FPS_RESIDENT_MAX) FPS_WAVE_CASE(25);
-  else if (fps_coop_enabled && N <= FPS_MULTI_MAX && M >= 1024 && M <= FPS_CLUSTER_MAX_PICKS &&
-           ((N + FPS_RESIDENT_MAX - 1) / FPS_RESIDENT_MAX) * B <= fps_num_cus()) {
+  else if (fps_takes_coop_cluster_kernel(B, N, M)) {
     // several exact picks per round on 2..4 cooperating workgroups per scene (fps_cluster_kernel<.., true>)
     if (!workspace) return REGNET_ERR_NULL;
     const int G = (int)((N + FPS_RESIDENT_MAX - 1) / FPS_RESIDENT_MAX);
     const int Bpad = (int)((B + 7) / 8 * 8);                                       // a scene's workgroups on one XCD
     const int64_t Nh = (N + G - 1) / G;
-    hipError_t e = hipMemsetAsync(workspace + fps_xchg_offset_floats(B, N), 0, (size_t)B * FPS_XCHG_BYTES, st);   // tags 0 = nothing published
+    hipError_t e = hipMemsetAsync(workspace + fps_xchg_offset_floats(B, N), 0, (size_t)B * FPS_XCHG_BYTES + FPS_STATUS_BYTES,
+                                  st);   // tags 0 = nothing published, status 0 = no poll gave up
     if (e != hipSuccess) return (int)e;
     if (Nh <= 12288) FPS_COOP_CASE(12);
     else if (Nh <= 16384) FPS_COOP_CASE(16);

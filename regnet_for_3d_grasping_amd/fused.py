@@ -445,6 +445,10 @@ def sa_group(module, xyz, ctr):
             else:
                 geo["src_xyz"], ctr_xyz = xyz, new_xyz
             geo["V"] = mlp_layer(pack_rows(None, ctr_xyz, 4), 4, v_layer, B * M)
+            # V = W_xyz . centre with the first layer's BatchNorm folded in: a function of the WEIGHTS too, unlike the rest
+            # of the plan.  sa_features recomputes it when the block's weights changed since (a plan reused across an
+            # optimizer step / load_state_dict)
+            geo["V_signature"] = _signature(module.mlp)
     return geo
 
 
@@ -491,8 +495,12 @@ def sa_features(module, xyz, feature, geo):
         # U[j] - V[c] = s W [f_j | x_j - x_c] - t only up to fp32 rounding of the two big terms: both sides use the
         # coordinates RELATIVE TO THE SCENE'S MEAN (the difference is unchanged, the magnitudes -- table-top scenes sit
         # ~0.75 m from the origin -- and with them the cancellation error of the subtraction shrink)
-        if "V" in geo:                       # coordinate-only parts already done by the geometry stage (sa_group)
-            src_xyz, V = geo["src_xyz"], geo["V"]
+        if "V" in geo and geo.get("V_signature") == _signature(module.mlp):
+            src_xyz, V = geo["src_xyz"], geo["V"]       # already done by the geometry stage (sa_group), same weights
+        elif "V" in geo:                                 # stale: the weights moved after the plan was made
+            src_xyz = geo["src_xyz"]
+            ctr_xyz = geo["new_xyz"] - xyz.mean(dim=2, keepdim=True) if PREMUL_CENTRE else geo["new_xyz"]
+            V = mlp_layer(pack_rows(None, ctr_xyz, 4), 4, v_layer, B * M)
         else:
             if PREMUL_CENTRE:
                 mu = xyz.mean(dim=2, keepdim=True)

@@ -40,10 +40,18 @@ def _pool_rows(all_feature, rows):
 _rows_cache = [None, None]
 
 
+def forget_rows():
+    """Drop the cached contiguous rows (and with them the autograd nodes they hang on).  ``RefineTrainer.step`` calls
+    this at the end of every iteration; in training the cache holds ``flat`` strongly, because its graph must survive
+    from the region head's pool to the refine head's."""
+    _rows_cache[0] = _rows_cache[1] = None
+
+
 def _contiguous_rows(all_feature):
     """``all_feature.contiguous().view(-1, F)``, made ONCE per feature map: ScoreNet hands the map out as a transposed view
     in training, the region head and the refine head both pool from it, and every ``.contiguous()`` is a 210 MB transpose
-    copy forward and another one backward (B = 8).  Keyed on the tensor object (weakly: the cache keeps no graph alive)."""
+    copy forward and another one backward (B = 8).  Keyed on the tensor object, weakly; the copy itself is held strongly
+    only while it requires grad (one training iteration: ``forget_rows``), never in eval mode."""
     import weakref
     ref, flat = _rows_cache
     if ref is not None and ref() is all_feature and flat is not None:

@@ -539,6 +539,8 @@ class ForwardPipeline:
             worker.join()
         for s in streams:
             cur.wait_stream(s)
+        from . import pn2_ext
+        pn2_ext.raise_if_fps_failed()         # (only holds flags when cooperative sampling launches were issued)
         if self.with_region:
             from . import region_ops
             region_ops.raise_if_out_of_range()

@@ -66,7 +66,35 @@ def farthest_point_sample(points, num_centroids):
         _check(_L.regnet_fps_f32(points.data_ptr(), sb, sc, sn, B, N, M, index.data_ptr(),
                                  ws.data_ptr() if ws is not None else None, _stream(points)),
                "farthest_point_sample")
+        status_at = _L.regnet_fps_status_offset_bytes(B, N, M)
+        if status_at >= 0:
+            # cooperative sampling (N > 25 600): accumulate the launch's status word into the device's flag -- one tiny
+            # launch on the same stream, no synchronisation; raise_if_fps_failed() reads it where the caller synchronises
+            flag = _fps_flag(points.device)
+            torch.bitwise_or(flag, ws[status_at // 4: status_at // 4 + 1].view(torch.int32), out=flag)
     return index
+
+
+_fps_flags = {}
+
+
+def _fps_flag(device):
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    if key not in _fps_flags:
+        _fps_flags[key] = torch.zeros(1, dtype=torch.int32, device=device)
+    return _fps_flags[key]
+
+
+def raise_if_fps_failed():
+    """RuntimeError if a cooperative furthest-point-sampling launch since the last check lost a partner workgroup (a
+    scene's 2-4 workgroups exchange records every round and must all be resident; a poll gives up after 2^22 tries, flags
+    the launch and stops instead of sampling on with diverged selections).  Synchronises; called where the caller
+    synchronises anyway (end of pipeline.forward_scenes / ForwardPipeline.run), like region_ops.raise_if_out_of_range."""
+    for flag in _fps_flags.values():
+        if int(flag.item()):
+            flag.zero_()
+            raise RuntimeError("farthest_point_sample: a cooperating workgroup lost its partner (launch not fully "
+                               "resident?); the returned indices are incomplete")
 
 
 def ball_query(points, centroids, radius, num_neighbours):

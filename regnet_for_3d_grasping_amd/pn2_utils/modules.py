@@ -56,7 +56,13 @@ class _GroupMinus(torch.autograd.Function):
         (index,) = ctx.saved_tensors
         dY = dY.contiguous()
         dU = pn2_ext.group_points_backward(dY, index, ctx.num_points) if ctx.needs_input_grad[0] else None
-        dV = region_ops.rowsum_neg(dY, dY.shape[-1]) if ctx.needs_input_grad[1] else None
+        dV = None
+        if ctx.needs_input_grad[1]:
+            K = dY.shape[-1]
+            if 4 <= K <= 256 and K & (K - 1) == 0 and dY.data_ptr() % 16 == 0:
+                dV = region_ops.rowsum_neg(dY, K)
+            else:                         # neighbourhood sizes rowsum_neg_kernel has no instantiation for (e.g. K = 48)
+                dV = -(dY.sum(-1))
         return dU, dV, None
 
 

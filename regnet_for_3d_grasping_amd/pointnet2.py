@@ -83,7 +83,9 @@ class PointNet2Seg(nn.Module):
     def plan(self, points, level1_ctr=None, on_level=None):
         """Geometry of a forward pass -- FPS / ball-query / 3-NN indices of every level (``level1_ctr``: the level-1
         sampling from ``sample_level1``, or the list of all levels' from ``sample_levels``, when already computed).  Depends on
-        xyz only, so it can be computed ahead of (and concurrently with) the feature pass; hand the
+        xyz only -- except the per-centre first-layer term ``V`` of levels 2-3 in eval mode, which is stored with the
+        signature of the weights it was computed from and recomputed by ``fused.sa_features`` if they changed since -- so it
+        can be computed ahead of (and concurrently with) the feature pass; hand the
         result to ``forward(points, plan=...)`` -- the fused inference path or the operator-granular training path.
         GPU only; always computed without autograd (the reference's geometry ops return no gradients)."""
         from . import fused

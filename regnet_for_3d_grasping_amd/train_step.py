@@ -208,18 +208,26 @@ class ScoreTrainer:
     def __init__(self, score_net, lr=0.001, reduce="sum"):
         self.net = score_net
         self.reduce = reduce
-        broadcast_module_state(score_net)
         self.optimizer = torch.optim.Adam([{"params": score_net.parameters(), "initial_lr": lr}], lr=lr)
         self.scheduler = torch.optim.lr_scheduler.StepLR(self.optimizer, step_size=5, gamma=0.5)
         self.geometry = GeometryPrefetcher(score_net)
-        self.bucket = GradientBucket([score_net], reduce) if _distributed() else None
+        self.bucket = None           # created by the first step that finds a process group (_ensure_bucket)
+        self._ensure_bucket()
 
     def prefetch(self, pc):
         """Start the geometry of a FUTURE batch on a side stream; pass the result to ``step(..., plan=...)``."""
         return self.geometry.prefetch(pc)
 
+    def _ensure_bucket(self):
+        """The gradient all-reduce is decided per STEP, not at construction: a process group initialised after the
+        trainer was built must not leave the ranks training apart without an error."""
+        if self.bucket is None and _distributed():
+            broadcast_module_state(self.net)
+            self.bucket = GradientBucket([self.net], self.reduce)
+
     def step(self, pc, pc_score, pc_label=None, plan=None):
         self.net.train()
+        self._ensure_bucket()
         if self.bucket is None:
             self.optimizer.zero_grad()
         else:
@@ -295,7 +303,6 @@ class RefineTrainer:
             gc.freeze()      # what exists now (modules, parameters, the interpreter's own objects) is never traversed again:
             gc.disable()     # a periodic collection then only walks the iterations' garbage (~100 ms -> a few ms)
         self.params, self.gripper_params, self.reduce = params, gripper_params, reduce
-        broadcast_module_state(score_net, region_net)
         self.opt_score = torch.optim.Adam([{"params": score_net.parameters(), "initial_lr": lr}], lr=lr)
         self.opt_region = torch.optim.Adam([{"params": region_net.parameters(), "initial_lr": lr}], lr=lr)
         self.sched_score = torch.optim.lr_scheduler.StepLR(self.opt_score, step_size=5, gamma=0.5)
@@ -304,7 +311,15 @@ class RefineTrainer:
         self._region_stream = None
         # both networks' gradients in ONE flat buffer: one all-reduce per training iteration (28.3 MB for the reference's
         # 5 542 531 + 1 524 396 parameters)
-        self.bucket = GradientBucket([score_net, region_net], reduce) if _distributed() else None
+        self.bucket = None           # created by the first step that finds a process group (_ensure_bucket)
+        self._ensure_bucket()
+
+    def _ensure_bucket(self):
+        """The gradient all-reduce is decided per STEP, not once at construction: a process group initialised after the
+        trainer was built must not leave the ranks training apart without an error."""
+        if self.bucket is None and _distributed():
+            broadcast_module_state(self.score_net, self.region_net)
+            self.bucket = GradientBucket([self.score_net, self.region_net], self.reduce)
 
     def prefetch(self, pc):
         """Start the geometry of a FUTURE batch on a side stream; pass the result to ``step(..., plan=...)``."""
@@ -373,6 +388,7 @@ class RefineTrainer:
     def step(self, pc, pc_score, grasp_records, plan=None):
         self.score_net.train()
         self.region_net.train()
+        self._ensure_bucket()
         if self.bucket is None:      # single process: gradients stay where autograd puts them (no accumulate-into-view adds)
             self.opt_score.zero_grad()
             self.opt_region.zero_grad()
@@ -405,6 +421,8 @@ class RefineTrainer:
             self.bucket.reduce_gradients()
         self.opt_score.step()
         self.opt_region.step()
+        from . import gripper_region_network
+        gripper_region_network.forget_rows()     # the iteration's contiguous feature rows (210 MB at B = 8) and their graph
         self._iterations += 1
         if self.gc_interval and self._iterations % self.gc_interval == 0:
             import gc
@@ -412,5 +430,7 @@ class RefineTrainer:
         return total.detach(), parts
 
     def end_epoch(self):
+        from . import pn2_ext
+        pn2_ext.raise_if_fps_failed()    # cooperative sampling launches (scenes beyond 25 600 points) flag a lost partner
         self.sched_score.step()
         self.sched_region.step()

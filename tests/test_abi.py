@@ -47,7 +47,11 @@ def test_argument_checks_without_gpu():
     assert L.regnet_fps_workspace_bytes(4, 25600, 5120) == 4 * 25600 * 4       # long run: the Morton permutation
     assert L.regnet_fps_f32(1, 3 * 25600, 25600, 1, 1, 25600, 5120, 1, None, None) == -2   # ... which must be provided
     # beyond 25 600 points: B x N words (permutation / running distances) + the cooperating workgroups' exchange area
-    assert L.regnet_fps_workspace_bytes(4, 51200, 5120) == 4 * 51200 * 4 + 4 * (2 * 4 * 64 * 8 * 4 + 256)
+    # ... + the launch's status word (a cooperating workgroup that lost its partner flags it instead of sampling on)
+    assert L.regnet_fps_workspace_bytes(4, 51200, 5120) == 4 * 51200 * 4 + 4 * (2 * 4 * 64 * 8 * 4 + 256) + 256
+    assert L.regnet_fps_status_offset_bytes(4, 51200, 5120) == 4 * 51200 * 4 + 4 * (2 * 4 * 64 * 8 * 4 + 256)
+    assert L.regnet_fps_status_offset_bytes(4, 25600, 5120) == -1          # one workgroup per scene: nothing to lose
+    assert L.regnet_fps_status_offset_bytes(4, 51200, 64) == -1            # short run: not the cooperative cluster kernel
     with pytest.raises(RuntimeError):
         _lib.check(-1, "x")
 

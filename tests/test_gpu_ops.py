@@ -160,6 +160,21 @@ def test_fps_cooperative_cluster_kernel_bit_exact(ext, orc, B, N, M, dup, grid):
         N, M, (got != want).nonzero()[:1].tolist())
 
 
+def test_fps_cooperative_status_word_is_accumulated_and_raised_lazily(ext):
+    """A cooperative launch's status word (bit 0: a poll ran out of budget, the workgroup stopped sampling) is OR-ed into a
+    per-device flag on the launch's stream; ``raise_if_fps_failed`` reads it where the caller synchronises.  A healthy
+    launch leaves it clear; a set flag raises once and is cleared."""
+    x = cloud(77, 2, 51200).to(DEV)
+    ext.farthest_point_sample(x, 1024)
+    ext.raise_if_fps_failed()                       # nothing lost
+    flag = ext._fps_flag(x.device)
+    assert int(flag.item()) == 0
+    flag.fill_(1)                                   # what a launch with a lost partner leaves behind
+    with pytest.raises(RuntimeError, match="lost its partner"):
+        ext.raise_if_fps_failed()
+    ext.raise_if_fps_failed()                       # cleared by the raise
+
+
 def test_fps_multi_workgroup_ties_and_duplicates(ext, orc):
     """Lattice points (many exactly equal distances) and duplicated points across the workgroup boundary."""
     g = torch.stack(torch.meshgrid(torch.arange(40.), torch.arange(40.), torch.arange(20.), indexing="ij"), -1).view(1, -1, 3)
