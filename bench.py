@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=8, help="scenes per GPU per step (configs[2]: 8)")
     ap.add_argument("--points", type=int, default=25600)
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="scenes per step over ALL ranks (configs[3]: 16 on 2 or 4 GPUs, configs[4]: 32 x 51 200 points on 8); "
+                         "the per-rank batch is derived from it (overrides --batch / --train-batch)")
     ap.add_argument("--cpu-scenes", type=int, default=4, help="scenes timed for cpu_baseline (0 = skip)")
     ap.add_argument("--score-only", action="store_true", help="configs[1]: ScoreNet forward only")
     ap.add_argument("--latency-runs", type=int, default=5,
@@ -306,6 +309,7 @@ def measure_train(args, rank, world, dev, steps, warmup, batch):
                                       grasp_score_threshold=pipeline.GRASP_SCORE_THRESHOLD, radius=pipeline.DEPTH,
                                       reg_channel=pipeline.REG_CHANNEL)
     region_net.load_state_dict(synthetic.seeded_state_dict(region_net, 11))
+    synthetic.set_region_head_affine(region_net)   # decoded grasps hold points: the refine losses run on real rows
     import gc
     gc_was_on = gc.isenabled()
     trainer = RefineTrainer(score_net.to(dev), region_net.to(dev), pipeline.PARAMS, pipeline.GRIPPER_PARAMS,
@@ -335,13 +339,14 @@ def measure_train(args, rank, world, dev, steps, warmup, batch):
     fence()
     timer.enabled = True
     t0 = time.perf_counter()
-    region_steps = 0
+    region_steps = refine_steps = 0
     allreduce_ms = []
     for _ in range(steps):
         nxt = trainer.prefetch(pc)
         loss, parts = trainer.step(pc, target, records, plan=ahead)
         ahead = nxt
         region_steps += "region_error" not in parts
+        refine_steps += parts.get("refine") is not None
         if trainer.bucket is not None and trainer.bucket.last_ms is not None:
             allreduce_ms.append(trainer.bucket.last_ms)
     fence()
@@ -369,11 +374,13 @@ def measure_train(args, rank, world, dev, steps, warmup, batch):
             # iterations itself: left on, it stalls every ~10th iteration by 60-100 ms); the amortised cost is in this figure
             "gc": {"interval_iterations": TRAIN_GC_INTERVAL, "one_collection_ms": round(gc_ms, 2),
                    "ms_per_step_incl_amortised_gc": round(dt / steps * 1e3 + gc_ms / TRAIN_GC_INTERVAL, 3)},
-            "config": {"workload": "configs[3]: training iteration (forward with labels, stage-2 + refine losses, backward, "
-                                   "two Adam steps), %d-pt synthetic scenes, batch=%d per GPU" % (N, B),
+            "config": {"workload": "%s: training iteration (forward with labels, stage-2 + refine losses, backward, "
+                                   "two Adam steps), %d-pt synthetic scenes, batch=%d per GPU" % (
+                                       "configs[4]" if N == 51200 else "configs[3]", N, B),
                        "points": N, "batch_per_gpu": B, "global_batch": B * world,
                        "parallelism": "dp%d: ONE flat fp32 gradient all-reduce per iteration (%d elements, both networks) over RCCL" % (world, grads),
-                       "steps_with_region_losses": region_steps, "last_loss": float(loss)}}
+                       "steps_with_region_losses": region_steps, "steps_with_refine_losses": refine_steps,
+                       "last_loss": float(loss)}}
 
 
 def run_train(args, rank, world, dev):
@@ -462,6 +469,10 @@ def main():
         module = importlib.import_module("regnet_for_3d_grasping_amd." + mod)
         assert isinstance(getattr(module, name), bool), target
         setattr(module, name, value not in ("0", "false", "False"))
+    if args.global_batch:
+        if args.global_batch % world:
+            raise SystemExit("--global-batch %d is not a multiple of the %d ranks" % (args.global_batch, world))
+        args.batch = args.train_batch = args.global_batch // world
     if args.train:
         run_train(args, rank, world, dev)
         if world > 1:

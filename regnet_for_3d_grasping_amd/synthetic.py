@@ -150,6 +150,41 @@ REGION_CALIBRATION_KEYS = tuple("%s.%s.%s" % (net, bn, leaf)
                                 for leaf in ("weight", "bias", "running_mean", "running_var"))
 
 
+def _stage2_affine(region_net, lift, spread, dev):
+    """(weight, bias) of ``bn_reg4`` per (anchor, channel), flattened: see ``calibrate_region_head``."""
+    A, C = region_net.anchor_number, region_net.reg_channel
+    tmpl = region_net.templates.detach().float().to(dev).view(A, 4)
+    w = torch.zeros(A, C, device=dev)
+    b = torch.zeros(A, C, device=dev)
+    w[:, 0:3], w[:, 3:6], w[:, 6] = spread[0], spread[1], spread[2]
+    b[:, 2] = lift / float(region_net.radius)
+    b[:, 3:6] = torch.tensor([1.0, 0.0, 0.0], device=dev).view(1, 3) - tmpl[:, :3]
+    b[:, 6] = -0.5 - tmpl[:, 3]
+    return w.view(-1), b.view(-1)
+
+
+def set_region_head_affine(region_net, lift=0.008, spread=(0.12, 0.15, 0.05), refine_spread=0.05):
+    """The TRAINING-mode counterpart of ``calibrate_region_head``: train-mode BatchNorm standardises with the batch's own
+    statistics, so writing the affine of the four last BatchNorms is all it takes for the decoded stage-2 grasps to hold
+    points in their closing boxes (refine losses on real rows instead of the ``len(gripper_mask) < 2`` skip).  No forward
+    pass; running statistics untouched."""
+    head, refine = region_net.extrat_feature_region, region_net.extrat_feature_refine
+    A, C = region_net.anchor_number, region_net.reg_channel
+    dev = head.bn_reg4.weight.device
+    w, b = _stage2_affine(region_net, lift, spread, dev)
+    reg_ch = (torch.arange(A * C, device=dev) % C) < 7
+    with torch.no_grad():
+        head.bn_cls4.weight.fill_(1.0)
+        head.bn_cls4.bias.fill_(0.0)
+        head.bn_reg4.weight[reg_ch] = w[reg_ch]
+        head.bn_reg4.bias[reg_ch] = b[reg_ch]
+        refine.bn_formal_cls3.weight.fill_(1.0)
+        refine.bn_formal_cls3.bias.fill_(0.0)
+        refine.bn_formal_reg3.weight.fill_(refine_spread)
+        refine.bn_formal_reg3.bias.fill_(0.0)
+    return region_net
+
+
 def calibrate_region_head(region_net, run, lift=0.008, spread=(0.12, 0.15, 0.05), refine_spread=0.05):
     """Make a seeded ``GripperRegionNetwork`` decode to grasps whose closing box actually holds points, so that the
     refine stage runs (gripper_region_network.py:333: ``if len(gripper_mask) >= 2``) and its class head keeps a share
@@ -183,14 +218,8 @@ def calibrate_region_head(region_net, run, lift=0.008, spread=(0.12, 0.15, 0.05)
         reg_ch = (torch.arange(A * C, device=dev) % C) < 7
         x_reg = x_reg.reshape(-1, A * C)
         y = torch.where(reg_ch.view(1, -1), x_reg, torch.zeros_like(x_reg))
-        tmpl = region_net.templates.detach().float().to(dev).view(A, 4)
-        w = torch.zeros(A, C, device=dev)
-        b = torch.zeros(A, C, device=dev)
-        w[:, 0:3], w[:, 3:6], w[:, 6] = spread[0], spread[1], spread[2]
-        b[:, 2] = lift / float(region_net.radius)
-        b[:, 3:6] = torch.tensor([1.0, 0.0, 0.0], device=dev).view(1, 3) - tmpl[:, :3]
-        b[:, 6] = -0.5 - tmpl[:, 3]
-        _standardise(head.bn_reg4, _bn_input(head.bn_reg4, y), w.view(-1), b.view(-1), channels=reg_ch)
+        w, b = _stage2_affine(region_net, lift, spread, dev)
+        _standardise(head.bn_reg4, _bn_input(head.bn_reg4, y), w, b, channels=reg_ch)
         grabbed.pop("refine", None)
         run()
         if "refine" not in grabbed:
