@@ -196,7 +196,7 @@ def _mlp_layer_kernel(d):
     t256, t128, kpad = ((P + 255) // 256) * nt, ((P + 127) // 128) * nt, (K + 15) // 16 * 16
     if N > 128 and t256 >= 1024:
         tile = "256,128"
-    elif t128 >= 1024:
+    elif t128 >= 1024 and (kpad < 256 or d.get("pool")):   # (two or more 128-wide slabs of K: the slab-accumulating tile)
         tile = "128,128"
     else:
         tile = "64,128"

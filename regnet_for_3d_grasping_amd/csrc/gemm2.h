@@ -15,6 +15,10 @@
 //    FETCHES: physical chunk c' of row r holds logical chunk c' ^ ((r >> 2) & 3).  A fragment read of 16-lane service
 //    group {fr..} then touches 16 distinct 16-byte slots of the 256-byte bank row (derivation in DESIGN.md §5.3).
 //  * workgroup tile TBM x TBN with WM x WN waves; a wave owns (TBM/WM) x (TBN/WN) as 32x32 accumulators.
+//  * slab accumulation (SLAB_KT > 0): the MFMAs accumulate SLAB_KT k-tiles (128 columns of K) into `acc`, which is then
+//    added to a second register set and cleared -- K = 1024 becomes eight 128-long fp32 chains added once each instead
+//    of one 1024-long chain (what a cache-blocked CPU sgemm does too: the reference's own arithmetic).  Measured on the
+//    S8 scores: profiles/r04_error_budget.txt.  One v_add per accumulator register per 128 MFMAs.
 //  * tail splitting: the last partial round of tiles (fewer tiles than the chip has workgroup slots) is cut into
 //    narrower-M sub-tiles inside the SAME launch, so a launch does not end with most CUs idle for a whole tile time.
 #pragma once
@@ -56,7 +60,7 @@ __device__ __forceinline__ long long g2_xcd_linear(unsigned vblock, long long to
 
 // Rows [row0, row0 + ROWS) x columns [col0, col0 + TBN) with WM x WN waves: the k-loop + epilogue of one (sub-)tile.
 //   ROWS = WM * TM * 32.  smem: ring of STAGES x (ROWS_MAX + TBN) x 64 bytes.
-template <int ROWS_MAX, int TBN, int WM, int WN, int TM, int STAGES, bool POOL>
+template <int ROWS_MAX, int TBN, int WM, int WN, int TM, int STAGES, bool POOL, int SLAB_KT>
 __device__ __forceinline__ void g2_tile(const G2Args& p, float* smem, long long row0, int col0) {
   constexpr int NW = WM * WN;
   constexpr int ROWS = WM * TM * 32;
@@ -108,6 +112,30 @@ __device__ __forceinline__ void g2_tile(const G2Args& p, float* smem, long long 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
+  // slab accumulation: the sum of the slabs finished so far (see the header); `since` counts the open slab's k-tiles
+  g2_f32x16 tot[SLAB_KT > 0 ? TM : 1][SLAB_KT > 0 ? TN : 1];
+  if constexpr (SLAB_KT > 0) {
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tot[mi][ni][r] = 0.f;
+  }
+  int since = 0;
+#define G2_SLAB()                                                                                                 \
+  if constexpr (SLAB_KT > 0) {                                                                                    \
+    if (++since == SLAB_KT) {                                                                                     \
+      since = 0;                                                                                                  \
+      _Pragma("unroll") for (int mi = 0; mi < TM; ++mi)                                                           \
+        _Pragma("unroll") for (int ni = 0; ni < TN; ++ni)                                                         \
+          _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                        \
+            tot[mi][ni][r] += acc[mi][ni][r];                                                                     \
+            acc[mi][ni][r] = 0.f;                                                                                 \
+          }                                                                                                       \
+    }                                                                                                             \
+  }
+
   // fragment offsets (floats) inside a stage: row * 16 + 4 * ((2 kk + fh) ^ ((fr >> 2) & 3))
   const int sw = (fr >> 2) & 3;
   int offA[2], offW[2];
@@ -158,6 +186,7 @@ __device__ __forceinline__ void g2_tile(const G2Args& p, float* smem, long long 
     int ns = stage + D; if (ns >= STAGES) ns -= STAGES;
     G2_ISSUE(kt + D, ns)
     G2_COMPUTE(stage)
+    G2_SLAB()
     if (++stage == STAGES) stage = 0;
   }
   // drain: the last D tiles, nothing left to fetch
@@ -165,8 +194,18 @@ __device__ __forceinline__ void g2_tile(const G2Args& p, float* smem, long long 
   for (int d = 0; d < D; ++d) {
     g2_wait_barrier<0>();
     G2_COMPUTE(stage)
+    G2_SLAB()
     if (++stage == STAGES) stage = 0;
   }
+  if constexpr (SLAB_KT > 0) {   // the open slab (all zeros when K is a multiple of the slab) joins the finished ones
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mi][ni][r] += tot[mi][ni][r];
+  }
+#undef G2_SLAB
 #undef G2_COMPUTE
 #undef G2_ISSUE
   // ---- epilogue.  C/D layout: element r of lane l is row (r & 3) + 8 (r >> 2) + 4 (l >> 5), column l & 31.
@@ -219,21 +258,33 @@ __device__ __forceinline__ void g2_tile(const G2Args& p, float* smem, long long 
   }
 }
 
+#ifndef G2_SLAB_MAX_TBM
+#define G2_SLAB_MAX_TBM 64   // largest tile height that accumulates in slabs (see G2Slab)
+#endif
+#ifndef G2_SLAB_KT
+#define G2_SLAB_KT 8      // k-tiles (of 16 columns) per accumulation slab; 0 = one chain over all of K (rounds 2-3)
+#endif
+// slabs where the second accumulator set fits the tile's register budget at its occupancy: 64 x 128 (74 -> ~106 of 128
+// VGPRs at 4 waves per SIMD) and 128 x 128 (118 -> ~182: 2 waves per SIMD instead of 3); the 256 x 128 tile (116 of 128 at
+// 4 waves per SIMD) keeps one chain -- no layer of the ScoreNet forward takes it since the chains (DESIGN.md par. 11)
+template <int TBM, int TBN> struct G2Slab { static constexpr int kt = (TBM <= G2_SLAB_MAX_TBM) ? G2_SLAB_KT : 0; };
+
 template <int TBM, int TBN, int WM, int WN, int STAGES, int WG_PER_CU, bool POOL>
 __global__ __launch_bounds__(WM * WN * 64, WG_PER_CU * WM * WN / 4)
 void gemm2_kernel(const G2Args p) {
+  constexpr int SLAB = G2Slab<TBM, TBN>::kt;
   constexpr int TM = TBM / WM / 32;
   __shared__ __attribute__((aligned(1024))) float smem[STAGES * (TBM + TBN) * G2_BK];
   const int bid = blockIdx.x;
   if (bid < p.main_blocks) {
     const long long t = g2_xcd_linear((unsigned)bid, p.main_blocks);
     const int tm = (int)(t / p.tiles_n), tn = (int)(t % p.tiles_n);
-    g2_tile<TBM, TBN, WM, WN, TM, STAGES, POOL>(p, smem, (long long)tm * TBM, tn * TBN);
+    g2_tile<TBM, TBN, WM, WN, TM, STAGES, POOL, SLAB>(p, smem, (long long)tm * TBM, tn * TBN);
   } else if constexpr (!POOL && TM == 2 && ((WM * 32 + TBN) / 16) % (WM * WN) == 0) {
     // tail: tile index = main_blocks + t (plain order), slice s of tail_split: half-height sub-tiles (TM = 1)
     const int t = (bid - p.main_blocks) / p.tail_split, s = (bid - p.main_blocks) % p.tail_split;
     const long long tile = (long long)p.main_blocks + t;
     const int tm = (int)(tile / p.tiles_n), tn = (int)(tile % p.tiles_n);
-    g2_tile<TBM, TBN, WM, WN, 1, STAGES, false>(p, smem, (long long)tm * TBM + (long long)s * (TBM / 2), tn * TBN);
+    g2_tile<TBM, TBN, WM, WN, 1, STAGES, false, SLAB>(p, smem, (long long)tm * TBM + (long long)s * (TBM / 2), tn * TBN);
   }
 }

@@ -517,7 +517,11 @@ static int launch_gemm2(const G2Args& g, bool pool, hipStream_t st) {
   const long long nt = (g.N + 127) / 128;
   const long long t256 = ((g.P + 255) / 256) * nt, t128 = ((g.P + 127) / 128) * nt;
   if (g.N > 128 && t256 >= 4 * G2_CUS) return launch_gemm2_tile<256, 128, 4, 2, 3, 2>(g, pool, st);
-  if (t128 >= 4 * G2_CUS) return launch_gemm2_tile<128, 128, 2, 2, 3, 3>(g, pool, st);
+  // (only the 64 x 128 tile has the registers for slab accumulation -- gemm2.h: G2Slab -- so a layer with two or more
+  // slabs of K takes it even where the 128 x 128 tile would be ~6 % faster: P = 40 960, N = 512, K = 256 / 512 of the
+  // ScoreNet forward, +18 us per step for 0.55e-5 of parity margin, profiles/r04_error_budget.txt)
+  if (t128 >= 4 * G2_CUS && (G2_SLAB_KT == 0 || g.Kpad < 2 * G2_SLAB_KT * G2_BK || pool))
+    return launch_gemm2_tile<128, 128, 2, 2, 3, 3>(g, pool, st);
   return launch_gemm2_tile<64, 128, 1, 4, 3, 4>(g, pool, st);
 }
 

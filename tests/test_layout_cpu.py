@@ -104,9 +104,11 @@ def test_bench_kernel_names_follow_the_tile_table():
     assert k({"P": 8192, "K": 3, "N": 256}) == "mlp_gemm_kernel<0>"             # Kpad < 32
     assert k({"P": 131072, "K": 512, "N": 1024, "pool": 64}) == "gemm2_kernel<256,128,pool>"
     assert k({"P": 204800, "K": 256, "N": 256}) == "gemm2_kernel<256,128>"      # >= four rounds of the big tile
-    assert k({"P": 40960, "K": 512, "N": 512}) == "gemm2_kernel<128,128>"       # 640 big tiles: not enough rounds
+    assert k({"P": 40960, "K": 512, "N": 512}) == "gemm2_kernel<64,128>"        # >= 2 slabs of K: the slab-accumulating tile
+    assert k({"P": 40960, "K": 128, "N": 512}) == "gemm2_kernel<128,128>"       # one slab, 640 big tiles: not enough rounds
     assert k({"P": 8192, "K": 1024, "N": 1024}) == "gemm2_kernel<64,128>"       # few tiles: the smallest one
     assert k({"P": 8192, "K": 1024, "N": 512}) == "gemm2_kernel<64,128>"
     assert k({"P": 40960, "K": 512, "N": 256}) == "gemm2_kernel<64,128>"
     assert k({"P": 2048, "K": 1024, "N": 1024}) == "gemm2_kernel<64,128>"
-    assert k({"P": 204800, "K": 256, "N": 128}) == "gemm2_kernel<128,128>"
+    assert k({"P": 204800, "K": 128, "N": 128}) == "gemm2_kernel<128,128>"
+    assert k({"P": 204800, "K": 256, "N": 128}) == "gemm2_kernel<64,128>"
