@@ -460,7 +460,8 @@ def main():
     if world > 1:
         # one process per GPU on one host: keep each rank's CPU-side helpers (torch intra-op pool, OpenMP) to its share
         # of the cores, so that N ranks' region-stage host threads do not fight over them
-        torch.set_num_threads(max(1, (os.cpu_count() or world) // (2 * world)))
+        # (sharding.pin_rank: a contiguous share of the GPU's NUMA node, affinity mask + OpenMP / torch pools)
+        pinned = sharding.pin_rank(local_rank, world, None if one_device else local_rank)
         sharding.init("gloo" if one_device else "nccl", dev)   # RCCL; forward: only the barrier + max-over-ranks of the contract
     import importlib
     for item in args.set:

@@ -258,21 +258,21 @@ __device__ __forceinline__ void g2_tile(const G2Args& p, float* smem, long long 
   }
 }
 
-#ifndef G2_SLAB_MAX_TBM
-#define G2_SLAB_MAX_TBM 64   // largest tile height that accumulates in slabs (see G2Slab)
-#endif
 #ifndef G2_SLAB_KT
 #define G2_SLAB_KT 8      // k-tiles (of 16 columns) per accumulation slab; 0 = one chain over all of K (rounds 2-3)
 #endif
-// slabs where the second accumulator set fits the tile's register budget at its occupancy: 64 x 128 (74 -> ~106 of 128
-// VGPRs at 4 waves per SIMD) and 128 x 128 (118 -> ~182: 2 waves per SIMD instead of 3); the 256 x 128 tile (116 of 128 at
-// 4 waves per SIMD) keeps one chain -- no layer of the ScoreNet forward takes it since the chains (DESIGN.md par. 11)
-template <int TBM, int TBN> struct G2Slab { static constexpr int kt = (TBM <= G2_SLAB_MAX_TBM) ? G2_SLAB_KT : 0; };
+// slabs where the second accumulator set fits the register budget of the tile's occupancy: wave tiles of 32 accumulator
+// registers (64 x 32: the 64 x 128 x 4-wave tile, 74 -> 104 of 128 VGPRs at 4 waves per SIMD; 32 x 64: the 128 x 128 x 8-wave
+// tile).  Wave tiles of 64 x 64 (128 x 128 x 4 waves: 118 -> 168 + 51 spilled at 3 waves per SIMD; 256 x 128 x 8 waves: 116 of
+// 128) keep one chain.
+template <int TBM, int TBN, int WM, int WN> struct G2Slab {
+  static constexpr int kt = ((TBM / WM / 32) * (TBN / WN / 32) <= 2) ? G2_SLAB_KT : 0;
+};
 
 template <int TBM, int TBN, int WM, int WN, int STAGES, int WG_PER_CU, bool POOL>
 __global__ __launch_bounds__(WM * WN * 64, WG_PER_CU * WM * WN / 4)
 void gemm2_kernel(const G2Args p) {
-  constexpr int SLAB = G2Slab<TBM, TBN>::kt;
+  constexpr int SLAB = G2Slab<TBM, TBN, WM, WN>::kt;
   constexpr int TM = TBM / WM / 32;
   __shared__ __attribute__((aligned(1024))) float smem[STAGES * (TBM + TBN) * G2_BK];
   const int bid = blockIdx.x;

@@ -514,6 +514,7 @@ static int launch_gemm2(const G2Args& g, bool pool, hipStream_t st) {
   if (force_tile == 0) return launch_gemm2_tile<256, 128, 4, 2, 3, 2>(g, pool, st);
   if (force_tile == 1) return launch_gemm2_tile<128, 128, 2, 2, 3, 3>(g, pool, st);
   if (force_tile == 2) return launch_gemm2_tile<64, 128, 1, 4, 3, 4>(g, pool, st);
+  if (force_tile == 3 && !pool) return launch_gemm2_tile<128, 128, 4, 2, 3, 2>(g, pool, st);   // 8 waves of 32 x 64: slabs fit
   const long long nt = (g.N + 127) / 128;
   const long long t256 = ((g.P + 255) / 256) * nt, t128 = ((g.P + 127) / 128) * nt;
   if (g.N > 128 && t256 >= 4 * G2_CUS) return launch_gemm2_tile<256, 128, 4, 2, 3, 2>(g, pool, st);

@@ -48,3 +48,67 @@ def gather_counts(count, device="cpu"):
     t = torch.tensor([count], dtype=torch.int64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return int(t.item())
+
+
+# ---- host side of one-process-per-GPU: which cores a rank's Python, OpenMP and torch intra-op threads run on ------------
+def _parse_cpulist(text):
+    """'0-15,128-143' -> [0, ..., 15, 128, ..., 143] (the kernel's cpulist format)."""
+    cpus = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.extend(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def rank_core_slice(local_rank, local_world, cpus):
+    """The share of ``cpus`` (a list of logical CPU ids, e.g. a NUMA node's) that local rank ``local_rank`` of
+    ``local_world`` ranks sharing them gets: contiguous, disjoint, every rank at least one core."""
+    cpus = list(cpus)
+    per = max(1, len(cpus) // max(1, local_world))
+    lo = (local_rank * per) % max(1, len(cpus))
+    return cpus[lo:lo + per] or cpus[:1]
+
+
+def gpu_numa_node(device_index):
+    """NUMA node of GPU ``device_index`` from sysfs (PCI bus id of the torch device), or None when unknown."""
+    try:
+        bus = torch.cuda.get_device_properties(device_index).pci_bus_id
+        dom = getattr(torch.cuda.get_device_properties(device_index), "pci_domain_id", 0)
+        dev = getattr(torch.cuda.get_device_properties(device_index), "pci_device_id", 0)
+        with open("/sys/bus/pci/devices/%04x:%02x:%02x.0/numa_node" % (dom, bus, dev)) as f:
+            node = int(f.read().strip())
+        return node if node >= 0 else None
+    except (OSError, ValueError, RuntimeError, AssertionError, AttributeError):
+        return None
+
+
+def pin_rank(local_rank, local_world, device_index=None):
+    """Give this rank's process its own cores: the region stage's host thread (numpy draws, label matching), the launch
+    thread and the OpenMP / torch intra-op pools of N ranks on one host otherwise migrate over all sockets and fight for
+    the same cores.  The slice comes from the GPU's NUMA node when sysfs knows it (ranks whose GPUs share a node split
+    that node's cores), else from the process's current affinity mask.  Returns the list of cores (also when the
+    platform has no ``sched_setaffinity``: then nothing is pinned and only the thread pools are sized)."""
+    allowed = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    cpus, share, slot = allowed, local_world, local_rank
+    node = gpu_numa_node(device_index) if device_index is not None else None
+    if node is not None:
+        try:
+            with open("/sys/devices/system/node/node%d/cpulist" % node) as f:
+                on_node = [c for c in _parse_cpulist(f.read()) if c in set(allowed)]
+            peers = [r for r in range(local_world) if gpu_numa_node(r) == node]   # local ranks = device indices
+            if on_node and local_rank in peers:
+                cpus, share, slot = on_node, len(peers), peers.index(local_rank)
+        except OSError:
+            pass
+    mine = rank_core_slice(slot, share, cpus)
+    if hasattr(os, "sched_setaffinity"):
+        try:
+            os.sched_setaffinity(0, mine)
+        except OSError:
+            pass
+    threads = max(1, len(mine) // 2)          # half for the intra-op pool, the rest for the launch + region threads
+    os.environ["OMP_NUM_THREADS"] = str(threads)
+    torch.set_num_threads(threads)
+    return mine

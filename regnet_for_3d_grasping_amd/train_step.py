@@ -201,6 +201,51 @@ def broadcast_module_state(*modules, src=0):
     return total
 
 
+def broadcast_buffers(*modules, src=0):
+    """Every rank takes rank ``src``'s BUFFERS (BatchNorm running statistics, ``num_batches_tracked``): parameters stay
+    identical across ranks by construction (same start, all-reduced gradients), running statistics do not -- each rank
+    tracks its own shard, as each ``nn.DataParallel`` replica does, and the reference's checkpoint holds device 0's
+    (utils.py:129-133, train.py:467-468).  Call before evaluating or saving on a rank other than ``src`` --
+    ``save_checkpoint`` does.  No-op without a process group.  Returns the number of elements broadcast."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return 0
+    total = 0
+    by_dtype = {}
+    for m in modules:
+        for b in m.buffers():
+            by_dtype.setdefault(b.dtype, []).append(b.data)
+    for dtype in sorted(by_dtype, key=str):
+        group = by_dtype[dtype]
+        flat = torch.cat([t.reshape(-1) for t in group])
+        dist.broadcast(flat, src=src)
+        offset = 0
+        for t in group:
+            n = t.numel()
+            t.copy_(flat[offset:offset + n].view_as(t))
+            offset += n
+        total += flat.numel()
+    return total
+
+
+def save_checkpoint(score_net, region_net, score_path, region_path, src=0):
+    """The reference's end-of-epoch save (train.py:467-468: two whole-object pickles) under one process per GPU: all ranks
+    take rank ``src``'s BatchNorm buffers (a collective: EVERY rank must call this), then rank ``src`` alone writes the
+    files (``checkpoint.save_model``: the reference's class paths)."""
+    import torch.distributed as dist
+    from . import checkpoint
+    nets = [n for n in (score_net, region_net) if n is not None]
+    broadcast_buffers(*nets, src=src)
+    rank = dist.get_rank() if _distributed() else 0
+    if rank == src:
+        if score_net is not None:
+            checkpoint.save_model(score_net, score_path)
+        if region_net is not None:
+            checkpoint.save_model(region_net, region_path)
+    if _distributed():
+        dist.barrier()
+
+
 class ScoreTrainer:
     """ScoreNet + Adam + StepLR with the reference's hyper-parameters; ``step(pc, pc_score)`` is one
     training iteration on this rank's scenes and returns the (local) loss."""

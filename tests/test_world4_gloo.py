@@ -1,0 +1,122 @@
+"""Four gloo ranks on the CPU (configs[3] at 4 GPUs: global batch 16 = 4 scenes per rank; configs[4]: 32 over 8):
+disjoint scene shards for every step, ONE gradient collective per training iteration through ``GradientBucket`` (created
+lazily: the process group is initialised AFTER the trainer-side object exists), replicas bit-identical after the optimizer
+steps, BatchNorm running statistics per rank until ``broadcast_buffers`` / ``save_checkpoint`` hands out rank 0's, and only
+rank 0 writing the checkpoint.  Host-side helpers of ``sharding.pin_rank`` on made-up core lists."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.multiprocessing as mp
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_scene_shards_are_disjoint_and_cover_the_global_batch():
+    from regnet_for_3d_grasping_amd import sharding
+    for world, global_batch in ((2, 16), (4, 16), (8, 32)):      # BASELINE.json configs[3] (2 and 4 GPUs) and configs[4]
+        per_rank = global_batch // world
+        for step in range(3):
+            seen = []
+            for rank in range(world):
+                seeds = sharding.scene_seeds(rank, world, per_rank, step=step)
+                assert len(seeds) == per_rank
+                seen += seeds
+            assert len(set(seen)) == global_batch                                   # disjoint across ranks
+            assert sorted(seen) == list(range(1000 + step * global_batch, 1000 + (step + 1) * global_batch))
+
+
+def test_rank_core_slices_are_disjoint_and_never_empty():
+    from regnet_for_3d_grasping_amd import sharding
+    assert sharding._parse_cpulist("0-3,8-9\n") == [0, 1, 2, 3, 8, 9]
+    node = sharding._parse_cpulist("0-31,128-159")                                  # one NUMA node of a 2-socket SMT host
+    slices = [sharding.rank_core_slice(r, 4, node) for r in range(4)]
+    assert all(len(s) == 16 for s in slices) and len({c for s in slices for c in s}) == 64
+    assert sharding.rank_core_slice(5, 8, [0, 1, 2]) in ([0], [1], [2])             # more ranks than cores: still one core
+    assert sharding.gpu_numa_node(0) is None or isinstance(sharding.gpu_numa_node(0), int)
+
+
+class _Tiny(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        from regnet_for_3d_grasping_amd.pn2_utils.modules import PointNetSAModule, PointnetFPModule
+        self.sa = PointNetSAModule(3, (16, 32), 32, 0.2, 16, True)
+        self.fp = PointnetFPModule(32 + 3, (16,), 3)
+        self.head = torch.nn.Conv1d(16, 1, 1)
+
+    def forward(self, pc, target):
+        pts = pc.permute(0, 2, 1)
+        xyz, rgb = pts[:, :3, :], pts[:, 3:6, :]
+        new_xyz, feat = self.sa(xyz, rgb)
+        return torch.nn.functional.mse_loss(torch.sigmoid(self.head(self.fp(xyz, new_xyz, rgb, feat))).squeeze(1), target)
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, REPO)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    import torch.distributed as td
+    from oracle.install import oracle_backend
+    from regnet_for_3d_grasping_amd import sharding, synthetic, train_step
+    torch.manual_seed(rank)                     # DIFFERENT start per rank: the bucket's creation must broadcast rank 0's
+    net = _Tiny().train()
+    holder = train_step.ScoreTrainer.__new__(train_step.ScoreTrainer)      # the trainer's bucket logic on a small network
+    holder.net, holder.reduce, holder.bucket = net, "sum", None
+    holder._ensure_bucket()
+    assert holder.bucket is None               # no process group yet
+    sharding.init("gloo")                      # ... initialised AFTER the trainer exists
+    calls = []
+    orig = td.all_reduce
+
+    def counting(t, *a, **k):
+        calls.append(int(t.numel()))
+        return orig(t, *a, **k)
+    td.all_reduce = counting
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    seeds_seen = []
+    for step in range(2):
+        holder._ensure_bucket()
+        assert holder.bucket is not None
+        seeds = sharding.scene_seeds(rank, world, 1, first_seed=6000, step=step)
+        seeds_seen.append(seeds)
+        pc = torch.from_numpy(np.stack([synthetic.make_scene(s, 512) for s in seeds], 0))
+        target = torch.from_numpy(np.random.default_rng(seeds[0]).uniform(0, 1, (1, 512)).astype(np.float32))
+        holder.bucket.prepare()
+        with oracle_backend():
+            net(pc, target).backward()
+        holder.bucket.reduce_gradients()
+        opt.step()
+    td.all_reduce = orig
+    stats_before = net.sa.mlp[0].bn.running_mean.clone()
+    ckpt = os.path.join(out_dir, "tiny_%d.model")
+    train_step.save_checkpoint(net, None, ckpt % 0 if rank == 0 else ckpt % rank, None)    # collective: every rank calls it
+    torch.save({"calls": calls, "seeds": seeds_seen, "params": {k: p.detach().clone() for k, p in net.named_parameters()},
+                "stats_before": stats_before, "stats_after": net.sa.mlp[0].bn.running_mean.clone(),
+                "n_grad": sum(p.numel() for p in net.parameters()), "n_params": len(list(net.parameters())),
+                "wrote": os.path.exists(ckpt % rank)}, os.path.join(out_dir, "w4_rank%d.pt" % rank))
+    td.destroy_process_group()
+
+
+def test_four_ranks_one_collective_per_iteration_and_rank0_checkpoint(tmp_path):
+    for var in ("OMP_NUM_THREADS", "MKL_NUM_THREADS"):
+        os.environ[var] = "1"
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    world = 4
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    parts = [torch.load(os.path.join(tmp_path, "w4_rank%d.pt" % r)) for r in range(world)]
+    p0 = parts[0]
+    all_seeds = [s for p in parts for step in p["seeds"] for s in step]
+    assert len(set(all_seeds)) == 2 * world and sorted(all_seeds) == list(range(6000, 6000 + 2 * world))
+    for p in parts:
+        assert p["calls"] == [p0["n_grad"] + p0["n_params"]] * 2          # ONE collective per iteration, same length everywhere
+        for k in p0["params"]:
+            assert torch.equal(p["params"][k], p0["params"][k]), k         # lazily created bucket broadcast rank 0's start
+        assert torch.equal(p["stats_after"], p0["stats_before"])           # save_checkpoint: every rank holds rank 0's buffers
+    assert any(not torch.equal(p["stats_before"], p0["stats_before"]) for p in parts[1:])   # ... which differed per shard before
+    assert [p["wrote"] for p in parts] == [True, False, False, False]      # only rank 0 writes
