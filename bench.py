@@ -223,6 +223,43 @@ def pmc_traffic(kernel):
         return None
 
 
+def traffic_source():
+    """Is profiles/pmc_traffic.json still about THIS library?  Every kernel name the PMC passes recorded (``kernel_names`` per
+    family, scripts/collect_pmc.py) must be a kernel of the library that is loaded now (``nm -C`` of the .so: the kernel
+    handles carry rocprofv3's demangled spelling).  -> {"file", "stale": True / False / None (no names recorded or no nm),
+    "missing": [...]}."""
+    import subprocess
+    from regnet_for_3d_grasping_amd import _lib
+    path = os.path.join(REPO, "profiles", "pmc_traffic.json")
+    out = {"file": "profiles/pmc_traffic.json", "stale": None, "missing": []}
+    try:
+        with open(path) as f:
+            recorded = sorted({n for v in json.load(f).values() if isinstance(v, dict) for n in v.get("kernel_names", [])})
+        syms = subprocess.run(["nm", "-C", "--defined-only", _lib.LIB_PATH], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+                              text=True, timeout=60).stdout
+    except (OSError, ValueError, subprocess.SubprocessError):
+        return out
+    if not recorded or not syms:
+        return out
+    have = set()
+    for line in syms.splitlines():
+        parts = line.split(" ", 2)
+        if len(parts) == 3:
+            name = parts[2].strip()
+            name = name[5:] if name.startswith("void ") else name
+            depth = 0
+            for i, ch in enumerate(name):
+                depth += ch == "<"
+                depth -= ch == ">"
+                if ch == "(" and depth == 0:
+                    name = name[:i]
+                    break
+            have.add(name)
+    out["missing"] = [n for n in recorded if n not in have]
+    out["stale"] = bool(out["missing"])
+    return out
+
+
 def cpu_baseline(args, n_scenes, gpu_models=None):
     """The same forward on the host CPU: the host-side mirror driven by the C oracle (OpenMP) and
     torch-CPU 1x1 convs.  Bounded sample: ``n_scenes`` scenes of the bench workload, batch 1.
@@ -234,7 +271,8 @@ def cpu_baseline(args, n_scenes, gpu_models=None):
     score_net, region_net = pipeline.build_models("cpu")
     pc0 = synthetic.make_batch(1000, 1, args.points)
     first_out = None
-    with oracle_backend():
+    from oracle import pn2_ext_oracle
+    with oracle_backend(), pn2_ext_oracle.native_build() as native:
         if gpu_models is not None:
             score_net.load_state_dict({k: v.cpu() for k, v in gpu_models[0].state_dict().items()})
             region_net.load_state_dict({k: v.cpu() for k, v in gpu_models[1].state_dict().items()})
@@ -269,9 +307,10 @@ def cpu_baseline(args, n_scenes, gpu_models=None):
             parity["grasp_max_abs_err"] = (float((got["next_grasp"].cpu() - first_out["next_grasp"]).abs().max())
                                            if same else None)
     return {"value": n_scenes / dt, "unit": "scenes/s", "cores": threads, "kind": "port",
-            "sample": "%d scene(s) x %d pts, batch 1, eval forward (%s), oracle C kernels (OpenMP) + torch-CPU convs, "
+            "sample": "%d scene(s) x %d pts, batch 1, eval forward (%s), oracle C kernels (OpenMP, %s) + torch-CPU convs, "
                       "%.1f s total; host %s" % (n_scenes, args.points,
-                                                 "ScoreNet" if args.score_only else "ScoreNet+grouping+GRN+refine", dt,
+                                                 "ScoreNet" if args.score_only else "ScoreNet+grouping+GRN+refine",
+                                                 "-O3 -march=native, built on this host" if native else "-O2 portable build", dt,
                                                  _cpu_model()),
             "parity": parity}
 
@@ -657,6 +696,10 @@ def main():
                                                 "max": round(max(shares), 4), "batches": len(shares)}
                 roofline["executed_share_of_algorithmic_flops"] = round(1.0 - 0.5 * small * 49152.0 / 49920.0, 4)
                 roofline["frac_executed"] = round(roofline["frac"] * roofline["executed_share_of_algorithmic_flops"], 4)
+        if roofline:
+            src = traffic_source()
+            roofline["traffic_source"] = src
+            roofline["traffic_source_stale"] = src["stale"]
         if roofline and getattr(pipe, "split_chain_tail", False):
             roofline["overlap_note"] = ("the previous batch's last chain kernel leaves its partial final round of row blocks (64 of "
                                         "1600 workgroup passes) on a side stream; it runs beside the first ~0.25 ms of this kernel's "

@@ -64,6 +64,36 @@ def fma_contracted():
         _lib = saved
 
 
+@__import__("contextlib").contextmanager
+def native_build():
+    """bench.py's cpu_baseline leg: inside the block the kernels come from a ``-O3 -march=native`` build of the same source
+    made on THIS host (the portable -O2 library stays the checker's).  Falls back to the portable build when
+    the host has no compiler."""
+    global _lib
+    import socket
+    so = os.path.join(_HERE, "_build", "libpn2_oracle_native.so")
+    stamp = so + ".host"
+    src = os.path.join(_HERE, "pn2_oracle.c")
+    host = socket.gethostname()
+    try:
+        fresh = (os.path.exists(so) and os.path.getmtime(so) >= os.path.getmtime(src) and os.path.exists(stamp)
+                 and open(stamp).read() == host)
+        if not fresh:
+            subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "_build/libpn2_oracle_native.so"])
+            with open(stamp, "w") as f:
+                f.write(host)
+        native = _load(so)
+    except (OSError, subprocess.CalledProcessError):
+        native = None
+    saved = _lib
+    if native is not None:
+        _lib = native
+    try:
+        yield native is not None
+    finally:
+        _lib = saved
+
+
 def _check(rc, what):
     if rc != 0:
         raise RuntimeError("oracle %s failed (rc=%d)" % (what, rc))

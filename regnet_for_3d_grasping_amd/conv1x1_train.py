@@ -12,10 +12,10 @@ import os
 
 import torch
 
-ENABLED = os.environ.get("REGNET_CONV1X1_TRAIN", "1") != "0"
+ENABLED = True     # module switches (bench.py --set conv1x1_train.ENABLED=0); nothing in the product reads the environment
 # 1: forward / input gradient / weight gradient on this repo's own fp32-MFMA kernels (csrc/tgemm.hip) whenever the
 # shape qualifies (channel counts multiples of 16, see regnet_conv1x1_train_supported); 0: rocBLAS batched GEMMs only
-NATIVE = os.environ.get("REGNET_CONV1X1_NATIVE", "1") != "0"
+NATIVE = True
 
 
 def _native_ok(B, Co, Ci, L, wgrad=False):

@@ -52,9 +52,16 @@ def _stamp():
     return h.hexdigest()
 
 
-def build_variant(out_path, defines):
+REPO = os.path.dirname(os.path.dirname(HERE))
+# measurement twins of product sources (scripts/ablate/): the product translation units carry no measurement branches
+MEASURE_SOURCES = {"geometry.hip": os.path.join(REPO, "scripts", "ablate", "geometry_measure.hip")}
+CHAIN_TRACE = ["-DCH_TRACE_H=\"%s\"" % os.path.join(REPO, "scripts", "ablate", "chain_trace.h")]
+
+
+def build_variant(out_path, defines, measure=False):
     """An extra copy of the library with -D defines applied to every source (A/B measurements only, e.g.
-    ``build_variant('/tmp/x.so', ['-DRC_WAVES=4'])``); the product library is ``build()``'s."""
+    ``build_variant('/tmp/x.so', ['-DRC_WAVES=4'])``); the product library is ``build()``'s.  ``measure=True`` swaps in
+    the measurement twins of ``MEASURE_SOURCES`` (the FPS_ABLATE / FPS_ONE_BARRIER / FPS_FORCE_MULTI branches live there)."""
     hipcc = _hipcc()
     objs = []
     tmp = out_path + ".objs"
@@ -62,7 +69,8 @@ def build_variant(out_path, defines):
     procs = []
     for src, extra in SOURCES:
         obj = os.path.join(tmp, src.replace(".hip", ".o"))
-        procs.append(subprocess.Popen([hipcc] + COMMON + extra + list(defines) + ["-c", os.path.join(HERE, src), "-o", obj]))
+        path = MEASURE_SOURCES.get(src, os.path.join(HERE, src)) if measure else os.path.join(HERE, src)
+        procs.append(subprocess.Popen([hipcc] + COMMON + extra + ["-I", HERE] + list(defines) + ["-c", path, "-o", obj]))
         objs.append(obj)
     for p in procs:
         if p.wait() != 0:

@@ -173,17 +173,17 @@ __device__ __forceinline__ void chain_group(const ChainArgs& p, const float* __r
   }
 }
 
-#ifdef CH_TRACE   // timing experiments only (scripts/wg_timeline.py): per-workgroup start / end stamps (100 MHz) + placement
-__device__ unsigned long long* g_ch_trace = nullptr;
-extern "C" int regnet_debug_set_chain_trace(unsigned long long* buf) {
-  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_ch_trace), &buf, sizeof(buf));
-}
+// Measurement hook: scripts/wg_timeline.py builds a variant with -DCH_TRACE_H='"<repo>/scripts/ablate/chain_trace.h"', which
+// defines the two macros (per-workgroup start / end stamps + placement) and its own debug export; the product compiles none.
+#ifdef CH_TRACE_H
+#include CH_TRACE_H
+#else
+#define CH_TRACE_BEGIN()
+#define CH_TRACE_END()
 #endif
 
 __global__ __launch_bounds__(CH_THREADS, 2) void sa_chain_kernel(const ChainArgs p) {
-#ifdef CH_TRACE
-  const unsigned long long tr_t0 = __builtin_amdgcn_s_memrealtime();
-#endif
+  CH_TRACE_BEGIN();
   __shared__ __attribute__((aligned(16))) float sW2[CH_C * CH_LD];
   __shared__ __attribute__((aligned(16))) float sW3[2][32 * CH_LD];
   __shared__ __attribute__((aligned(16))) float sW1[CH_C * 12];   // [c][w0..w7 | scale | shift | 0 0]
@@ -241,14 +241,7 @@ __global__ __launch_bounds__(CH_THREADS, 2) void sa_chain_kernel(const ChainArgs
 
   if (npt == 2) chain_group<2>(p, sW2, sW3, sW1, sS2, sT2, x, gs, valid, w3a, w3b, tid, lane, fr, fh, t_row0, t_c4);
   else chain_group<1>(p, sW2, sW3, sW1, sS2, sT2, x, gs, valid, w3a, w3b, tid, lane, fr, fh, t_row0, t_c4);
-#ifdef CH_TRACE
-  if (g_ch_trace && tid == 0) {
-    unsigned long long* t = g_ch_trace + (long long)blockIdx.x * 4;
-    t[0] = tr_t0; t[1] = __builtin_amdgcn_s_memrealtime();
-    t[2] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_ID
-    t[3] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // XCC_ID
-  }
-#endif
+  CH_TRACE_END();
 }
 
 static bool aligned16c(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }

@@ -20,7 +20,7 @@ ENABLED = True
 CHAIN3 = True   # level-1 set-abstraction block as one register-chained kernel (see sa_features)
 SPLITK_MAX_ROWS = 1024   # at most this many rows: the GEMM is "skinny" and is split along K (see mlp_layer)
 PREMUL = True   # evaluate the first layer of wide set-abstraction blocks per source point (see sa_features)
-PREMUL_CENTRE = __import__("os").environ.get("REGNET_PREMUL_CENTRE", "1") != "0"   # ... on mean-centred coordinates
+PREMUL_CENTRE = True   # ... on mean-centred coordinates (a module switch like the others: bench.py --set fused.PREMUL_CENTRE=0)
 
 _check = _lib.check
 _L = _lib.lib

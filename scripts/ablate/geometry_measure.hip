@@ -1,3 +1,7 @@
+// MEASUREMENT TWIN of regnet_for_3d_grasping_amd/csrc/geometry.hip (round 4): the same kernels WITH the timing / ablation
+// branches the product source used to carry -- FPS_ABLATE (phase stamps, skipped stages: results are wrong), FPS_ONE_BARRIER,
+// FPS_FORCE_MULTI.  Built only by scripts (csrc/build.py:build_variant(measure=True), scripts/ablate/fps_ablate.cpp); the
+// numbers in DESIGN.md par. 5.1 / 11.1 and profiles/r03_fps_* came from these branches.  Never part of libregnet_hip.so.
 // geometry.hip -- furthest point sampling, ball query, 3-NN for gfx950 (CDNA4, wave64).
 //
 // Built with -ffp-contract=off: every index these kernels emit depends on fp32 compares of
@@ -9,6 +13,9 @@
 //   3-NN       csrc/interpolate_kernel.cu:28-77
 #include "common.h"
 
+#ifndef FPS_ABLATE
+#define FPS_ABLATE 0  // 0 = product; >0 = timing experiments of scripts/ablate (results are wrong)
+#endif
 
 // =====================================================================================
 // Furthest point sampling
@@ -85,6 +92,13 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
     lo = take ? olo : lo;                                                                                          \
   }
 
+#ifndef FPS_ONE_BARRIER
+#define FPS_ONE_BARRIER 0   // 1: fps_sorted_kernel with ONE barrier per round (measurement builds, scripts/fps_multi_probe.py).
+                            // Bit-identical, but SLOWER: 2.02 us per round against 1.63 (N = 25 600, one scene) -- every wave
+                            // then searches its candidate's slot in front of the barrier (75 VALU instructions x 16 waves on 4
+                            // SIMDs) where the two-barrier scheme lets the ONE winning wave do it; what the second barrier
+                            // costs is less than that.
+#endif
 
 // min(a, b) for non-NaN operands as ONE v_min_f32 (fminf() inserts a canonicalising v_max first).
 __device__ __forceinline__ float vmin_f32(float a, float b) {
@@ -190,6 +204,15 @@ __device__ __forceinline__ unsigned spread4(unsigned v) {  // 4 bits -> every th
   return (v & 1u) | ((v & 2u) << 2) | ((v & 4u) << 4) | ((v & 8u) << 6);
 }
 
+#if FPS_ABLATE == 11
+__device__ unsigned long long fps_dbg[8];
+#endif
+#if FPS_ABLATE == 9
+__device__ unsigned long long fps_dbg[8];
+#define FPS_T(k) do { if (blockIdx.x == 0) { unsigned long long t_ = __builtin_readcyclecounter(); if (tid == tstamp_tid) atomicAdd(&fps_dbg[k], t_ - tprev); tprev = t_; } } while (0)
+#else
+#define FPS_T(k) do {} while (0)
+#endif
 
 template <int PPT>
 __device__ __forceinline__ float dist_at(const float (&d)[PPT], int s) {  // register array, dynamic index
@@ -250,6 +273,7 @@ __global__ __launch_bounds__(1024) void fps_sorted_kernel(const float* __restric
   __shared__ float red[6][W];
   __shared__ unsigned wsum[W];
   __shared__ unsigned win_key[2];
+  __shared__ uint2 rec[2][W];          // FPS_ONE_BARRIER: per wave (bits of its maximum, ~its smallest tie-break key)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* base = xyz + (int64_t)blockIdx.x * sb;
   int64_t* out = index + (int64_t)blockIdx.x * M;
@@ -387,7 +411,15 @@ __global__ __launch_bounds__(1024) void fps_sorted_kernel(const float* __restric
     }
     __syncthreads();
     int i = 1, last = 0;
+#if FPS_ABLATE == 9
+    const int tstamp_tid = 0;
+    unsigned long long tprev = __builtin_readcyclecounter();
+#endif
     while (i < M) {
+      FPS_T(0);
+#if FPS_ABLATE == 9
+      if (blockIdx.x == 0 && tid == 0) atomicAdd(&fps_dbg[7], 1ull);
+#endif
       const int n = __builtin_amdgcn_readfirstlane(acc_n);
       bool scanned = false;
       for (int c = 0; c < n; ++c) {
@@ -402,6 +434,7 @@ __global__ __launch_bounds__(1024) void fps_sorted_kernel(const float* __restric
           scanned = true;
         }
       }
+      FPS_T(1);
       if (scanned) {   // wave-uniform: this wave's rows get new records
         float t1 = dist[0], t2 = -1.f;
 #pragma unroll
@@ -433,7 +466,9 @@ __global__ __launch_bounds__(1024) void fps_sorted_kernel(const float* __restric
           rrec_b[row] = make_float2(sz, __int_as_float(tid * PPT + slot));
         }
       }
+      FPS_T(2);
       __syncthreads();
+      FPS_T(3);
       if (wave == 0) {
         const float4 ra = rrec_a[lane];
         const float2 rb = rrec_b[lane];
@@ -479,7 +514,9 @@ __global__ __launch_bounds__(1024) void fps_sorted_kernel(const float* __restric
         }
         if (lane == 0) { acc_n = cnt; fb_mx = m0; }
       }
+      FPS_T(4);
       __syncthreads();
+      FPS_T(5);
       const int got = __builtin_amdgcn_readfirstlane(acc_n);
       if (got > 0) {
         last = __builtin_amdgcn_readfirstlane(__float_as_int(accb[got - 1].w));
@@ -514,13 +551,26 @@ __global__ __launch_bounds__(1024) void fps_sorted_kernel(const float* __restric
   }
 
   int cur = 0;
+#if FPS_ABLATE == 9
+  const int tstamp_tid = 0;
+  unsigned long long tprev = __builtin_readcyclecounter();
+#endif
   for (int i = 1; i < M; ++i) {
     const int buf = i & 1;
+    FPS_T(0);
+#if FPS_ABLATE == 3
+    const float cx = 0.001f * cur, cy = 0.002f * cur, cz = 0.75f;  // no centroid load
+#else
     const float cx = base[(int64_t)cur * sn];
     const float cy = base[sc + (int64_t)cur * sn];
     const float cz = base[2 * sc + (int64_t)cur * sn];
+#endif
     const bool need = sqdist3(qx, qy, qz, cx, cy, cz) < thr;
-    if (__ballot(need) != 0ull) {  // wave-uniform: scan all 64 lanes' points (extra updates are no-ops)
+#if FPS_ABLATE == 9
+    asm volatile("" :: "v"(need ? 1 : 0));
+    FPS_T(1);
+#endif
+    if (FPS_ABLATE != 1 && (FPS_ABLATE == 4 || __ballot(need) != 0ull)) {  // wave-uniform: scan all 64 lanes' points (extra updates are no-ops)
       float m = 0.f;
 #pragma unroll
       for (int s = 0; s < PPT; ++s) {
@@ -532,16 +582,65 @@ __global__ __launch_bounds__(1024) void fps_sorted_kernel(const float* __restric
       const float reach = R + sqrtf(m) * 1.0001f;
       thr = has_points ? reach * reach * 1.0001f + 1e-30f : -1.f;
     }
+    FPS_T(2);
     const float wmax = wave_max_f32(tmax);
+#if FPS_ONE_BARRIER && FPS_ABLATE == 0
+    {
+      // ONE barrier per round: every wave settles its own candidate BEFORE the barrier -- the lanes holding the wave's
+      // maximum look up which slot it was and their tie-break key (the search rounds 1-2 ran after a first barrier, in the
+      // winning wave only: it was on the critical path there too), the wave's smallest key and its maximum go to LDS as one
+      // 64-bit record; behind the barrier every wave reduces the 16 records by itself (4 DPP steps on (bits, ~key) pairs:
+      // largest distance, then smallest key -- the order the two-barrier scheme realised with a block maximum followed by
+      // an LDS atomicMin over the keys).  No atomics, no second barrier, no re-arming; records are double-buffered by the
+      // round's parity (a wave can be at most one barrier ahead of the slowest).
+      unsigned kmin = 0xffffffffu;
+      if (wmax > 0.f && tmax == wmax) {
+        int nmatch = 0, slot = 0;
+#pragma unroll
+        for (int s = 0; s < PPT; ++s) {
+          const bool hit = dist[s] == wmax;
+          nmatch += hit ? 1 : 0;
+          slot = hit ? s : slot;
+        }
+        kmin = fps_key((int)perm[tid * PPT + slot], rb_log2);
+        if (nmatch > 1) {
+#pragma unroll 1
+          for (int s = 0; s < PPT; ++s)
+            if (dist_at(dist, s) == wmax) kmin = min(kmin, fps_key((int)perm[tid * PPT + s], rb_log2));
+        }
+      }
+      const unsigned wkey = wave_min_u32(kmin);
+      if (lane == 0) rec[buf][wave] = make_uint2(__float_as_uint(wmax), ~wkey);
+      __syncthreads();
+      const uint2 r16 = rec[buf][lane & (W - 1)];
+      unsigned hi = r16.x, lo = r16.y;
+      DPP_MAXPAIR_STEP(hi, lo, 0xB1)
+      DPP_MAXPAIR_STEP(hi, lo, 0x4E)
+      DPP_MAXPAIR_STEP(hi, lo, 0x141)
+      DPP_MAXPAIR_STEP(hi, lo, 0x140)
+      const unsigned bhi = (unsigned)__builtin_amdgcn_readfirstlane((int)hi);
+      const unsigned blo = (unsigned)__builtin_amdgcn_readfirstlane((int)lo);
+      if (bhi != 0u) cur = fps_unkey(~blo, rb_log2);      // all distances 0: repeat cur (the reference's max_ind stays cur)
+      cur = __builtin_amdgcn_readfirstlane(cur);
+      if (tid == 0) out[i] = cur;
+      continue;
+    }
+#endif
     if (lane == 0) part[buf][wave] = wmax;
+    FPS_T(3);
     __syncthreads();
     if (tid == 0) win_key[buf ^ 1] = 0xffffffffu;   // after the barrier: see fps_resident_kernel
+    FPS_T(4);
     float mx = 0.f;
 #pragma unroll
     for (int w4 = 0; w4 < W / 4; ++w4) {
       const float4 v = *reinterpret_cast<const float4*>(&part[buf][w4 * 4]);
       mx = fmaxf(fmaxf(mx, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
     }
+#if FPS_ABLATE == 2
+    cur = (i * 37) % N;  // no stage 2
+    if (mx < 0.f) cur = 0;
+#else
     if (mx > 0.f && tmax == mx) {
       // which slot(s) hold the maximum?  Branch-free count + last match (pure VALU), ONE LDS read
       // for the usual single match; several equal maxima in one thread (duplicated points) take
@@ -561,9 +660,12 @@ __global__ __launch_bounds__(1024) void fps_sorted_kernel(const float* __restric
       }
       atomicMin(&win_key[buf], kmin);
     }
+    FPS_T(5);
     __syncthreads();
+    FPS_T(6);
     const unsigned key = win_key[buf];
     if (key != 0xffffffffu) cur = fps_unkey(key, rb_log2);
+#endif
     cur = __builtin_amdgcn_readfirstlane(cur);
     if (tid == 0) out[i] = cur;
   }
@@ -837,10 +939,24 @@ __global__ __launch_bounds__(1024) void fps_cluster_kernel(const float* __restri
     picks[0] = -1;                            // entries < 0: -(original index + 1); >= 0: workgroup << 24 | sorted position
   }
   __syncthreads();
+#if FPS_ABLATE == 10
+  return;                                     // measurement build: the prologue alone (sort, loads, cluster spheres)
+#endif
   int i = 1;
   unsigned round = 0;                         // MULTI: exchange tag (every workgroup of the scene runs the same rounds)
+#if FPS_ABLATE == 11
+  const unsigned long long t_loop0 = __builtin_readcyclecounter();
+#endif
   float rho = 0.5f;                           // wave 0: candidate threshold as a fraction of the maximum (adaptive)
+#if FPS_ABLATE == 9
+  const int tstamp_tid = 0;
+  unsigned long long tprev = __builtin_readcyclecounter();
+#endif
   while (i < M) {
+    FPS_T(0);
+#if FPS_ABLATE == 9
+    if (blockIdx.x == 0 && tid == 0) atomicAdd(&fps_dbg[7], 1ull);
+#endif
     const int n = __builtin_amdgcn_readfirstlane(acc_n);
     bool touched = false;
     for (int c = 0; c < n; ++c) {
@@ -849,6 +965,9 @@ __global__ __launch_bounds__(1024) void fps_cluster_kernel(const float* __restri
       const float cy = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a.y)));
       const float cz = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a.z)));
       unsigned mask = (unsigned)__ballot(sqdist3(cqx, cqy, cqz, cx, cy, cz) < cthr);    // lanes >= PPT: cthr = -1
+#if FPS_ABLATE == 9
+      if (blockIdx.x == 0 && lane == 0) atomicAdd(&fps_dbg[6], (unsigned long long)__popc(mask));
+#endif
       while (mask) {
         const int s = __builtin_ctz(mask);
         mask &= mask - 1;
@@ -858,11 +977,14 @@ __global__ __launch_bounds__(1024) void fps_cluster_kernel(const float* __restri
         }
       }
     }
+    FPS_T(1);
     if (touched) {
       const float reach = cR + sqrtf(fmaxf(cmax, 0.f)) * 1.0001f;
       cthr = cthr >= 0.f ? reach * reach * 1.0001f + 1e-30f : -1.f;
     }
+    FPS_T(2);
     __syncthreads();
+    FPS_T(3);
     if (wave == 0) {
       // 64 lane records out of the C cluster records: the lane's best cluster and a bound on everything else it looked at
       int l_ = lane;                       // opaque: addresses derived from it are recomputed here, not kept (spilled) across the loop
@@ -986,8 +1108,17 @@ __global__ __launch_bounds__(1024) void fps_cluster_kernel(const float* __restri
         if (l_ == 0) { acc_n = cnt; fb_mx = m0; }
       }
     }
+    FPS_T(4);
     __syncthreads();
+    FPS_T(5);
     const int got = __builtin_amdgcn_readfirstlane(acc_n);
+#if FPS_ABLATE == 11   // measurement build: when (cycle counter since the loop began) the run passes 32 / 64 / 128 / 256 / 1024 picks
+    if (blockIdx.x == 0 && tid == 0 && got > 0) {
+      const int marks[5] = {32, 64, 128, 256, 1024};
+      for (int k = 0; k < 5; ++k)
+        if (i < marks[k] && i + got >= marks[k]) fps_dbg[k] = __builtin_readcyclecounter() - t_loop0;
+    }
+#endif
     if (MULTI && got < 0) break;            // (uniform: acc_n is the workgroup's)
     if (got > 0) {
       i += got;
@@ -1256,6 +1387,9 @@ static int64_t fps_xchg_offset_floats(int64_t B, int64_t N) { return (B * N + 3)
 
 extern "C" int64_t regnet_fps_workspace_bytes(int64_t B, int64_t N, int64_t M) {
   (void)M;
+#ifdef FPS_FORCE_MULTI
+  if (N > 8192 && N <= FPS_RESIDENT_MAX) return B * 64;
+#endif
 #if FPS_CLUSTERS
   if (N > 8192 && N <= FPS_RESIDENT_MAX && M >= 1024 && M <= FPS_CLUSTER_MAX_PICKS)
     return B * N * (int64_t)sizeof(unsigned);   // fps_cluster_kernel: the sort's permutation
@@ -1312,6 +1446,19 @@ extern "C" int regnet_fps_f32(const float* xyz, int64_t sb, int64_t sc, int64_t 
   // The in-thread scan keeps the first strict maximum in slot order; that equals the reference's
   // order only if all points of a thread share one reference lane (j mod RB), i.e. T % RB == 0 or
   // one point per thread.  Hence T = RB (PPT 1) up to 512 points and T in {512, 1024} above.
+#ifdef FPS_FORCE_MULTI   // measurement builds only (scripts/fps_multi_probe.py): G cooperating workgroups also for N <= 25 600
+  if (N > 8192 && N <= FPS_RESIDENT_MAX && M < 32768 && FPS_FORCE_MULTI * B <= fps_num_cus()) {
+    if (!workspace) return REGNET_ERR_NULL;
+    const int G = FPS_FORCE_MULTI;
+    const int Bpad = (int)((B + 7) / 8 * 8);
+    hipError_t e = hipMemsetAsync(workspace, 0, (size_t)B * 64, st);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL((fps_multi_kernel<25>), dim3((unsigned)(Bpad * G)), dim3(1024), 0, st, xyz, sb, sc, sn, (int)N,
+                       (int)M, rbl, G, (int)B, Bpad, (unsigned long long*)workspace, index);
+    REGNET_LAUNCH_CHECK();
+    return REGNET_OK;
+  }
+#endif
   if (regnet_fps_workspace_bytes(B, N, M) > 0 && !workspace) return REGNET_ERR_NULL;
   if (N <= 64) FPS_CASE(64, 1);
   else if (N <= 128) FPS_CASE(128, 1);

@@ -36,6 +36,23 @@ def family(kernel_name):
     return None
 
 
+NAMES = collections.defaultdict(set)   # family -> exact kernel names (rocprofv3's demangled spelling) the passes saw
+
+
+def short_name(kernel_name):
+    """'void fps_cluster_kernel<25, 8, false>(float const*, ...)' -> 'fps_cluster_kernel<25, 8, false>'."""
+    name = kernel_name.strip()
+    if name.startswith("void "):
+        name = name[5:]
+    depth = 0
+    for i, ch in enumerate(name):
+        depth += ch == "<"
+        depth -= ch == ">"
+        if ch == "(" and depth == 0:
+            return name[:i]
+    return name
+
+
 def collect(directory, counter):
     tot, n = collections.Counter(), collections.Counter()
     for f in glob.glob(directory + "/**/*counter_collection.csv", recursive=True):
@@ -44,6 +61,7 @@ def collect(directory, counter):
             if fam and r["Counter_Name"] == counter:
                 tot[fam] += float(r["Counter_Value"])
                 n[fam] += 1
+                NAMES[fam].add(short_name(r["Kernel_Name"]))
     return tot, n
 
 
@@ -61,7 +79,9 @@ def main(fetch_dir, write_dir):
                     "fetch_correction": corr,
                     "write_size_kib_per_launch_raw": round(write_kib, 1),
                     "write_calibration": round(wcal, 4),
-                    "hbm_bytes_per_launch": int((fetch_kib * corr + write_kib * wcal) * 1024)}
+                    "hbm_bytes_per_launch": int((fetch_kib * corr + write_kib * wcal) * 1024),
+                    # what bench.py holds against the library's kernel list (roofline.traffic_source.stale)
+                    "kernel_names": sorted(NAMES[fam])}
     json.dump(out, sys.stdout, indent=1, sort_keys=True)
     print()
 

@@ -1,6 +1,6 @@
 """MEASURE (not argue) a 2-4-CU cooperative furthest point sampling at N = 25 600: the library's fps_multi_kernel -- the
 kernel that serves scenes beyond one CU's register file -- forced onto single-CU-sized scenes by measurement builds
-(-DFPS_FORCE_MULTI=G, built here with csrc/build.py:build_variant into scripts/ablate/), against the default
+(-DFPS_FORCE_MULTI=G of scripts/ablate/geometry_measure.hip, built here with csrc/build.py:build_variant(measure=True)), against the default
 single-workgroup fps_sorted_kernel<25>.  One subprocess per library; outputs are compared bit for bit.
 
     python scripts/fps_multi_probe.py build      # authoring container (hipcc cross-compiles)
@@ -17,9 +17,9 @@ LIBS = {"default (1 workgroup per scene)": None,
 if len(sys.argv) > 1 and sys.argv[1] == "build":
     from regnet_for_3d_grasping_amd.csrc import build
     for g, path in ((2, LIBS["2 cooperating workgroups"]), (4, LIBS["4 cooperating workgroups"])):
-        build.build_variant(path, ["-DFPS_FORCE_MULTI=%d" % g])
+        build.build_variant(path, ["-DFPS_FORCE_MULTI=%d" % g], measure=True)
         print("built", path)
-    build.build_variant(LIBS["one barrier per round (-DFPS_ONE_BARRIER=1)"], ["-DFPS_ONE_BARRIER=1"])
+    build.build_variant(LIBS["one barrier per round (-DFPS_ONE_BARRIER=1)"], ["-DFPS_ONE_BARRIER=1"], measure=True)
     sys.exit(0)
 
 if len(sys.argv) > 1 and sys.argv[1] == "child":
