@@ -140,7 +140,7 @@ def install_timers(timer):
     import regnet_for_3d_grasping_amd.get_regiondataset as grd
     import regnet_for_3d_grasping_amd.gripper_region_network as grn
     ext = fn.pn2_ext
-    timer.wrap(ext, "farthest_point_sample", lambda p, m: ("B%d N%d M%d" % (p.size(0), p.size(2), m)))
+    timer.wrap(ext, "farthest_point_sample", lambda p, m, chain=None: ("B%d N%d M%d" % (p.size(0), p.size(2), m)))
     timer.wrap(ext, "ball_query", lambda p, c, r, k: ("B%d N%d M%d K%d" % (p.size(0), p.size(2), c.size(2), k)))
     timer.wrap(ext, "point_search", lambda q, k, n: ("B%d Q%d K%d" % (q.size(0), q.size(2), k.size(2))))
     timer.wrap(ext, "group_points_forward", lambda x, i: ("B%d C%d M%d K%d" % (x.size(0), x.size(1), i.size(1), i.size(2))))

@@ -52,6 +52,21 @@ int regnet_fps_f32(const float* xyz, int64_t sb, int64_t sc, int64_t sn, int64_t
  * through which the 2-4 cooperating workgroups of a scene exchange their candidate records + 256 bytes (status word).  The callee
  * initialises it; `workspace` may be NULL when this returns 0.                                   */
 int64_t regnet_fps_workspace_bytes(int64_t B, int64_t N, int64_t M);
+/* regnet_fps_f32 for a cloud that is itself a furthest-point-sampling sequence -- what PointNet++ does at levels 2 and 3:
+ * FarthestPointSampler over the previous level's centroids in their pick order (pointnet2.py:40-42, modules.py:23-26).
+ * Pick k+1 of the producing run was the furthest point of the WHOLE cloud from picks 0..k, hence also the furthest among
+ * the picks themselves, with the same fp32 distance: sampling the sequence from index 0 re-derives 0, 1, 2, ... unless two
+ * points TIE at a maximum (the reference's tie order depends on array positions, which differ between the two runs).
+ *   first_tie (B) int32, may be NULL: written with the first pick position (>= 1) of THIS run whose choice was not a unique
+ *             strict maximum (several holders, or all distances zero); 0x7fffffff when there was none; 0 = "not tracked"
+ *             (the single-workgroup round kernels for short runs and the streaming kernels; cooperating workgroups count
+ *             every pick of their exact one-pick path).
+ *   prefix_ok (B) int32, may be NULL: the `first_tie` of the run that PRODUCED this cloud's order.  Scenes with
+ *             prefix_ok[b] >= M get index[b, :] = 0 .. M-1 without sampling (and first_tie[b] = prefix_ok[b]); the others are
+ *             sampled as by regnet_fps_f32.  Results are identical to regnet_fps_f32's either way.
+ * Same workspace and errors as regnet_fps_f32.                                                                           */
+int regnet_fps_chain_f32(const float* xyz, int64_t sb, int64_t sc, int64_t sn, int64_t B, int64_t N, int64_t M,
+                         int64_t* index, float* workspace, const int32_t* prefix_ok, int32_t* first_tie, void* stream);
 /* Byte offset, inside that workspace, of the launch's 32-bit status word, or -1 when the kernel (B,N,M) selects has
  * none (every single-workgroup kernel).  The cooperative kernels (N > 25600) poll each other's exchange slots with a
  * bounded budget; a workgroup whose partner never answered ORs bit 0 into the word and stops sampling -- `index` is

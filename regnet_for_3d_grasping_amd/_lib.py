@@ -18,6 +18,7 @@ SIGNATURES = {
     "regnet_build_info": (ctypes.c_char_p, []),
     "regnet_strerror": (ctypes.c_char_p, [_int]),
     "regnet_fps_f32": (_int, [_vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp]),
+    "regnet_fps_chain_f32": (_int, [_vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
     "regnet_fps_workspace_bytes": (_i64, [_i64, _i64, _i64]),
     "regnet_fps_status_offset_bytes": (_i64, [_i64, _i64, _i64]),
     "regnet_ball_query_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _f32, _i64,

@@ -100,10 +100,33 @@ __device__ __forceinline__ float vmin_f32(float a, float b) {
 //            key with an LDS atomic min -> barrier -> every lane decodes the winner.
 // Searching the slot after the fact costs 2 instructions per point in (typically) one wave instead
 // of 2 per point in all sixteen.
+// ---- sampling a cloud that is itself a furthest-point-sampling sequence (levels 2 and 3 of the network) ----------------
+// PointNet++ samples level l+1 from the level-l centroids IN THEIR PICK ORDER, starting from index 0 (pointnet2.py:40-42,
+// modules.py:23-26).  Pick k+1 of the level-l run was the point of the WHOLE cloud furthest from picks 0..k; it is one of
+// the level-l centroids, so it is also the furthest among THEM, with the same fp32 distance (same two points, same
+// formula): the level-(l+1) run re-derives picks 0, 1, 2, ... of level l.  The only way out is a TIE at the maximum,
+// which the two runs break by different rules (the reference's tie order depends on positions in the array, and those
+// differ).  So a run reports `first_tie` -- the first pick position whose choice was not a unique strict maximum -- and a
+// run over its result whose `prefix_ok` (= that value) is >= M writes 0 .. M-1 and returns: no sampling at all, bit-exact
+// by construction (and by tests/test_gpu_ops.py against the oracle, which does sample).  Kernels that do not track ties
+// report 0 ("unknown"): the next level then samples for real.
+__device__ __forceinline__ bool fps_prefix_shortcut(const int* __restrict__ prefix_ok, int* __restrict__ first_tie, int b,
+                                                    int M, int64_t* __restrict__ out, int tid, int T, bool writer) {
+  if (!prefix_ok) return false;
+  const int ok = prefix_ok[b];                    // workgroup-uniform
+  if (ok < M) return false;
+  if (writer) {
+    for (int k = tid; k < M; k += T) out[k] = k;
+    if (tid == 0 && first_tie) first_tie[b] = ok;
+  }
+  return true;
+}
+
 template <int T, int PPT>
 __global__ __launch_bounds__(T) void fps_resident_kernel(const float* __restrict__ xyz, int64_t sb, int64_t sc,
                                                          int64_t sn, int N, int M, int rb_log2,
-                                                         int64_t* __restrict__ index) {
+                                                         int64_t* __restrict__ index, const int* __restrict__ prefix_ok,
+                                                         int* __restrict__ first_tie) {
   constexpr int W = T / 64;
   constexpr int WP = (W + 3) / 4 * 4;
   __shared__ __attribute__((aligned(16))) float part[2][WP];
@@ -111,6 +134,8 @@ __global__ __launch_bounds__(T) void fps_resident_kernel(const float* __restrict
   const int tid = threadIdx.x;
   const float* base = xyz + (int64_t)blockIdx.x * sb;
   int64_t* out = index + (int64_t)blockIdx.x * M;
+  if (fps_prefix_shortcut(prefix_ok, first_tie, (int)blockIdx.x, M, out, tid, T, true)) return;
+  if (first_tie && tid == 0) first_tie[blockIdx.x] = 0;   // this kernel does not track ties: "unknown"
 
   float px[PPT], py[PPT], pz[PPT], dist[PPT];
 #pragma unroll
@@ -242,8 +267,12 @@ __device__ __forceinline__ float readlane_f32(float v, int lane) {
 template <int PPT, int KP>
 __global__ __launch_bounds__(1024) void fps_sorted_kernel(const float* __restrict__ xyz, int64_t sb, int64_t sc,
                                                           int64_t sn, int N, int M, int rb_log2,
-                                                          int64_t* __restrict__ index) {
+                                                          int64_t* __restrict__ index, const int* __restrict__ prefix_ok,
+                                                          int* __restrict__ first_tie) {
   constexpr int T = 1024, W = 16, CELLS = 4096;
+  if (fps_prefix_shortcut(prefix_ok, first_tie, (int)blockIdx.x, M, index + (int64_t)blockIdx.x * M, (int)threadIdx.x, T, true))
+    return;
+  if (first_tie && threadIdx.x == 0) first_tie[blockIdx.x] = 0;   // this kernel does not track ties: "unknown"
   __shared__ unsigned perm[T * PPT];   // sorted position -> original index (also the tie-break lookup)
   __shared__ unsigned hist[CELLS];     // histogram, then exclusive offsets
   __shared__ __attribute__((aligned(16))) float part[2][W];
@@ -766,7 +795,7 @@ __device__ __forceinline__ void fps_morton_perm(const float* __restrict__ base, 
     break;
 #define FPS_SLOT_FALLBACK(S)                                                                                           \
   if constexpr (S < PPT) {                                                                                             \
-    if (dist##S == mx) kmin = min(kmin, fps_key(n0 + (int)perm[S * 1024 + tid], rb_log2));                             \
+    if (dist##S == mx) { kmin = min(kmin, fps_key(n0 + (int)perm[S * 1024 + tid], rb_log2)); nm += 1; }                \
   }
 
 // MULTI: G = 2..4 cooperating workgroups per scene (scenes beyond one CU's registers: 25 600 < N <= 102 400).  Workgroup h owns
@@ -785,7 +814,8 @@ template <int PPT, int KP, bool MULTI>
 __global__ __launch_bounds__(1024) void fps_cluster_kernel(const float* __restrict__ xyz, int64_t sb, int64_t sc,
                                                            int64_t sn, int N, int M, int rb_log2,
                                                            unsigned* __restrict__ perm_ws, int64_t* __restrict__ index,
-                                                           int G, int B, int Bpad, float* __restrict__ xchg_ws) {
+                                                           int G, int B, int Bpad, float* __restrict__ xchg_ws,
+                                                           const int* __restrict__ prefix_ok, int* __restrict__ first_tie) {
   static_assert(PPT <= 25 && KP >= 1 && KP <= 15, "one lane per cluster of a wave, one DPP row of candidates");
   constexpr int T = 1024, W = 16, CELLS = 4096, C = PPT * 16;
   __shared__ float pzl[T * PPT];     // z of sorted position q (x, y and the running distance are registers)
@@ -797,6 +827,7 @@ __global__ __launch_bounds__(1024) void fps_cluster_kernel(const float* __restri
     h = (int)(blockIdx.x / (unsigned)Bpad);
     if (b >= B) return;
   }
+  if (fps_prefix_shortcut(prefix_ok, first_tie, b, M, index + (int64_t)b * M, (int)threadIdx.x, 1024, h == 0)) return;
   const int Nh = MULTI ? (N + G - 1) / G : N;          // slice length; this workgroup's slice is [n0, n0 + Nl)
   const int n0 = h * Nh, Nl = min(N - n0, Nh);
   unsigned* perm = perm_ws + (int64_t)b * N + n0;      // sorted position -> index inside the slice: N words of workspace per scene
@@ -830,13 +861,16 @@ __global__ __launch_bounds__(1024) void fps_cluster_kernel(const float* __restri
     rec_v[g] = make_float2(-1.f, -1.f);
     if (g < C) rec_p[g] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
+  __shared__ int tie_cnt;                     // one-pick path: points holding the maximum (this workgroup's)
   if (tid == 0) {
     accb[0] = make_float4(base[0], base[sc], base[2 * sc], __int_as_float(-1));
     acc_n = 1;
     win_key = 0xffffffffu;
+    tie_cnt = 0;
     picks[0] = -1;                            // entries < 0: -(original index + 1); >= 0: workgroup << 24 | sorted position
   }
   __syncthreads();
+  int tie_at = 0x7fffffff;                    // (thread 0) first pick position that was not a unique strict maximum
   int i = 1;
   unsigned round = 0;                         // MULTI: exchange tag (every workgroup of the scene runs the same rounds)
   float rho = 0.5f;                           // wave 0: candidate threshold as a fraction of the maximum (adaptive)
@@ -997,8 +1031,9 @@ __global__ __launch_bounds__(1024) void fps_cluster_kernel(const float* __restri
     const float mx = fb_mx;
     if (mx > 0.f) {
       unsigned kmin = 0xffffffffu;
+      int nm = 0;
       FPS_SLOTS(FPS_SLOT_FALLBACK)
-      if (kmin != 0xffffffffu) atomicMin(&win_key, kmin);
+      if (kmin != 0xffffffffu) { atomicMin(&win_key, kmin); atomicAdd(&tie_cnt, nm); }
     }
     __syncthreads();
     if constexpr (MULTI) {
@@ -1027,6 +1062,11 @@ __global__ __launch_bounds__(1024) void fps_cluster_kernel(const float* __restri
     __syncthreads();
     if (MULTI && key == FPS_LOST_KEY) break;
     if (tid == 0) {
+      // a pick of this path is a unique strict maximum only if exactly ONE point held it (the multi-pick rounds accept
+      // nothing else by construction); several holders, or all distances zero, is where a run over the picks could differ.
+      // Cooperating workgroups only see their own holders: every pick of this path counts there (it is rare)
+      if (MULTI || tie_cnt != 1) tie_at = min(tie_at, i);
+      tie_cnt = 0;
       win_key = 0xffffffffu;
       if (key != 0xffffffffu) {
         const int cur1 = fps_unkey(key, rb_log2);
@@ -1051,6 +1091,7 @@ __global__ __launch_bounds__(1024) void fps_cluster_kernel(const float* __restri
       out[k] = (int64_t)n0 + (int64_t)perm[v & 0xffffff];
     }
   }
+  if (first_tie && tid == 0 && h == 0) first_tie[b] = tie_at;
 }
 
 // Fallback for scenes too large to keep resident: min-distances live in a caller-provided
@@ -1280,29 +1321,43 @@ extern "C" int64_t regnet_fps_status_offset_bytes(int64_t B, int64_t N, int64_t 
 
 #define FPS_CASE(T, PPT)                                                                                  \
   hipLaunchKernelGGL((fps_resident_kernel<T, PPT>), dim3((unsigned)B), dim3(T), 0, st, xyz, sb, sc, sn, \
-                     (int)N, (int)M, rbl, index)
+                     (int)N, (int)M, rbl, index, prefix_ok, first_tie)
 
 #define FPS_WAVE_CASE(PPT)                                                                                       \
   hipLaunchKernelGGL((fps_sorted_kernel<PPT, FPS_PICKS>), dim3((unsigned)B), dim3(1024), 0, st, xyz, sb, sc, sn, \
-                     (int)N, (int)M, rbl, index)
+                     (int)N, (int)M, rbl, index, prefix_ok, first_tie)
 #if FPS_CLUSTERS
 #define FPS_CLUSTER_LIMIT FPS_CLUSTER_MAX_PICKS
 #define FPS_SORTED_CASE(PPT)                                                                                          \
   hipLaunchKernelGGL((fps_cluster_kernel<PPT, FPS_CLUSTER_PICKS, false>), dim3((unsigned)B), dim3(1024), 0, st, xyz, \
                      sb, sc, sn, (int)N, (int)M, rbl, reinterpret_cast<unsigned*>(workspace), index, 1, (int)B, (int)B,    \
-                     (float*)nullptr)
+                     (float*)nullptr, prefix_ok, first_tie)
 // G cooperating workgroups per scene; the exchange area sits behind the B x N permutation words of the workspace
 #define FPS_COOP_CASE(PPT)                                                                                                \
   hipLaunchKernelGGL((fps_cluster_kernel<PPT, FPS_CLUSTER_PICKS, true>), dim3((unsigned)(Bpad * G)), dim3(1024), 0, st,   \
                      xyz, sb, sc, sn, (int)N, (int)M, rbl, reinterpret_cast<unsigned*>(workspace), index, G, (int)B, Bpad, \
-                     workspace + fps_xchg_offset_floats(B, N))
+                     workspace + fps_xchg_offset_floats(B, N), prefix_ok, first_tie)
 #else
 #define FPS_CLUSTER_LIMIT (1 << 30)
 #define FPS_SORTED_CASE(PPT) FPS_WAVE_CASE(PPT)
 #endif
 
+static int fps_launch(const float* xyz, int64_t sb, int64_t sc, int64_t sn, int64_t B, int64_t N, int64_t M, int64_t* index,
+                      float* workspace, const int* prefix_ok, int* first_tie, void* stream);
+
 extern "C" int regnet_fps_f32(const float* xyz, int64_t sb, int64_t sc, int64_t sn, int64_t B, int64_t N, int64_t M,
                               int64_t* index, float* workspace, void* stream) {
+  return fps_launch(xyz, sb, sc, sn, B, N, M, index, workspace, nullptr, nullptr, stream);
+}
+
+extern "C" int regnet_fps_chain_f32(const float* xyz, int64_t sb, int64_t sc, int64_t sn, int64_t B, int64_t N, int64_t M,
+                                    int64_t* index, float* workspace, const int32_t* prefix_ok, int32_t* first_tie,
+                                    void* stream) {
+  return fps_launch(xyz, sb, sc, sn, B, N, M, index, workspace, prefix_ok, first_tie, stream);
+}
+
+static int fps_launch(const float* xyz, int64_t sb, int64_t sc, int64_t sn, int64_t B, int64_t N, int64_t M, int64_t* index,
+                      float* workspace, const int* prefix_ok, int* first_tie, void* stream) {
   if (M <= 0 || N < M || B < 0) return REGNET_ERR_SHAPE;
   if (N >= (int64_t)1 << 30) return REGNET_ERR_UNSUPPORTED;
   if (B == 0) return REGNET_OK;
@@ -1358,10 +1413,15 @@ extern "C" int regnet_fps_f32(const float* xyz, int64_t sb, int64_t sc, int64_t 
     const int Bpad = (int)((B + 7) / 8 * 8);                                       // a scene's workgroups on one XCD
     hipError_t e = hipMemsetAsync(workspace, 0, (size_t)B * 64, st);               // round tag 0 = "nothing published"
     if (e != hipSuccess) return (int)e;
+    if (first_tie && (e = hipMemsetAsync(first_tie, 0, (size_t)B * sizeof(int), st)) != hipSuccess) return (int)e;   // "unknown"
     hipLaunchKernelGGL((fps_multi_kernel<25>), dim3((unsigned)(Bpad * G)), dim3(1024), 0, st, xyz, sb, sc, sn, (int)N,
                        (int)M, rbl, G, (int)B, Bpad, (unsigned long long*)workspace, index);
   } else {
     if (!workspace) return REGNET_ERR_NULL;
+    if (first_tie) {
+      hipError_t e = hipMemsetAsync(first_tie, 0, (size_t)B * sizeof(int), st);    // (no tie tracking, no shortcut: "unknown")
+      if (e != hipSuccess) return (int)e;
+    }
     hipLaunchKernelGGL((fps_streaming_kernel<1024>), dim3((unsigned)B), dim3(1024), 0, st, xyz, sb, sc, sn, (int)N,
                        (int)M, rbl, workspace, index);
   }

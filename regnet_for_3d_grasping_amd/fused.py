@@ -410,17 +410,25 @@ def _as_channels_last(feature):
 # Every block is split into its GEOMETRY part (indices; depends on xyz only) and its FEATURE part
 # (the MLP chain).  Called back to back they are the module forward; pipeline.ForwardPipeline runs
 # the geometry of batch i+1 on another stream while the features of batch i are on the matrix cores.
-def sa_sample(module, xyz):
-    """Furthest point sampling of a PointNetSAModule (modules.py:23-26): the long latency chain."""
-    return pn2_ext.farthest_point_sample(xyz, module.num_centroids)
+def sa_sample(module, xyz, prefix_ok=None):
+    """Furthest point sampling of a PointNetSAModule (modules.py:23-26): the long latency chain.  -> (ctr, first_tie).
+    ``prefix_ok``: the ``first_tie`` of the sampling run that produced ``xyz``'s ORDER when ``xyz`` is the previous level's
+    centroids in pick order (never anything else): scenes whose run had no tie among its first M picks then get 0 .. M-1
+    without sampling -- the same indices the sampling would return (pn2_ext.FpsChain, csrc/geometry.hip)."""
+    chain = pn2_ext.FpsChain(prefix_ok)
+    ctr = pn2_ext.farthest_point_sample(xyz, module.num_centroids, chain)
+    return ctr, chain.first_tie
 
 
-def sa_group(module, xyz, ctr):
-    """Centroid gather + ball query given the sampled indices (modules.py:41, :238-239)."""
+def sa_group(module, xyz, ctr, first_tie=None):
+    """Centroid gather + ball query given the sampled indices (modules.py:41, :238-239).  ``first_tie``: of the run that
+    sampled ``ctr`` (kept in the plan: the next level's ``prefix_ok``)."""
     B, M = ctr.shape
     new_xyz = torch.gather(xyz, 2, ctr[:, None, :].expand(B, 3, M))
     nbr, count = pn2_ext.ball_query(xyz, new_xyz, module.grouper.radius, module.grouper.num_neighbours)
     geo = {"ctr": ctr, "new_xyz": new_xyz, "nbr": nbr}
+    if first_tie is not None:
+        geo["first_tie"] = first_tie
     if (CHAIN3 and module.grouper.num_neighbours == 64 and len(module.mlp) == 3
             and module.mlp[0].conv.in_channels <= 8):
         # for the register-chained block (narrow gathered input, sa_features): neighbourhoods with <= 32 members first
@@ -452,9 +460,13 @@ def sa_group(module, xyz, ctr):
     return geo
 
 
-def sa_geometry(module, xyz, ctr=None):
-    """FPS + centroid gather + ball query of a PointNetSAModule."""
-    return sa_group(module, xyz, sa_sample(module, xyz) if ctr is None else ctr)
+def sa_geometry(module, xyz, ctr=None, prefix_ok=None):
+    """FPS + centroid gather + ball query of a PointNetSAModule.  ``prefix_ok``: see sa_sample (``xyz`` must then be the
+    previous level's ``new_xyz``)."""
+    if ctr is not None:
+        return sa_group(module, xyz, ctr)
+    ctr, first_tie = sa_sample(module, xyz, prefix_ok)
+    return sa_group(module, xyz, ctr, first_tie)
 
 
 def sa_features(module, xyz, feature, geo):

@@ -47,8 +47,20 @@ def _eq(a, b, text):
         raise RuntimeError("%s" % text)  # CHECK_EQ
 
 
-def farthest_point_sample(points, num_centroids):
-    """points (B,3,N1) -> index (B,N2) int64.  csrc/sampling_kernel.cu:126-170."""
+class FpsChain:
+    """Optional third argument of ``farthest_point_sample`` for callers that sample a cloud which is itself a
+    furthest-point-sampling sequence (PointNet++ levels 2 and 3 sample the previous level's centroids in pick order):
+    ``prefix_ok`` in -- the ``first_tie`` tensor of the run that produced the cloud's order, or None -- and ``first_tie``
+    out, (B,) int32 (include/regnet_hip.h: regnet_fps_chain_f32).  Scenes whose producing run had no tie among its first M
+    picks get 0 .. M-1 without sampling; the result is the same tensor either way."""
+
+    def __init__(self, prefix_ok=None):
+        self.prefix_ok, self.first_tie = prefix_ok, None
+
+
+def farthest_point_sample(points, num_centroids, chain=None):
+    """points (B,3,N1) -> index (B,N2) int64.  csrc/sampling_kernel.cu:126-170.  ``chain``: see FpsChain (not part of the
+    reference's signature; the result does not depend on it)."""
     _need_f32(points, "points")
     _eq(points.dim(), 3, "points must be (B, 3, N)")
     _eq(points.size(1), 3, "points.size(1) does not equal to 3")
@@ -63,9 +75,19 @@ def farthest_point_sample(points, num_centroids):
         ws_bytes = _L.regnet_fps_workspace_bytes(B, N, M)
         ws = torch.empty((ws_bytes // 4,), dtype=torch.float32, device=points.device) if ws_bytes else None
         sb, sc, sn = points.stride()
-        _check(_L.regnet_fps_f32(points.data_ptr(), sb, sc, sn, B, N, M, index.data_ptr(),
-                                 ws.data_ptr() if ws is not None else None, _stream(points)),
-               "farthest_point_sample")
+        if chain is None:
+            _check(_L.regnet_fps_f32(points.data_ptr(), sb, sc, sn, B, N, M, index.data_ptr(),
+                                     ws.data_ptr() if ws is not None else None, _stream(points)),
+                   "farthest_point_sample")
+        else:
+            prefix = chain.prefix_ok
+            if prefix is not None and (prefix.dtype != torch.int32 or prefix.numel() != B or not prefix.is_cuda):
+                raise RuntimeError("FpsChain.prefix_ok must be a (B,) int32 GPU tensor")
+            chain.first_tie = torch.empty((B,), dtype=torch.int32, device=points.device)
+            _check(_L.regnet_fps_chain_f32(points.data_ptr(), sb, sc, sn, B, N, M, index.data_ptr(),
+                                           ws.data_ptr() if ws is not None else None,
+                                           prefix.contiguous().data_ptr() if prefix is not None else None,
+                                           chain.first_tie.data_ptr(), _stream(points)), "farthest_point_sample")
         status_at = _L.regnet_fps_status_offset_bytes(B, N, M)
         if status_at >= 0:
             # cooperative sampling (N > 25 600): accumulate the launch's status word into the device's flag -- one tiny

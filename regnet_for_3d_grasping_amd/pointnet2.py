@@ -60,7 +60,7 @@ class PointNet2Seg(nn.Module):
         if not (fused.ENABLED and xyz.is_cuda):
             raise RuntimeError("PointNet2Seg.sample_level1 needs GPU tensors")
         with torch.no_grad():
-            return fused.sa_sample(self.sa_modules[0], xyz)
+            return fused.sa_sample(self.sa_modules[0], xyz)[0]
 
     def sample_levels(self, points, after_level=None):
         """Furthest point sampling of ALL set-abstraction levels (each level samples the previous level's centroids): the
@@ -71,9 +71,10 @@ class PointNet2Seg(nn.Module):
         if not (fused.ENABLED and xyz.is_cuda):
             raise RuntimeError("PointNet2Seg.sample_levels needs GPU tensors")
         ctrs = []
+        first_tie = None         # of the level above: levels 2+ sample that level's picks in pick order (fused.sa_sample)
         with torch.no_grad():
             for sa in self.sa_modules:
-                ctr = fused.sa_sample(sa, xyz)
+                ctr, first_tie = fused.sa_sample(sa, xyz, first_tie)
                 ctrs.append(ctr)
                 if after_level is not None:
                     after_level(len(ctrs) - 1)     # (a pipeline records an event here: level 1 is usable before levels 2-3 exist)
@@ -102,10 +103,12 @@ class PointNet2Seg(nn.Module):
         from . import fused
         levels, sa_geo = [xyz], []
         ctrs = list(level1_ctr) if isinstance(level1_ctr, (list, tuple)) else [level1_ctr]
+        first_tie = None
         for i, sa in enumerate(self.sa_modules):
             if on_level is not None:
                 on_level("sa", i, None)
-            geo = fused.sa_geometry(sa, levels[-1], ctrs[i] if i < len(ctrs) else None)
+            geo = fused.sa_geometry(sa, levels[-1], ctrs[i] if i < len(ctrs) else None, prefix_ok=first_tie)
+            first_tie = geo.get("first_tie")    # None when this level's picks were handed in: the next level samples for real
             if on_level is not None:
                 on_level("sa", i, geo)
             sa_geo.append(geo)
@@ -121,17 +124,26 @@ class PointNet2Seg(nn.Module):
 
     def forward(self, points, add_channel1=None, add_channel2=None, plan=None):
         B, _, N = points.size()
+        from . import fused
         xyz_stack, feat_stack = [points[:, :3, :]], [points[:, 3:6, :]]
+        first_tie = None     # fused path: the sampling certificate of the level above (fused.sa_sample)
         for level, sa in enumerate(self.sa_modules):
             if plan is not None:
                 _wait_ready(plan["sa"][level])
                 xyz, feat = sa(xyz_stack[-1], feat_stack[-1], geo=plan["sa"][level])
+            elif (type(sa) is PointNetSAModule and fused.usable(sa, xyz_stack[-1]) and sa.num_centroids > 0
+                  and sa.grouper is not None and fused.supports_sa(sa, feat_stack[-1])):
+                # the module's own fused forward, with its geometry made here so that levels 2+ know their input is the
+                # level above's pick sequence (no sampling launch at all unless that run had a tie)
+                geo = fused.sa_geometry(sa, xyz_stack[-1], prefix_ok=first_tie)
+                first_tie = geo.get("first_tie")
+                xyz, feat = sa(xyz_stack[-1], feat_stack[-1], geo=geo)
             else:
+                first_tie = None
                 xyz, feat = sa(xyz_stack[-1], feat_stack[-1])
             xyz_stack.append(xyz)
             feat_stack.append(feat)
 
-        from . import fused
         sparse_xyz, sparse_feature = xyz_stack[-1], feat_stack[-1]
         for level, fp in enumerate(self.fp_modules):
             dense_xyz = xyz_stack[-2 - level]

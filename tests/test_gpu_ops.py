@@ -160,6 +160,79 @@ def test_fps_cooperative_cluster_kernel_bit_exact(ext, orc, B, N, M, dup, grid):
         N, M, (got != want).nonzero()[:1].tolist())
 
 
+CHAIN_CASES = [  # (B, N, (M1, M2, M3), dup, grid)
+    (3, 25600, (5120, 1024, 256), 0.0, None),      # the network's three levels on generic clouds
+    (2, 51200, (5120, 1024, 256), 0.0, None),      # level 1 on cooperating workgroups
+    (2, 6144, (5120, 1024, 256), 0.0, None),       # the small golden configuration
+    (2, 25600, (5120, 1024, 256), 0.3, None),      # duplicated points: zero distances and exact ties
+    (2, 12000, (4096, 1024, 256), 0.0, 0.05),      # lattice: ties at the maximum are frequent
+    (1, 30000, (2048, 1024, 300), 0.1, 0.02),      # cooperative + lattice + duplicates
+    (2, 3000, (1024, 512, 64), 0.0, None),         # level 1 on a kernel that does not track ties ("unknown")
+    (1, 9000, (8800, 8000, 3000), 0.0, None),      # nearly every point picked, long chains
+]
+
+
+@pytest.mark.parametrize("B,N,Ms,dup,grid", CHAIN_CASES)
+def test_fps_chain_levels_equal_independent_sampling(ext, orc, B, N, Ms, dup, grid):
+    """Levels 2 and 3 sample the level above's centroids in pick order; with the level above's ``first_tie`` handed down
+    (pn2_ext.FpsChain) scenes without a tie get 0 .. M-1 without sampling.  Whatever the shortcut does, every level must
+    equal the ORACLE's sampling of the same cloud (which knows nothing of the shortcut), bit for bit."""
+    x = cloud(4200 + N + Ms[0], B, N, dup, grid)
+    xyz_gpu, xyz_cpu = x.to(DEV), x.contiguous()
+    prefix = None
+    shortcuts = 0
+    for level, M in enumerate(Ms):
+        chain = ext.FpsChain(prefix)
+        got = ext.farthest_point_sample(xyz_gpu, M, chain)
+        want = orc.farthest_point_sample(xyz_cpu, M)
+        assert torch.equal(got.cpu(), want), "level %d (N=%d M=%d): first difference at %s" % (
+            level + 1, xyz_cpu.shape[2], M, (got.cpu() != want).nonzero()[:1].tolist())
+        tie = chain.first_tie.cpu()
+        assert tie.dtype == torch.int32 and tie.shape == (B,)
+        if prefix is not None:
+            took = prefix.cpu() >= M
+            shortcuts += int(took.sum())
+            for b in range(B):
+                if took[b]:           # the shortcut's claim, checked against the oracle above; its certificate is handed down
+                    assert torch.equal(want[b], torch.arange(M)) and int(tie[b]) == int(prefix[b])
+        # a certificate must never claim more than the truth: wherever first_tie says "no tie among the first m picks", the
+        # next level's oracle sampling of the picks must be 0 .. m-1 (checked by the next iteration through `want`)
+        prefix = chain.first_tie
+        xyz_gpu = torch.gather(xyz_gpu, 2, got[:, None, :].expand(B, 3, M))
+        xyz_cpu = torch.gather(xyz_cpu, 2, want[:, None, :].expand(B, 3, M)).contiguous()
+    if dup == 0.0 and grid is None and N >= 6144:
+        assert shortcuts == 2 * B, "generic clouds: both lower levels of every scene should have skipped their sampling"
+
+
+def test_fps_chain_is_what_the_network_uses(ext, orc, monkeypatch):
+    """PointNet2Seg.sample_levels / plan / the no-plan forward hand the certificate down: three FPS calls per forward, the
+    second and third with a prefix; all three index tensors equal the oracle's."""
+    from regnet_for_3d_grasping_amd import pipeline, synthetic
+    net, _ = pipeline.build_models(DEV)
+    pc = synthetic.make_batch(7300, 2, 25600).to(DEV)
+    calls = []
+    orig = ext.farthest_point_sample
+
+    def spy(points, m, chain=None):
+        out = orig(points, m, chain)
+        calls.append((points.detach().clone(), int(m), chain is not None and chain.prefix_ok is not None, out.clone()))
+        return out
+    monkeypatch.setattr(ext, "farthest_point_sample", spy)
+    for run in ("sample_levels", "plan", "forward"):
+        calls.clear()
+        with torch.no_grad():
+            if run == "sample_levels":
+                net.sample_levels(pc)
+            elif run == "plan":
+                net.plan(pc)
+            else:
+                net(pc)
+        assert [c[1] for c in calls] == [5120, 1024, 256], run
+        assert [c[2] for c in calls] == [False, True, True], run
+        for points, m, _, out in calls:
+            assert torch.equal(out.cpu(), orc.farthest_point_sample(points.cpu().contiguous(), m)), (run, m)
+
+
 def test_fps_cooperative_status_word_is_accumulated_and_raised_lazily(ext):
     """A cooperative launch's status word (bit 0: a poll ran out of budget, the workgroup stopped sampling) is OR-ed into a
     per-device flag on the launch's stream; ``raise_if_fps_failed`` reads it where the caller synchronises.  A healthy
