@@ -11,6 +11,9 @@ score_net, region_net = pipeline.build_models(DEV)
 pc = synthetic.make_batch(1000, 8, 25600).to(DEV)
 synthetic.calibrate_score_head(score_net, pc)
 np.random.seed(1)
+WITH_REGION = os.environ.get("WITH_REGION", "1") != "0"       # 0: the pipeline without its region stage (bench.py --score-only)
+if WITH_REGION and os.environ.get("CALIB", "1") != "0":      # 1: region head calibrated, the refine network runs (round 4)
+    synthetic.calibrate_region_head(region_net, lambda: pipeline.forward_scenes(score_net, region_net, pc))
 rec = []
 
 class Probe(pipeline.ForwardPipeline):
@@ -34,7 +37,7 @@ class Probe(pipeline.ForwardPipeline):
         rec.append((t0, time.perf_counter(), e0, e1, geo_ev, geo_enq))
         return item
 
-pipe = Probe(score_net, region_net, first_launch_groups=4)
+pipe = Probe(score_net, region_net, with_region=WITH_REGION, first_launch_groups=4)
 for _ in pipe.run((pc for _ in range(5))):
     pass
 torch.cuda.synchronize()
