@@ -274,6 +274,20 @@ int regnet_gather_max_arg_f32(const float* feat, int64_t num_rows, int64_t F, co
                               float* out, int64_t* arg, void* stream);
 int regnet_rowsum_neg_f32(const float* x, int64_t rows, int64_t K, float* out, void* stream);
 
+/* Decodes of the two grasp heads WITHOUT labels (inference), one launch each instead of ~25 / ~12 small tensor ops.
+ * regnet_stage2_decode_f32 (gripper_region_network.py:69-90, `ground is None`): cls (n,A), reg (n,A,C >= 7), centre rows
+ * (n, centre_ld >= 3), tmpl (A,4) = the anchors' [r | theta] -> out (n,C): the arg-max anchor's regression turned into
+ * [delta*radius + centre | (delta + r)/sqrt(|.|^2 + 1e-12) | pi*(delta + theta) | channels 7..], the latter through a
+ * sigmoid when sigmoid_tail != 0 (pointnet2.py:187, for a head that hands over raw values).
+ * regnet_refine_decode_f32 (gripper_region_network.py:201-215): grasp (n, grasp_ld >= C), cls (n,2), reg (n,C >= 8) ->
+ * final_grasp (n,C) = grasp + deltas (the first three times radius), flags (2,n) uint8: [class 1 | class 1 and
+ * final[:,7] > score_thre].                                                                                            */
+int regnet_stage2_decode_f32(const float* cls, const float* reg, int64_t A, int64_t C, const float* centre,
+                             int64_t centre_ld, const float* tmpl, float radius, int sigmoid_tail, int64_t n, float* out,
+                             void* stream);
+int regnet_refine_decode_f32(const float* grasp, int64_t grasp_ld, const float* cls, const float* reg, int64_t C,
+                             float radius, float score_thre, int64_t n, float* final_grasp, uint8_t* flags, void* stream);
+
 /* regnet_gripper_frame_f32: grasp (n, ld >= 7) rows [centre | closing axis | theta | ...] -> centre (n,3), rot (n,3,3) with rows
  * [approach; axis_y; minor_normal] -- the frame maths of get_gripper_region_transform (gripper_region_network.py:447-506) in
  * one launch.  regnet_crop_pick: the drawn candidate positions of a box crop resolved to group positions and scene indices

@@ -262,6 +262,81 @@ extern "C" int regnet_gripper_frame_f32(const float* grasp, int64_t ld, int64_t 
   return REGNET_OK;
 }
 
+// Stage-2 decode without labels (gripper_region_network.py:69-90 with `ground is None`): per centre, the arg-max anchor's
+// regression becomes the grasp -- centre = delta * radius + centre point, closing axis = (delta + template) / sqrt(|.|^2 + 1e-12),
+// theta = pi * (delta + template), the remaining channels passed through (their sigmoid, pointnet2.py:187, applied here when
+// the head hands over raw values).  One thread per centre; every operation individually rounded (this file is compiled with
+// -ffp-contract=off) in the order of the ~25 small torch kernels it replaces.
+__global__ __launch_bounds__(64) void stage2_decode_kernel(const float* __restrict__ cls, const float* __restrict__ reg, int A, int C,
+                                                          const float* __restrict__ centre, int64_t centre_ld,
+                                                          const float* __restrict__ tmpl, float radius, int sigmoid_tail, int n,
+                                                          float* __restrict__ out) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= n) return;
+  const float* cl = cls + (int64_t)i * A;
+  int pick = 0;
+  float best = cl[0];
+  for (int a = 1; a < A; ++a)
+    if (cl[a] > best) { best = cl[a]; pick = a; }          // first maximum, as torch.max(dim) returns it
+  const float* r = reg + ((int64_t)i * A + pick) * C;
+  const float* c = centre + (int64_t)i * centre_ld;
+  const float* t = tmpl + pick * 4;
+  float* o = out + (int64_t)i * C;
+  o[0] = r[0] * radius + c[0];
+  o[1] = r[1] * radius + c[1];
+  o[2] = r[2] * radius + c[2];
+  const float ax = r[3] + t[0], ay = r[4] + t[1], az = r[5] + t[2];
+  const float norm = sqrtf(((ax * ax + ay * ay) + az * az) + 1e-12f);
+  o[3] = ax / norm; o[4] = ay / norm; o[5] = az / norm;
+  o[6] = 3.14159265358979323846f * (r[6] + t[3]);
+  for (int k = 7; k < C; ++k) o[k] = sigmoid_tail ? 1.f / (1.f + expf(-r[k])) : r[k];
+}
+
+extern "C" int regnet_stage2_decode_f32(const float* cls, const float* reg, int64_t A, int64_t C, const float* centre,
+                                        int64_t centre_ld, const float* tmpl, float radius, int sigmoid_tail, int64_t n,
+                                        float* out, void* stream) {
+  if (n < 0 || A <= 0 || C < 7 || centre_ld < 3) return REGNET_ERR_SHAPE;
+  if (n >= (int64_t)1 << 31 || A >= 1024 || C >= 1024) return REGNET_ERR_UNSUPPORTED;
+  if (n == 0) return REGNET_OK;
+  if (!cls || !reg || !centre || !tmpl || !out) return REGNET_ERR_NULL;
+  hipLaunchKernelGGL(stage2_decode_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, as_stream(stream), cls, reg, (int)A,
+                     (int)C, centre, centre_ld, tmpl, radius, sigmoid_tail, (int)n, out);
+  REGNET_LAUNCH_CHECK();
+  return REGNET_OK;
+}
+
+// Refine decode without labels (gripper_region_network.py:201-215): final = stage-2 grasp + refine deltas (centre deltas times
+// radius), predicted class = arg-max of the two class scores, flags[0] = class 1, flags[1] = class 1 and final score channel 7
+// above the threshold.  One thread per grasp.
+__global__ __launch_bounds__(64) void refine_decode_kernel(const float* __restrict__ grasp, int64_t grasp_ld,
+                                                          const float* __restrict__ cls, const float* __restrict__ reg, int C,
+                                                          float radius, float score_thre, int n, float* __restrict__ final_grasp,
+                                                          uint8_t* __restrict__ flags) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= n) return;
+  const float* g = grasp + (int64_t)i * grasp_ld;
+  const float* r = reg + (int64_t)i * C;
+  float* o = final_grasp + (int64_t)i * C;
+  for (int k = 0; k < 3; ++k) o[k] = g[k] + r[k] * radius;
+  for (int k = 3; k < C; ++k) o[k] = g[k] + r[k];
+  const bool one = cls[2 * i + 1] > cls[2 * i];            // torch.max(dim=-1)[1]: the first maximum, so class 0 on a tie
+  flags[i] = one ? 1 : 0;
+  flags[n + i] = (one && o[7] > score_thre) ? 1 : 0;
+}
+
+extern "C" int regnet_refine_decode_f32(const float* grasp, int64_t grasp_ld, const float* cls, const float* reg, int64_t C,
+                                        float radius, float score_thre, int64_t n, float* final_grasp, uint8_t* flags,
+                                        void* stream) {
+  if (n < 0 || C < 8 || grasp_ld < C) return REGNET_ERR_SHAPE;
+  if (n >= (int64_t)1 << 30 || C >= 1024) return REGNET_ERR_UNSUPPORTED;
+  if (n == 0) return REGNET_OK;
+  if (!grasp || !cls || !reg || !final_grasp || !flags) return REGNET_ERR_NULL;
+  hipLaunchKernelGGL(refine_decode_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, as_stream(stream), grasp, grasp_ld, cls,
+                     reg, (int)C, radius, score_thre, (int)n, final_grasp, flags);
+  REGNET_LAUNCH_CHECK();
+  return REGNET_OK;
+}
+
 // The drawn positions of a box crop resolved to indices (gripper_region_network.py:540-548): index[i][r] = the position
 // inside the group of the r-th drawn candidate, index_inall[i][r] = that member's index in the scene, both -1 for a grasp
 // without a valid crop (<= 5 points in the box).  One launch instead of 2 gathers, 3 `where`s and their temporaries.

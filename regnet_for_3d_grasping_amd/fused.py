@@ -919,16 +919,18 @@ def _chain(x, layers, names):
     return x
 
 
-def twostage_forward(net, mp_x):
+def twostage_forward(net, mp_x, raw_reg=False):
     """PointNet2TwoStage.forward after the max-pool (pointnet2.py:174-188): mp_x (n, 256, 1) ->
-    x_cls (n, k_cls), x_reg (n, k_cls, k_reg/k_cls) with sigmoid on channels 7:."""
+    x_cls (n, k_cls), x_reg (n, k_cls, k_reg/k_cls) with sigmoid on channels 7: (``raw_reg``: without it -- the caller's
+    decode kernel applies it to the one anchor it keeps, region_ops.stage2_decode)."""
     n = mp_x.shape[0]
     L = _packed_named(net, _TWOSTAGE)
     x = mp_x.reshape(n, -1).contiguous()
     h = mlp_layer(x, L["conv"].K, L["conv"], n)
     x_cls = _chain(h, L, ["conv_cls2", "conv_cls3", "conv_cls4"])
     x_reg = _chain(h, L, ["conv_reg2", "conv_reg3", "conv_reg4"]).view(n, -1, net.k_reg_no_anchor)
-    x_reg[:, :, 7:] = torch.sigmoid(x_reg[:, :, 7:])
+    if not raw_reg:
+        x_reg[:, :, 7:] = torch.sigmoid(x_reg[:, :, 7:])
     return x_cls, x_reg
 
 

@@ -167,6 +167,16 @@ class GripperRegionNetwork(nn.Module):
         2.5 cm, its axis within 60 deg (1 - cos < 0.5) and its angle within 1.047 rad of the label;
         CE on a class-balanced subset (numpy RNG) + four smooth-L1 terms on the positives."""
         dev = next_grasp.device
+        if (next_gt is None and next_grasp.is_cuda and not torch.is_grad_enabled() and next_grasp.dtype == torch.float32
+                and hasattr(region_ops, "refine_decode")):
+            # inference: deltas, class arg-max and both selections' flags in ONE launch, one read (csrc/region.hip)
+            final_grasp, flags8 = region_ops.refine_decode(next_grasp, next_x_cls, next_x_reg, self.radius,
+                                                           self.grasp_score_thre)
+            flags = flags8.cpu().numpy().astype(bool)
+            class_select = torch.from_numpy(np.nonzero(flags[0])[0]).to(dev)
+            score_select = torch.from_numpy(np.nonzero(flags[1])[0]).to(dev)
+            return (final_grasp[class_select], final_grasp[score_select], next_grasp[class_select], class_select,
+                    score_select, (None, None), (None, None, None, None))
         final_grasp = next_grasp.clone()
         final_grasp[:, :3] = final_grasp[:, :3] + next_x_reg[:, :3] * self.radius
         final_grasp[:, 3:] = final_grasp[:, 3:] + next_x_reg[:, 3:]
@@ -258,17 +268,28 @@ class GripperRegionNetwork(nn.Module):
         """Shapes as the reference (gripper_region_network.py:361-375); returns its 16-tuple."""
         B, N_C, N_G, _ = pc_group.shape
         N = all_feature.shape[1]
-        anchors = self._enumerate_anchors(center_pc[:, :, :3].reshape(-1, 3).float())
         pc_group_more_xyz = pc_group_more[:, :, :, :6].reshape(B * N_C, -1, 6)
 
         scene = torch.arange(B, device=pc_group_index.device).view(B, 1)
         rows = (pc_group_index.long().view(B, N_C * N_G) + scene * N).view(B * N_C, N_G)
         pooled = _pool_rows(all_feature, rows)                                    # (B*N_C, F, 1)
-        x_cls, x_reg, mp_center_feature = self.extrat_feature_region(pooled, None, pooled=True)
-
-        next_grasp, loss_tuple, correct_tuple, next_gt, _, true_mask = self.compute_loss(x_reg, anchors, x_cls,
-                                                                                        ground_grasp)
-        keep2 = _per_scene_counts(true_mask, N_C, B)
+        # inference without labels on the GPU: the head hands its regression over raw and ONE kernel decodes the arg-max
+        # anchor of every centre (region_ops.stage2_decode) -- no anchor tensor, no gathers; every centre is kept
+        fast = (ground_grasp is None and pooled.is_cuda and not torch.is_grad_enabled() and center_pc.dtype == torch.float32
+                and hasattr(region_ops, "stage2_decode"))
+        x_cls, x_reg, mp_center_feature = self.extrat_feature_region(pooled, None, pooled=True, raw_reg=fast)
+        if fast:
+            self.templates = self.templates.to(center_pc.device)
+            tmpl = _float_templates(self.templates)
+            next_grasp = region_ops.stage2_decode(x_cls, x_reg, center_pc.reshape(B * N_C, -1), tmpl, self.radius,
+                                                  self.extrat_feature_region.reg_is_raw)
+            true_mask, keep2 = _all_centres(B, N_C, center_pc.device)
+            loss_tuple, correct_tuple, next_gt = (None, None), (None, None, None, None), None
+        else:
+            anchors = self._enumerate_anchors(center_pc[:, :, :3].reshape(-1, 3).float())
+            next_grasp, loss_tuple, correct_tuple, next_gt, _, true_mask = self.compute_loss(x_reg, anchors, x_cls,
+                                                                                            ground_grasp)
+            keep2 = _per_scene_counts(true_mask, N_C, B)
 
         res = (None,) * 5 + (None, None, None)
         keep3 = keep3_score = None
@@ -287,6 +308,34 @@ class GripperRegionNetwork(nn.Module):
         return (next_grasp.detach(), keep2, true_mask, loss_tuple, correct_tuple, next_gt, select_class,
                 select_score, select_class_stage2, keep3, keep3_score, final_mask, final_mask_sthre,
                 loss_refine_tuple, correct_refine_tuple, gt)
+
+
+_template_cache = {}
+
+
+def _float_templates(templates):
+    """The fp16 anchor templates as a contiguous (A,4) float32 tensor on their device, converted once per tensor object."""
+    key = (id(templates), templates.device)
+    hit = _template_cache.get(key)
+    if hit is None or hit[0] is not templates:
+        _template_cache.clear()
+        hit = (templates, templates.float().reshape(-1, 4).contiguous())
+        _template_cache[key] = hit
+    return hit[1]
+
+
+_centre_cache = {}
+
+
+def _all_centres(B, per_scene, device):
+    """(true_mask, keep counts) when every centre is kept (no labels): arange(B * per_scene) and B 0-dim tensors holding
+    ``per_scene``, built once per (B, per_scene, device) -- read-only results (callers index with them, never write)."""
+    key = (B, per_scene, device)
+    if key not in _centre_cache:
+        _centre_cache[key] = (torch.arange(0, B * per_scene, device=device),
+                              list(torch.full((B,), per_scene, dtype=torch.int64, device=device).unbind(0)))
+    mask, keep = _centre_cache[key]
+    return mask, list(keep)
 
 
 def _per_scene_counts(ids, per_scene, B):

@@ -232,15 +232,19 @@ class PointNet2TwoStage(nn.Module):
             x = _head_layer(getattr(self, "conv_%s%d" % (tag, i)), getattr(self, "bn_%s%d" % (tag, i)), x, True)
         return _head_layer(getattr(self, "conv_%s4" % tag), getattr(self, "bn_%s4" % tag), x, False)
 
-    def forward(self, xyz, feature, pooled=False):
+    def forward(self, xyz, feature, pooled=False, raw_reg=False):
         """xyz: grouped features (n, 256, num_points) -- or, with ``pooled=True``, the already
-        max-pooled (n, 256, 1) tensor produced by the fused gather+max kernel."""
+        max-pooled (n, 256, 1) tensor produced by the fused gather+max kernel.  ``raw_reg`` (the fused eval path only; whether
+        it was honoured is left in ``self.reg_is_raw``): channels 7: of ``x_reg`` WITHOUT their sigmoid, for a caller whose
+        decode kernel applies it."""
         mp_x = xyz if pooled else self.mp1(xyz)
         if feature is not None:
             mp_x = torch.cat((mp_x, feature.view(feature.shape[0], feature.shape[1], 1)), dim=1)
         from . import fused
+        self.reg_is_raw = False
         if fused.usable(self, mp_x) and mp_x.shape[1] % 4 == 0:
-            x_cls, x_reg = fused.twostage_forward(self, mp_x)
+            x_cls, x_reg = fused.twostage_forward(self, mp_x, raw_reg=raw_reg)
+            self.reg_is_raw = bool(raw_reg)
             return x_cls, x_reg, mp_x
         x = _head_layer(self.conv, self.bn, mp_x, True)
         x_cls = self._branch(x, "cls")

@@ -187,6 +187,38 @@ def gripper_frame(grasp):
     return centre, rot
 
 
+def stage2_decode(x_cls, x_reg, centres, templates, radius, sigmoid_tail):
+    """x_cls (n,A), x_reg (n,A,C) contiguous float32, centres (n, >= 3) rows (any row stride), templates (A,4) float32 ->
+    next_grasp (n,C): gripper_region_network.py:69-90 without labels, one launch (csrc/region.hip)."""
+    _need_f32(x_cls, "x_cls")
+    _need_f32(x_reg, "x_reg")
+    n, A, C = x_reg.shape
+    x_cls, x_reg, templates = x_cls.contiguous(), x_reg.contiguous(), templates.contiguous()
+    c = centres if centres.stride(1) == 1 else centres.contiguous()
+    with torch.cuda.device(x_reg.device):
+        out = torch.empty((n, C), dtype=torch.float32, device=x_reg.device)
+        _check(_L.regnet_stage2_decode_f32(x_cls.data_ptr(), x_reg.data_ptr(), A, C, c.data_ptr(), c.stride(0) if n else 3,
+                                           templates.data_ptr(), float(radius), int(bool(sigmoid_tail)), n, out.data_ptr(),
+                                           _stream(x_reg)), "stage2_decode")
+    return out
+
+
+def refine_decode(grasp, x_cls, x_reg, radius, score_thre):
+    """grasp (m, >= C) rows, x_cls (m,2), x_reg (m,C) float32 -> final_grasp (m,C), flags (2,m) uint8 [class 1 | class 1 and
+    score above the threshold]: gripper_region_network.py:201-215 without labels, one launch."""
+    _need_f32(grasp, "grasp")
+    m, C = x_reg.shape
+    g = grasp if grasp.stride(1) == 1 else grasp.contiguous()
+    x_cls, x_reg = x_cls.contiguous(), x_reg.contiguous()
+    with torch.cuda.device(g.device):
+        final = torch.empty((m, C), dtype=torch.float32, device=g.device)
+        flags = torch.empty((2, m), dtype=torch.uint8, device=g.device)
+        _check(_L.regnet_refine_decode_f32(g.data_ptr(), g.stride(0) if m else C, x_cls.data_ptr(), x_reg.data_ptr(), C,
+                                           float(radius), float(score_thre), m, final.data_ptr(), flags.data_ptr(),
+                                           _stream(g)), "refine_decode")
+    return final, flags
+
+
 def crop_pick(cand, pos, valid, group_index):
     """cand (n,G) int32, pos (n,R) int64, valid (n) bool, group_index (n,G) int64 -> index, index_inall (n,R) int64."""
     n, G = cand.shape

@@ -11,5 +11,6 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --output-format csv -d $OUT/prof_train -o train -- python $REPO/bench.py --train --batch 8 --steps 24 --warmup 6 > $OUT/train_prof.log 2>&1
 cd $REPO
 python scripts/trace_tail.py $OUT/prof_train 600 60 > $OUT/train_steady_state_kernels.txt
+python scripts/trace_gaps.py $OUT/prof_train 600 40 > $OUT/train_steady_state_gaps.txt
 rm -rf $OUT/prof_train
-head -45 $OUT/train_steady_state_kernels.txt
+head -12 $OUT/train_steady_state_kernels.txt; cat $OUT/train_steady_state_gaps.txt
