@@ -237,19 +237,28 @@ class GripperRegionNetwork(nn.Module):
         return sel_class, sel_score, sel_class_stage2, class_select, score_select, loss_refine_tuple, counts
 
     def refine_forward(self, pc_group_more_xyz, pc_group_more_index, true_mask, all_feature, group_feature_mp,
-                       next_grasp, gripper_params, next_gt=None):
+                       next_grasp, gripper_params, next_gt=None, all_kept=False):
         """Crop the gripper closing box out of the large groups, pool the ScoreNet features of
-        the cropped points and refine the grasps (gripper_region_network.py:311-359)."""
+        the cropped points and refine the grasps (gripper_region_network.py:311-359).  ``all_kept``: ``true_mask`` is
+        every centre in order (inference without labels), so the reference's ``[true_mask]`` gathers are identities and
+        are not made (12.6 + 4.2 MB of copies per batch of 8)."""
         B, N = all_feature.shape[0], all_feature.shape[1]
         N_C, N_G_M = pc_group_more_index.shape[1], pc_group_more_index.shape[2]
+        if all_kept:
+            group_xyz, group_index = pc_group_more_xyz, pc_group_more_index.view(-1, N_G_M)
+        else:
+            group_xyz, group_index = pc_group_more_xyz[true_mask], pc_group_more_index.view(-1, N_G_M)[true_mask]
         _, _, index_inall, gripper_mask = get_gripper_region_transform(
-            pc_group_more_xyz[true_mask], pc_group_more_index.view(-1, N_G_M)[true_mask], next_grasp,
-            self.gripper_number, gripper_params, points_too=False)
+            group_xyz, group_index, next_grasp, self.gripper_number, gripper_params, points_too=False)
         out = [None, None, None, None, None, (None, None), (None, None), next_gt]
         self.last_valid_crops = int(len(gripper_mask))    # rows of the refine network in this call (host-known, no sync)
         if len(gripper_mask) >= 2:
-            scene = torch.arange(B, device=true_mask.device).view(-1, 1).repeat(1, N_C).view(-1)[true_mask]
-            rows = (index_inall.long() + scene.view(-1, 1) * N)[gripper_mask]
+            if all_kept:
+                scene_off = _scene_offsets(B, N_C, N, true_mask.device)
+            else:
+                scene = torch.arange(B, device=true_mask.device).view(-1, 1).repeat(1, N_C).view(-1)[true_mask]
+                scene_off = scene.view(-1, 1) * N
+            rows = (index_inall.long() + scene_off)[gripper_mask]
             gripper_feature = _pool_rows(all_feature, rows)                       # (m, F, 1)
             region_feature = group_feature_mp.view(-1, 128)[gripper_mask].contiguous()  # the 128-wide re-view quirk
             next_x_cls, next_x_reg = self.extrat_feature_refine(gripper_feature, region_feature, pooled=True)
@@ -270,8 +279,7 @@ class GripperRegionNetwork(nn.Module):
         N = all_feature.shape[1]
         pc_group_more_xyz = pc_group_more[:, :, :, :6].reshape(B * N_C, -1, 6)
 
-        scene = torch.arange(B, device=pc_group_index.device).view(B, 1)
-        rows = (pc_group_index.long().view(B, N_C * N_G) + scene * N).view(B * N_C, N_G)
+        rows = (pc_group_index.long().view(B, N_C * N_G) + _scene_offsets(B, 1, N, pc_group_index.device)).view(B * N_C, N_G)
         pooled = _pool_rows(all_feature, rows)                                    # (B*N_C, F, 1)
         # inference without labels on the GPU: the head hands its regression over raw and ONE kernel decodes the arg-max
         # anchor of every centre (region_ops.stage2_decode) -- no anchor tensor, no gathers; every centre is kept
@@ -295,7 +303,7 @@ class GripperRegionNetwork(nn.Module):
         keep3 = keep3_score = None
         if self.is_training_refine:
             res = self.refine_forward(pc_group_more_xyz, pc_group_more_index, true_mask, all_feature,
-                                      mp_center_feature, next_grasp.detach(), gripper_params, next_gt)
+                                      mp_center_feature, next_grasp.detach(), gripper_params, next_gt, all_kept=fast)
             final_mask, final_mask_sthre = res[3], res[4]
             if final_mask is not None:
                 keep3 = _per_scene_counts(final_mask, N_C, B)
@@ -325,6 +333,17 @@ def _float_templates(templates):
 
 
 _centre_cache = {}
+_offset_cache = {}
+
+
+def _scene_offsets(B, per_scene, N, device):
+    """(B * per_scene, 1) int64: scene index of every centre times N (the row offset of its scene in the flattened feature
+    map), built once per (B, per_scene, N, device); read-only."""
+    key = (B, per_scene, N, device)
+    if key not in _offset_cache:
+        _offset_cache[key] = (torch.arange(B * per_scene, device=device) // per_scene * N).view(-1, 1)
+    return _offset_cache[key]
+
 
 
 def _all_centres(B, per_scene, device):
