@@ -274,6 +274,17 @@ int regnet_gather_max_arg_f32(const float* feat, int64_t num_rows, int64_t F, co
                               float* out, int64_t* arg, void* stream);
 int regnet_rowsum_neg_f32(const float* x, int64_t rows, int64_t K, float* out, void* stream);
 
+/* regnet_heads_chain_f32: a small tree of conv(1x1) + folded eval BatchNorm (+ ReLU) layers over FEW rows in one launch -- the
+ * grasp heads of the region stage (pointnet2.py:174-188: 256 -> 1024 -> {256 -> 128 -> k_cls | 256 -> 128 -> k_reg};
+ * pointnet2.py:240-253: 384 -> 1024 -> {128 -> k_cls | 128 -> k_reg}) on the B * 64 centres / the valid crops.  A workgroup
+ * takes 16 rows through all layers; activations stay in LDS.  x (n, Kx) rows with stride ldx (multiple of 4, 16-byte
+ * aligned); descr: `layers` (<= 8) records of 9 int64 [W, scale, shift (device addresses: W packed [>= ceil16(N)][Kpad] zero
+ * padded, scale / shift [N]: y = relu?(scale * (W . x) + shift)), K, Kpad (multiple of 16), N, relu, src, dst]; buffers: 0 =
+ * input, 1..3 = LDS scratch (a scratch buffer's width is its producer's N rounded up to 16 and must equal its consumers'
+ * Kpad), dst 4 / 5 = out_a (n, lda) / out_b (n, ldb).  Layers run in order.  REGNET_ERR_UNSUPPORTED beyond 160 KiB of LDS. */
+int regnet_heads_chain_f32(const float* x, int64_t ldx, int64_t Kx, int64_t n, const int64_t* descr, int64_t layers,
+                           float* out_a, int64_t lda, float* out_b, int64_t ldb, void* stream);
+
 /* Decodes of the two grasp heads WITHOUT labels (inference), one launch each instead of ~25 / ~12 small tensor ops.
  * regnet_stage2_decode_f32 (gripper_region_network.py:69-90, `ground is None`): cls (n,A), reg (n,A,C >= 7), centre rows
  * (n, centre_ld >= 3), tmpl (A,4) = the anchors' [r | theta] -> out (n,C): the arg-max anchor's regression turned into

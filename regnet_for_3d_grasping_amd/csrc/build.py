@@ -23,6 +23,7 @@ SOURCES = [
     ("mlp.hip", []),
     ("sa_chain.hip", ["-fno-slp-vectorize"]),   # SLP turns the layer-1 FMAs into v_pk_mul + separate adds
     ("rowchain.hip", ["-fno-slp-vectorize"]),
+    ("heads.hip", []),
     ("tgemm.hip", []),
     ("bn_train.hip", []),
     ("np_random.hip", []),

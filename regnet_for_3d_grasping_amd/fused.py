@@ -912,6 +912,35 @@ _REFINE = [("conv_formal", "bn_formal", True), ("conv_formal_cls2", "bn_formal_c
            ("conv_formal_reg3", "bn_formal_reg3", False)]
 
 
+HEADS_CHAIN = True   # the grasp heads as ONE launch each (csrc/heads.hip) instead of a split-K GEMM + its reduction per layer
+
+
+def _heads_chain(x, L, plan, n_a, n_b):
+    """x (n, K) float32 rows; ``plan``: [(layer name, src buffer, dst buffer)] in execution order (buffers: 0 input, 1-3 LDS
+    scratch, 4 / 5 outputs a / b) -> (out_a (n, n_a), out_b (n, n_b)).  The int64 descriptor (device addresses of the packed
+    weights) is built per call: nine integers per layer."""
+    n = x.shape[0]
+    x = x if x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0 else x.contiguous().clone()
+    descr = []
+    for name, src, dst in plan:
+        lay = L[name]
+        descr += [lay.W.data_ptr(), lay.scale.data_ptr(), lay.shift.data_ptr(), lay.K, lay.Kpad, lay.N, lay.relu, src, dst]
+    import ctypes
+    arr = (ctypes.c_int64 * len(descr))(*descr)
+    out_a = torch.empty((n, n_a), dtype=torch.float32, device=x.device)
+    out_b = torch.empty((n, n_b), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _check(_L.regnet_heads_chain_f32(x.data_ptr(), x.stride(0), x.shape[1], n, ctypes.addressof(arr), len(plan),
+                                         out_a.data_ptr(), n_a, out_b.data_ptr(), n_b, _stream(x)), "heads_chain")
+    return out_a, out_b
+
+
+_TWOSTAGE_PLAN = [("conv", 0, 1), ("conv_cls2", 1, 2), ("conv_cls3", 2, 3), ("conv_cls4", 3, 4),
+                  ("conv_reg2", 1, 2), ("conv_reg3", 2, 3), ("conv_reg4", 3, 5)]
+_REFINE_PLAN = [("conv_formal", 0, 1), ("conv_formal_cls2", 1, 2), ("conv_formal_cls3", 2, 4),
+                ("conv_formal_reg2", 1, 2), ("conv_formal_reg3", 2, 5)]
+
+
 def _chain(x, layers, names):
     P = x.shape[0]
     for n in names:
@@ -926,6 +955,12 @@ def twostage_forward(net, mp_x, raw_reg=False):
     n = mp_x.shape[0]
     L = _packed_named(net, _TWOSTAGE)
     x = mp_x.reshape(n, -1).contiguous()
+    if HEADS_CHAIN and x.shape[1] % 16 == 0:
+        x_cls, x_reg = _heads_chain(x, L, _TWOSTAGE_PLAN, L["conv_cls4"].N, L["conv_reg4"].N)
+        x_reg = x_reg.view(n, -1, net.k_reg_no_anchor)
+        if not raw_reg:
+            x_reg[:, :, 7:] = torch.sigmoid(x_reg[:, :, 7:])
+        return x_cls, x_reg
     h = mlp_layer(x, L["conv"].K, L["conv"], n)
     x_cls = _chain(h, L, ["conv_cls2", "conv_cls3", "conv_cls4"])
     x_reg = _chain(h, L, ["conv_reg2", "conv_reg3", "conv_reg4"]).view(n, -1, net.k_reg_no_anchor)
@@ -939,6 +974,8 @@ def refine_forward(net, x):
     x_cls (n, 2), x_reg (n, k_reg)."""
     n = x.shape[0]
     L = _packed_named(net, _REFINE)
+    if HEADS_CHAIN and (x.numel() // max(n, 1)) % 16 == 0:
+        return _heads_chain(x.reshape(n, -1), L, _REFINE_PLAN, L["conv_formal_cls3"].N, L["conv_formal_reg3"].N)
     h = mlp_layer(x.reshape(n, -1).contiguous(), L["conv_formal"].K, L["conv_formal"], n)
     return (_chain(h, L, ["conv_formal_cls2", "conv_formal_cls3"]),
             _chain(h, L, ["conv_formal_reg2", "conv_formal_reg3"]))

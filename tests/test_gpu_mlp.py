@@ -497,3 +497,42 @@ def test_fp_head_chain_interp_equals_interp_affine_then_chain(B, Nd, Ns):
         ev.synchronize()
     torch.cuda.synchronize()
     assert torch.equal(F2, F) and torch.equal(s2, s)
+
+
+@pytest.mark.parametrize("n", [1, 16, 64, 449, 512])
+def test_heads_chain_kernel_matches_the_layerwise_heads(n):
+    """fused.HEADS_CHAIN: the grasp-region head (7 layers) and the refine head (5 layers) as ONE launch each
+    (csrc/heads.hip: 16 rows per workgroup through the whole tree, activations in LDS) against the layer-by-layer split-K
+    path and against torch's own modules in float64 (pointnet2.py:174-188, :240-253)."""
+    from regnet_for_3d_grasping_amd import fused, synthetic
+    from regnet_for_3d_grasping_amd.gripper_region_network import GripperRegionNetwork
+    net = GripperRegionNetwork(training=True, group_num=256, gripper_num=64, grasp_score_threshold=0.5, radius=0.06,
+                               reg_channel=10)
+    net.load_state_dict(synthetic.seeded_state_dict(net, 11))
+    net = net.to(DEV).eval()
+    g = torch.Generator().manual_seed(n)
+    x2 = torch.randn(n, 256, 1, generator=g).to(DEV)
+    x3 = torch.randn(n, 384, 1, generator=g).to(DEV)
+    outs = {}
+    for flag in (True, False):
+        old, fused.HEADS_CHAIN = fused.HEADS_CHAIN, flag
+        try:
+            with torch.no_grad():
+                outs[flag] = fused.twostage_forward(net.extrat_feature_region, x2) + fused.refine_forward(net.extrat_feature_refine, x3)
+        finally:
+            fused.HEADS_CHAIN = old
+    for a, b in zip(outs[True], outs[False]):
+        assert a.shape == b.shape
+        torch.testing.assert_close(a, b, rtol=0, atol=2e-5)
+    # float64 evaluation of the modules themselves
+    import copy
+    ref = copy.deepcopy(net).double()
+    old, fused.ENABLED = fused.ENABLED, False
+    try:
+        with torch.no_grad():
+            c64, r64, _ = ref.extrat_feature_region(x2.double(), None, pooled=True)
+            fc64, fr64 = ref.extrat_feature_refine(x3[:, :256].double(), x3[:, 256:].double().view(n, 128), pooled=True)
+    finally:
+        fused.ENABLED = old
+    for got, want in zip(outs[True], (c64, r64, fc64, fr64)):
+        assert float((got.double() - want).abs().max()) <= 2e-5
