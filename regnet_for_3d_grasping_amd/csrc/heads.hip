@@ -10,13 +10,13 @@
 // Here a workgroup takes 16 rows through ALL layers of the tree: activations live in LDS (input, trunk, two branch
 // buffers: 16 x (384 + 1024 + 256 + 128) floats), weights stream from L2 / HBM straight into MFMA operands
 // (v_mfma_f32_16x16x4_f32: exact fp32 products; a lane's float4 of K feeds four MFMAs), folded BatchNorm + ReLU in the
-// epilogue.  4 waves split a layer's 16-column blocks.  Eval-mode folded affine: y = relu(scale[n] * acc + shift[n]).
+// epilogue.  16 waves split a layer's 16-column blocks.  Eval-mode folded affine: y = relu(scale[n] * acc + shift[n]).
 #include "common.h"
 
 typedef float hd_f32x4 __attribute__((ext_vector_type(4)));
 
 #define HD_ROWS 16
-#define HD_THREADS 256
+#define HD_THREADS 1024   // 16 waves: a workgroup streams ~3.4 MB of weights through ONE CU -- what counts is loads in flight
 #define HD_MAX_LAYERS 8
 #define HD_PAD 4   // row padding (floats) of the LDS activation buffers: 16 rows x (K + 4) -> rows start 4 banks apart
 
@@ -73,8 +73,24 @@ __global__ __launch_bounds__(HD_THREADS) void heads_chain_kernel(const HdArgs p)
       const float* wrow = L.W + (long long)col * L.Kpad + 4 * ag;
       const float* arow = act + ar * lds_ld + 4 * ag;
       hd_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      // K in steps of 16: lane group g supplies k = k0 + 4 g + j to MFMA j (both operands agree, so the order is free)
-      for (int k0 = 0; k0 < L.Kpad; k0 += 16) {
+      // K in steps of 16: lane group g supplies k = k0 + 4 g + j to MFMA j (both operands agree, so the order is free).
+      // Eight steps' weight loads are issued before the first MFMA (8 KiB in flight per wave, 128 KiB per workgroup).
+      int k0 = 0;
+      for (; k0 + 128 <= L.Kpad; k0 += 128) {
+        float4 b[8], a[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) b[u] = *reinterpret_cast<const float4*>(wrow + k0 + 16 * u);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] = *reinterpret_cast<const float4*>(arow + k0 + 16 * u);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].x, b[u].x, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].y, b[u].y, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].z, b[u].z, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].w, b[u].w, acc, 0, 0, 0);
+        }
+      }
+      for (; k0 < L.Kpad; k0 += 16) {
         const float4 a = *reinterpret_cast<const float4*>(arow + k0);
         const float4 b = *reinterpret_cast<const float4*>(wrow + k0);
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
