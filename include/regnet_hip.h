@@ -299,6 +299,28 @@ int regnet_stage2_decode_f32(const float* cls, const float* reg, int64_t A, int6
 int regnet_refine_decode_f32(const float* grasp, int64_t grasp_ld, const float* cls, const float* reg, int64_t C,
                              float radius, float score_thre, int64_t n, float* final_grasp, uint8_t* flags, void* stream);
 
+/* The two grasp losses of the training iteration with their gradients (csrc/losses.hip; gripper_region_network.py:46-184,
+ * :186-309 with labels).  Every row-wise quantity in one launch, the class-balanced cross entropy in a second one after the
+ * host's numpy draws; smooth-L1 is torch's default (beta 1), 1 - cos as compute_cos_sim / CosineEmbeddingLoss write it.
+ * regnet_stage2_loss_rows_f32: cls (n,A), reg (n,A,10), centre rows (n, centre_ld), tmpl (A,4), label rows (n, label_ld >= 10),
+ *   rows (m) int64 = the labelled centres (NULL: all n = m), weights4 = the four regression terms' weights (host pointer) ->
+ *   compact per labelled centre: next_grasp (m,10) (arg-max decode), pick / g8 (m) int32 (arg-max class / label's anchor),
+ *   a_gt (m,7), terms (m,12) = [4 regression terms | 4 monitoring terms | g8 == pick | 0 0 0]; dreg (n,A,10) rows `rows` =
+ *   gradient of the weighted regression terms (other rows untouched: zero-fill first).
+ * regnet_ce_rows_f32: loss[k] = CE(cls[rows[idx[k]]], target[idx[k]]), dcls[rows[idx[k]], :] = (softmax - onehot) * scale.
+ * regnet_refine_loss_rows_f32: grasp rows (m, ld), cls (m,2), reg (m,10), label rows -> final_grasp (m,10), flags (3,m) uint8
+ *   [class 1 | class 1 and score kept | label-positive], terms (m,20) = [4 regression terms of positive rows | 3 x 4
+ *   monitoring terms | 4 confusion counts], dreg (m,10) = SL1' of the positive rows' residuals (unscaled).            */
+int regnet_stage2_loss_rows_f32(const float* cls, const float* reg, int64_t A, int64_t C, const float* centre,
+                                int64_t centre_ld, const float* tmpl, const float* label, int64_t label_ld, float radius,
+                                const float* weights4, const int64_t* rows, int64_t m, float* next_grasp, int32_t* pick,
+                                int32_t* g8, float* a_gt, float* terms, float* dreg, void* stream);
+int regnet_ce_rows_f32(const float* cls, int64_t A, const int32_t* target, const int64_t* idx, const int64_t* rows,
+                       int64_t nb, float scale, float* loss, float* dcls, void* stream);
+int regnet_refine_loss_rows_f32(const float* grasp, int64_t grasp_ld, const float* cls, const float* reg, const float* label,
+                                int64_t label_ld, int64_t C, float radius, float score_thre, int64_t m, float* final_grasp,
+                                uint8_t* flags, float* terms, float* dreg, void* stream);
+
 /* regnet_gripper_frame_f32: grasp (n, ld >= 7) rows [centre | closing axis | theta | ...] -> centre (n,3), rot (n,3,3) with rows
  * [approach; axis_y; minor_normal] -- the frame maths of get_gripper_region_transform (gripper_region_network.py:447-506) in
  * one launch.  regnet_crop_pick: the drawn candidate positions of a box crop resolved to group positions and scene indices

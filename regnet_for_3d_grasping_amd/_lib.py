@@ -42,6 +42,10 @@ SIGNATURES = {
     "regnet_box_crop_f32": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _f32, _i64, _i64, _vp, _vp, _vp]),
     "regnet_gather_max_f32": (_int, [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _vp]),
     "regnet_gripper_frame_f32": (_int, [_vp, _i64, _i64, _vp, _vp, _vp]),
+    "regnet_stage2_loss_rows_f32": (_int, [_vp, _vp, _i64, _i64, _vp, _i64, _vp, _vp, _i64, _f32, _vp, _vp, _i64, _vp, _vp, _vp,
+                                           _vp, _vp, _vp, _vp]),
+    "regnet_ce_rows_f32": (_int, [_vp, _i64, _vp, _vp, _vp, _i64, _f32, _vp, _vp, _vp]),
+    "regnet_refine_loss_rows_f32": (_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _f32, _f32, _i64, _vp, _vp, _vp, _vp, _vp]),
     "regnet_heads_chain_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
     "regnet_stage2_decode_f32": (_int, [_vp, _vp, _i64, _i64, _vp, _i64, _vp, _f32, _int, _i64, _vp, _vp]),
     "regnet_refine_decode_f32": (_int, [_vp, _i64, _vp, _vp, _i64, _f32, _f32, _i64, _vp, _vp, _vp]),

@@ -21,7 +21,7 @@ import numpy as np
 import torch
 from torch import nn
 
-from . import np_random, region_ops
+from . import np_random, region_losses, region_ops
 from .pointnet2 import PointNet2Refine, PointNet2TwoStage
 
 
@@ -167,6 +167,8 @@ class GripperRegionNetwork(nn.Module):
         2.5 cm, its axis within 60 deg (1 - cos < 0.5) and its angle within 1.047 rad of the label;
         CE on a class-balanced subset (numpy RNG) + four smooth-L1 terms on the positives."""
         dev = next_grasp.device
+        if next_gt is not None and region_losses.usable(next_grasp, next_x_cls, next_x_reg, next_gt):
+            return region_losses.refine_loss(next_grasp, next_x_cls, next_x_reg, next_gt, self.radius, self.grasp_score_thre)
         if (next_gt is None and next_grasp.is_cuda and not torch.is_grad_enabled() and next_grasp.dtype == torch.float32
                 and hasattr(region_ops, "refine_decode")):
             # inference: deltas, class arg-max and both selections' flags in ONE launch, one read (csrc/region.hip)
@@ -293,6 +295,14 @@ class GripperRegionNetwork(nn.Module):
                                                   self.extrat_feature_region.reg_is_raw)
             true_mask, keep2 = _all_centres(B, N_C, center_pc.device)
             loss_tuple, correct_tuple, next_gt = (None, None), (None, None, None, None), None
+        elif (ground_grasp is not None and center_pc.dtype == torch.float32
+              and region_losses.usable(x_reg, x_cls, center_pc, ground_grasp)):
+            # training on the GPU: the whole label branch of compute_loss (decode, anchor matching, four smooth-L1 terms, the
+            # class-balanced cross entropy, monitoring) in two launches + one read, gradients included (csrc/losses.hip)
+            self.templates = self.templates.to(center_pc.device)
+            next_grasp, loss_tuple, correct_tuple, next_gt, _, true_mask = region_losses.stage2_loss(
+                x_reg, x_cls, center_pc.reshape(B * N_C, -1), _float_templates(self.templates), ground_grasp, self.radius)
+            keep2 = _per_scene_counts(true_mask, N_C, B)
         else:
             anchors = self._enumerate_anchors(center_pc[:, :, :3].reshape(-1, 3).float())
             next_grasp, loss_tuple, correct_tuple, next_gt, _, true_mask = self.compute_loss(x_reg, anchors, x_cls,

@@ -522,3 +522,84 @@ def test_gather_max_train_matches_the_materialised_gather():
         (g1,) = torch.autograd.grad(y1, [flat], dy)
         assert torch.equal(y0, y1)
         torch.testing.assert_close(g1, g0, rtol=0.0, atol=1e-6)
+
+
+@pytest.mark.parametrize("seed", [3, 4, 5])
+def test_fused_region_losses_match_the_tensor_code(seed):
+    """region_losses (csrc/losses.hip: each grasp loss as two launches + one read, gradients included) against the tensor code
+    of GripperRegionNetwork.compute_loss / compute_loss_refine with labels (gripper_region_network.py:92-184, :233-309) on
+    the same GPU inputs and the same numpy stream: every entry of the returned tuples, the numpy stream position, and the
+    gradients with respect to the heads' outputs."""
+    from regnet_for_3d_grasping_amd import region_losses
+    from regnet_for_3d_grasping_amd.gripper_region_network import GripperRegionNetwork
+    from . import golden_util as gu
+    net = GripperRegionNetwork(training=True, group_num=256, gripper_num=64, grasp_score_threshold=0.5, radius=0.06,
+                               reg_channel=10).to(DEV)
+    stage2, refine = gu.loss_inputs(seed)
+
+    def close(a, b, tol=2e-6):
+        if a is None or b is None:
+            assert a is None and b is None
+            return
+        a, b = a.detach().float().cpu(), b.detach().float().cpu()
+        assert a.shape == b.shape, (a.shape, b.shape)
+        assert torch.allclose(a, b, rtol=1e-5, atol=tol, equal_nan=True), float((a - b).abs().max())
+
+    # ---- stage 2
+    centres = stage2["centres"].to(DEV)
+    ground = stage2["ground"].to(DEV)
+    B, Nc = ground.shape[0], ground.shape[1]
+    outs = []
+    for fused_path in (True, False):
+        reg = stage2["first_grasp"].clone().to(DEV).requires_grad_(True)
+        cls = stage2["first_cls"].clone().to(DEV).requires_grad_(True)
+        np.random.seed(100 + seed)
+        if fused_path:
+            tmpl = net.templates.float().reshape(-1, 4).to(DEV).contiguous()
+            res = region_losses.stage2_loss(reg, cls, centres, tmpl, ground, net.radius)
+        else:
+            old, region_losses.FUSED = region_losses.FUSED, False
+            try:
+                res = net.compute_loss(reg, net._enumerate_anchors(centres), cls, ground)
+            finally:
+                region_losses.FUSED = old
+        draw = int(np.random.randint(0, 2 ** 31 - 1))
+        res[1][0].backward()
+        outs.append((res, draw, reg.grad.clone(), cls.grad.clone()))
+    (ra, da, gra, gca), (rb, db, grb, gcb) = outs
+    assert da == db, "numpy stream position after the class-balancing draws"
+    close(ra[0], rb[0])
+    for x, y in zip(ra[1], rb[1]):
+        close(x, y)
+    for x, y in zip(ra[2], rb[2]):
+        close(x, y)
+    close(ra[3], rb[3]); close(ra[4], rb[4]); assert torch.equal(ra[5], rb[5])
+    close(gra, grb, 1e-6); close(gca, gcb, 1e-6)
+
+    # ---- refine
+    outs = []
+    for fused_path in (True, False):
+        reg = refine["next_x_reg"].clone().to(DEV).requires_grad_(True)
+        cls = refine["next_x_cls"].clone().to(DEV).requires_grad_(True)
+        grasp, gt = refine["next_grasp"].to(DEV), refine["next_gt"].to(DEV)
+        np.random.seed(200 + seed)
+        old, region_losses.FUSED = region_losses.FUSED, fused_path
+        try:
+            res = net.compute_loss_refine(grasp, cls, reg, gt)
+        finally:
+            region_losses.FUSED = old
+        draw = int(np.random.randint(0, 2 ** 31 - 1))
+        if res[5][0].requires_grad:
+            res[5][0].backward()
+        outs.append((res, draw, None if reg.grad is None else reg.grad.clone(), None if cls.grad is None else cls.grad.clone()))
+    (ra, da, gra, gca), (rb, db, grb, gcb) = outs
+    assert da == db
+    for k in range(3):
+        close(ra[k], rb[k])
+    assert torch.equal(ra[3].cpu(), rb[3].cpu()) and torch.equal(ra[4].cpu(), rb[4].cpu())
+    assert len(ra[5]) == len(rb[5]) == 18
+    for x, y in zip(ra[5], rb[5]):
+        close(x, y)
+    for x, y in zip(ra[6], rb[6]):
+        close(x, y)
+    close(gra, grb, 1e-6); close(gca, gcb, 1e-6)
