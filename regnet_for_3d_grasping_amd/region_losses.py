@@ -126,8 +126,8 @@ class _RefineLoss(torch.autograd.Function):
             nan = float("nan")
             reg_scale = [1.0 / (3 * P), 1.0 / (3 * P), 1.0 / P, 1.0 / (3 * P)] if num > 0 else [0.0] * 4
             if nc > 0:      # (the reference computes the score-kept terms whenever a class-1 row exists: empty means are nan)
-                mon = [1.0 / (3 * nc), 1.0 / nc, 1.0 / nc, 1.0 / (3 * nc)] * 2 + \\
-                      ([1.0 / (3 * ns), 1.0 / ns, 1.0 / ns, 1.0 / (3 * ns)] if ns > 0 else [nan] * 4)
+                mon = ([1.0 / (3 * nc), 1.0 / nc, 1.0 / nc, 1.0 / (3 * nc)] * 2
+                       + ([1.0 / (3 * ns), 1.0 / ns, 1.0 / ns, 1.0 / (3 * ns)] if ns > 0 else [nan] * 4))
             else:
                 mon = [0.0] * 12
             scale = torch.tensor(reg_scale + mon + [1.0] * 4, dtype=torch.float32).to(dev, non_blocking=True)
