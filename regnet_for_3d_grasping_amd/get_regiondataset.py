@@ -55,6 +55,7 @@ def get_grasp_allobj(pc, predict_score, params, data_paths, use_theta=True):
     return center_pc, center_pc_index, pc_group_index, pc_group, pc_group_more_index, pc_group_more, grasp_labels
 
 
+BATCHED_LABELS = True          # GPU: match all scenes' centres to their grasp labels in one batched pass (_get_center_grasp)
 NO_GRASP_SQ_DISTANCE = 0.005   # a centre further than this (SQUARED distance) from every grasp has no label (:120)
 
 
@@ -98,7 +99,34 @@ def _get_center_grasp(center_pc_index, center_pc, data_paths, depth, use_theta=T
     # every scene's label arrays go up in ONE host->device copy (four pageable copies per scene, each a
     # synchronisation, before)
     loaded = [_load_grasp_record(entry) for entry in data_paths]
-    flat = torch.cat([t.reshape(-1) for rec in loaded for t in rec]).to(dev)
+    if BATCHED_LABELS and dev.type == "cuda" and B > 1 and min(int(rec[0].shape[0]) for rec in loaded) > 0:
+        # one batched match for all scenes (the per-scene loop below is ~30 small launches per scene on the host-paced
+        # path of the training iteration, DESIGN.md par. 12.5): records padded to the longest, padded grasps at distance
+        # +inf.  Same expression per element as _compute_distance, same arg-min.
+        Gs = [int(rec[0].shape[0]) for rec in loaded]
+        Gmax = max(Gs)
+        host = np.zeros((B, Gmax, 19), dtype=np.float32)          # 16 frame entries | score | antipodal | centre score
+        for i, (frames, score, anti, cen) in enumerate(loaded):
+            host[i, :Gs[i], :16] = frames.reshape(Gs[i], 16).numpy()
+            host[i, :Gs[i], 16], host[i, :Gs[i], 17], host[i, :Gs[i], 18] = score.numpy(), anti.numpy(), cen.numpy()
+        packed = torch.from_numpy(host).to(dev)
+        valid = torch.from_numpy(np.arange(Gmax)[None, :] < np.asarray(Gs)[:, None]).to(dev)
+        frames = packed[:, :, :16].view(B, Gmax, 4, 4)
+        approach = frames[:, :, :3, 0]
+        contact = ((frames[:, :, :3, 3] + approach * depth).float() - approach * depth).float()
+        a = center_pc[:, :, :3]
+        d = -2 * torch.bmm(a, contact.transpose(1, 2))
+        d = d + torch.sum(contact * contact, 2).view(B, 1, Gmax)
+        d = d + torch.sum(a * a, 2).view(B, Nc, 1)
+        d = d.double().masked_fill(~valid.view(B, 1, Gmax), float("inf"))
+        dist, nearest = torch.min(d, dim=2)                           # (B, Nc)
+        has = dist <= NO_GRASP_SQ_DISTANCE
+        picked = torch.gather(packed, 1, nearest.unsqueeze(-1).expand(B, Nc, 19))
+        picked = picked.masked_fill(~has.unsqueeze(-1), -1.0)
+        label = picked[:, :, :16].view(B, Nc, 4, 4)[:, :, :3, :4]
+        score_l, anti_l, cen_l = picked[:, :, 16], picked[:, :, 17], picked[:, :, 18]
+        loaded = []                                                   # (skips the per-scene loop)
+    flat = torch.cat([t.reshape(-1) for rec in loaded for t in rec]).to(dev) if loaded else None
     at = 0
     for i, rec in enumerate(loaded):
         parts = []
