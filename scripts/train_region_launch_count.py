@@ -31,7 +31,7 @@ def count(fn):
         out = fn()
         torch.cuda.synchronize()
     ks = [e for e in prof.events() if e.device_type is not None and str(e.device_type).endswith("CUDA")]
-    return out, len(ks), collections.Counter(e.name[:60] for e in ks)
+    return out, len(ks), collections.Counter((e.name[50:160] if e.name.startswith("void at::native::vectorized_elementwise_kernel") else e.name[:70]) for e in ks)
 
 def grouping():
     with contextlib.redirect_stdout(io.StringIO()):
@@ -50,7 +50,7 @@ print("get_grasp_allobj with labels: %d device activities" % n1)
 # the network forward as a whole, then (separate passes: profilers do not nest) with one loss function profiled alone
 res, n2, c2 = count(lambda: network(g))
 parts = {}
-for name, attr in (("compute_loss (stage-2 decode + loss)", "compute_loss"), ("compute_loss_refine", "compute_loss_refine")):
+for name, attr in (("compute_loss_refine (fused: region_losses.refine_loss)", "compute_loss_refine"),):
     orig = getattr(r, attr)
     def w(*a, _orig=orig, _name=name, **k):
         out, n, c = count(lambda: _orig(*a, **k))
@@ -67,7 +67,7 @@ print("   %-44s %d" % ("pooling, heads, crops, gathers", n2 - inner))
 total = res[3][0].sum() + res[13][0].sum()
 _, n3, c3 = count(lambda: total.backward())
 print("backward of both losses through the region stage: %d device activities" % n3)
-for name, c in (("compute_loss", parts["compute_loss (stage-2 decode + loss)"][1]), ("backward", c3)):
+for name, c in (("the network forward", c2), ("the backward", c3), ("get_grasp_allobj", c1)):
     print("-- most frequent in %s" % name)
-    for k, v in c.most_common(8):
+    for k, v in c.most_common(14):
         print("   %4d %s" % (v, k))
