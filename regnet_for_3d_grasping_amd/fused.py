@@ -415,7 +415,7 @@ def sa_sample(module, xyz, prefix_ok=None):
     ``prefix_ok``: the ``first_tie`` of the sampling run that produced ``xyz``'s ORDER when ``xyz`` is the previous level's
     centroids in pick order (never anything else): scenes whose run had no tie among its first M picks then get 0 .. M-1
     without sampling -- the same indices the sampling would return (pn2_ext.FpsChain, csrc/geometry.hip)."""
-    chain = pn2_ext.FpsChain(prefix_ok)
+    chain = pn2_ext.FpsChain(prefix_ok if FPS_CHAIN else None)
     ctr = pn2_ext.farthest_point_sample(xyz, module.num_centroids, chain)
     return ctr, chain.first_tie
 
@@ -912,7 +912,12 @@ _REFINE = [("conv_formal", "bn_formal", True), ("conv_formal_cls2", "bn_formal_c
            ("conv_formal_reg3", "bn_formal_reg3", False)]
 
 
+FPS_CHAIN = True     # levels 2+ hand the level above's sampling certificate down (sa_sample): no sampling unless it had a tie
 HEADS_CHAIN = True   # the grasp heads as ONE launch each (csrc/heads.hip) instead of a split-K GEMM + its reduction per layer
+# ... up to this many rows.  The one launch is 16 rows per workgroup, each streaming all the head's weights through one CU for
+# ~0.1-0.4 ms: the latency win at B <= 4 (<= 256 centres).  At B = 8 its 32 whole-CU workgroups sit under the NEXT batch's SA
+# chains and the layer-wise split-K path measured 1 % faster end to end (scripts/ablate/frac_ab.sh, profiles/r04j_heads_ab.txt).
+HEADS_CHAIN_MAX_ROWS = 256
 
 
 def _heads_chain(x, L, plan, n_a, n_b):
@@ -955,7 +960,7 @@ def twostage_forward(net, mp_x, raw_reg=False):
     n = mp_x.shape[0]
     L = _packed_named(net, _TWOSTAGE)
     x = mp_x.reshape(n, -1).contiguous()
-    if HEADS_CHAIN and x.shape[1] % 16 == 0:
+    if HEADS_CHAIN and n <= HEADS_CHAIN_MAX_ROWS and x.shape[1] % 16 == 0:
         x_cls, x_reg = _heads_chain(x, L, _TWOSTAGE_PLAN, L["conv_cls4"].N, L["conv_reg4"].N)
         x_reg = x_reg.view(n, -1, net.k_reg_no_anchor)
         if not raw_reg:
@@ -974,7 +979,7 @@ def refine_forward(net, x):
     x_cls (n, 2), x_reg (n, k_reg)."""
     n = x.shape[0]
     L = _packed_named(net, _REFINE)
-    if HEADS_CHAIN and (x.numel() // max(n, 1)) % 16 == 0:
+    if HEADS_CHAIN and n <= HEADS_CHAIN_MAX_ROWS and (x.numel() // max(n, 1)) % 16 == 0:
         return _heads_chain(x.reshape(n, -1), L, _REFINE_PLAN, L["conv_formal_cls3"].N, L["conv_formal_reg3"].N)
     h = mlp_layer(x.reshape(n, -1).contiguous(), L["conv_formal"].K, L["conv_formal"], n)
     return (_chain(h, L, ["conv_formal_cls2", "conv_formal_cls3"]),

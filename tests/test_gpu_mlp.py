@@ -515,12 +515,13 @@ def test_heads_chain_kernel_matches_the_layerwise_heads(n):
     x3 = torch.randn(n, 384, 1, generator=g).to(DEV)
     outs = {}
     for flag in (True, False):
-        old, fused.HEADS_CHAIN = fused.HEADS_CHAIN, flag
+        old, fused.HEADS_CHAIN = (fused.HEADS_CHAIN, fused.HEADS_CHAIN_MAX_ROWS), flag
+        fused.HEADS_CHAIN_MAX_ROWS = 1 << 20          # (the product uses the one-launch kernel up to 256 rows)
         try:
             with torch.no_grad():
                 outs[flag] = fused.twostage_forward(net.extrat_feature_region, x2) + fused.refine_forward(net.extrat_feature_refine, x3)
         finally:
-            fused.HEADS_CHAIN = old
+            fused.HEADS_CHAIN, fused.HEADS_CHAIN_MAX_ROWS = old
     for a, b in zip(outs[True], outs[False]):
         assert a.shape == b.shape
         torch.testing.assert_close(a, b, rtol=0, atol=2e-5)
