@@ -507,8 +507,9 @@ def main():
         target, value = item.split("=")
         mod, name = target.rsplit(".", 1)
         module = importlib.import_module("regnet_for_3d_grasping_amd." + mod)
-        assert isinstance(getattr(module, name), bool), target
-        setattr(module, name, value not in ("0", "false", "False"))
+        current = getattr(module, name)
+        assert isinstance(current, (bool, int)), target          # module switches are booleans or small integer thresholds
+        setattr(module, name, value not in ("0", "false", "False") if isinstance(current, bool) else int(value))
     if args.global_batch:
         if args.global_batch % world:
             raise SystemExit("--global-batch %d is not a multiple of the %d ranks" % (args.global_batch, world))

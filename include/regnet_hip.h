@@ -504,6 +504,12 @@ int regnet_conv1x1_fwd_f32(const float* W, const float* X, float* Y, int64_t B, 
                            void* stream);
 int regnet_conv1x1_dgrad_f32(const float* W, const float* dY, float* dX, int64_t B, int64_t Co, int64_t Ci, int64_t L,
                              void* stream);
+/* ..._stream: the same two contractions by the persistent kernel (two workgroups per CU draw output tiles from `ticket`,
+ * an int32 zeroed by the caller, and keep one LDS ring running across tiles); bit-identical results.                  */
+int regnet_conv1x1_fwd_stream_f32(const float* W, const float* X, float* Y, int64_t B, int64_t Co, int64_t Ci, int64_t L,
+                                  int32_t* ticket, void* stream);
+int regnet_conv1x1_dgrad_stream_f32(const float* W, const float* dY, float* dX, int64_t B, int64_t Co, int64_t Ci, int64_t L,
+                                    int32_t* ticket, void* stream);
 int64_t regnet_conv1x1_wgrad_slices(int64_t B, int64_t Co, int64_t Ci, int64_t L);
 int64_t regnet_conv1x1_wgrad_workspace_bytes(int64_t B, int64_t Co, int64_t Ci, int64_t L);
 int regnet_conv1x1_wgrad_f32(const float* dY, const float* X, float* dW, int64_t B, int64_t Co, int64_t Ci, int64_t L,

@@ -99,6 +99,8 @@ SIGNATURES = {
     "regnet_conv1x1_train_supported": (_int, [_i64, _i64, _i64]),
     "regnet_conv1x1_fwd_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp]),
     "regnet_conv1x1_dgrad_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp]),
+    "regnet_conv1x1_fwd_stream_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
+    "regnet_conv1x1_dgrad_stream_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
     "regnet_conv1x1_wgrad_slices": (_i64, [_i64, _i64, _i64, _i64]),
     "regnet_conv1x1_wgrad_workspace_bytes": (_i64, [_i64, _i64, _i64, _i64]),
     "regnet_conv1x1_wgrad_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),

@@ -16,6 +16,8 @@ ENABLED = True     # module switches (bench.py --set conv1x1_train.ENABLED=0); n
 # 1: forward / input gradient / weight gradient on this repo's own fp32-MFMA kernels (csrc/tgemm.hip) whenever the
 # shape qualifies (channel counts multiples of 16, see regnet_conv1x1_train_supported); 0: rocBLAS batched GEMMs only
 NATIVE = True
+# forward / input gradient by the persistent ticket-driven kernel (csrc/tgemm.hip: tgemm_stream_kernel); 0: one workgroup per tile
+STREAM = True
 
 
 def _native_ok(B, Co, Ci, L, wgrad=False):
@@ -46,8 +48,14 @@ def native_fwd(x, w):
     Co = w.shape[0]
     y = torch.empty((B, Co, L), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
-        _lib.check(_lib.lib.regnet_conv1x1_fwd_f32(w.data_ptr(), x.data_ptr(), y.data_ptr(), B, Co, Ci, L, _stream(x)),
-                   "conv1x1_fwd")
+        if STREAM:
+            from . import fused
+            _lib.check(_lib.lib.regnet_conv1x1_fwd_stream_f32(w.data_ptr(), x.data_ptr(), y.data_ptr(), B, Co, Ci, L,
+                                                              fused._tickets(x.device).data_ptr(), _stream(x)),
+                       "conv1x1_fwd_stream")
+        else:
+            _lib.check(_lib.lib.regnet_conv1x1_fwd_f32(w.data_ptr(), x.data_ptr(), y.data_ptr(), B, Co, Ci, L, _stream(x)),
+                       "conv1x1_fwd")
     return y
 
 
@@ -58,8 +66,14 @@ def native_dgrad(w, dy):
     Ci = w.shape[1]
     dx = torch.empty((B, Ci, L), dtype=torch.float32, device=dy.device)
     with torch.cuda.device(dy.device):
-        _lib.check(_lib.lib.regnet_conv1x1_dgrad_f32(w.data_ptr(), dy.data_ptr(), dx.data_ptr(), B, Co, Ci, L,
-                                                     _stream(dy)), "conv1x1_dgrad")
+        if STREAM:
+            from . import fused
+            _lib.check(_lib.lib.regnet_conv1x1_dgrad_stream_f32(w.data_ptr(), dy.data_ptr(), dx.data_ptr(), B, Co, Ci, L,
+                                                                fused._tickets(dy.device).data_ptr(), _stream(dy)),
+                       "conv1x1_dgrad_stream")
+        else:
+            _lib.check(_lib.lib.regnet_conv1x1_dgrad_f32(w.data_ptr(), dy.data_ptr(), dx.data_ptr(), B, Co, Ci, L,
+                                                         _stream(dy)), "conv1x1_dgrad")
     return dx
 
 

@@ -19,6 +19,12 @@
 // (128 .. 1024), N the long axis (points, or Ci in the weight gradient); 2 workgroups per CU.
 // The weight gradient cuts the point axis into slices (split-K): slice partial sums go to a workspace and a second
 // kernel adds them in slice order (deterministic).
+//
+// Forward and input gradient (K = a channel count, 128 .. 1024: 8 .. 64 k-tiles per output tile) run as a STREAM
+// (tgemm_stream_kernel): two workgroups per CU walk the output tiles with one LDS ring that never drains -- the loads of
+// the next tile's first k-tiles are issued during the last two k-tiles of the current one, and its stores leave while
+// those loads are in flight.  Measured with one workgroup per tile: time per tile = 20 us + 0.25 us per unit of K on an
+// idle chip (workgroup dispatch, address set-up, two exposed load latencies, the store tail) -- 40 % of a K = 128 tile.
 #include "common.h"
 
 typedef float tg_f32x16 __attribute__((ext_vector_type(16)));
@@ -38,6 +44,8 @@ struct TgArgs {
   float* C;       long long ldc, c_batch, c_slice;
   int M, N, K;                                        // K = per-slice depth, multiple of 16
   int tiles_m, tiles_n, slices;                       // grid = tiles_m * tiles_n * slices * batches
+  int batches;                                        // tgemm_stream_kernel only (its grid does not encode them)
+  int* ticket;                                        // tgemm_stream_kernel: next tile to hand out - gridDim.x (zeroed by the caller)
 };
 
 __device__ __forceinline__ void tg_glds16(const float* gsrc, unsigned lds_dst) {
@@ -203,6 +211,206 @@ __global__ __launch_bounds__(TG_THREADS, 4) void tgemm_kernel(const TgArgs p) {
   }
 }
 
+template <int N> __device__ __forceinline__ void tg_wait() { asm volatile("s_waitcnt vmcnt(%0)" :: "i"(N) : "memory"); }
+// *p += 1, old value -> the returned register ONCE A LATER COUNTED WAIT HAS PASSED IT (no wait here: the compiler's own
+// vmcnt(0) in front of an atomic's result would also drain the k-tile loads in flight)
+__device__ __forceinline__ int tg_ticket_nowait(int* p) {
+  int r;
+  const int one = 1;
+  asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(r) : "v"(p), "v"(one) : "memory");
+  return r;
+}
+
+// C[M x N] = A[M x K] . B[K x N] per batch with B k-major (the activations / output gradients, points contiguous) and A the
+// weights, row (forward) or k-major (input gradient): tile 128 x 256 x 16 as tgemm_kernel, but persistent -- workgroup w
+// starts with tile w and draws further tiles from a ticket counter (channel tile fastest: the tiles sharing an activation
+// panel run at the same time), treating their k-tiles as ONE sequence through the 3-stage ring.  Tickets, not a fixed
+// stride: in the training iteration the next batch's sampling holds eight CUs for 4 ms at a time; a workgroup that cannot
+// start there must not own tiles (measured with a fixed stride: 5 % faster on an idle chip, 3 % slower in the iteration).
+template <bool A_KMAJ>
+__global__ __launch_bounds__(TG_THREADS, 4) void tgemm_stream_kernel(const TgArgs p) {
+  constexpr int TG_BN = 256, TNI = 2, WN_COLS = 64, NPIECE = 3;
+  constexpr int TG_STAGE_FLOATS = (TG_BM + TG_BN) * TG_BK;
+  __shared__ __attribute__((aligned(1024))) float smem[TG_STAGES * TG_STAGE_FLOATS];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int fr = lane & 31, fh = lane >> 5;
+  const int tiles = p.tiles_m * p.tiles_n;
+  const long long total = (long long)tiles * p.batches;
+  const int G = gridDim.x, bid = blockIdx.x;
+  if (bid >= total) return;
+  __shared__ long long s_next[2];                                 // tiles drawn from the counter, by parity of their number
+  const int KT = p.K / TG_BK;                                     // >= 2 (launcher)
+
+  // ---- LDS-DMA pieces of this wave (as tgemm_kernel: pieces 0..7 = A, 8..23 = B; piece = 1 KiB): tile-independent parts
+  unsigned dst[NPIECE];
+  long long kstep[NPIECE];
+#pragma unroll
+  for (int j = 0; j < NPIECE; ++j) {
+    const int piece = wave + 8 * j;
+    const bool isA = piece < 8;
+    const int q = isA ? piece : piece - 8;
+    dst[j] = (unsigned)((isA ? 0 : TG_BM * TG_BK * 4) + q * 1024);
+    kstep[j] = isA ? (A_KMAJ ? (long long)TG_BK * p.lda : (long long)TG_BK) : (long long)TG_BK * p.ldb;
+  }
+  const float* gp[NPIECE];          // issue cursor: this lane's source of the cursor's k-tile, per piece
+  int issue_kt = 0;                 // cursor = k-tile issue_kt of tile issue_t (-1: no tile left)
+  long long issue_t = bid;
+  int drawn = 0;                    // tiles drawn so far; a draw is pending while issue_t == -2
+  int ticket_reg = 0;               // thread 0: the pending draw's ticket (valid after the next counted wait)
+  auto set_issue_tile = [&](long long t) {
+    const int batch = (int)(t / tiles), r = (int)(t - (long long)batch * tiles);
+    const int tn = r / p.tiles_m, tm = r - tn * p.tiles_m;
+    const int m0 = tm * TG_BM, n0 = tn * TG_BN;
+    const float* Ab = p.A + batch * p.a_batch;
+    const float* Bb = p.B + batch * p.b_batch;
+#pragma unroll
+    for (int j = 0; j < NPIECE; ++j) {
+      const int piece = wave + 8 * j;
+      const int q = piece < 8 ? piece : piece - 8;
+      if (piece < 8) {
+        if (A_KMAJ) {
+          int m = m0 + 4 * (lane & 31);
+          if (m >= p.M) m = 0;
+          gp[j] = Ab + (long long)(2 * q + (lane >> 5)) * p.lda + m;
+        } else {
+          int r2 = m0 + 16 * q + (lane >> 2);
+          if (r2 >= p.M) r2 = 0;
+          gp[j] = Ab + (long long)r2 * p.lda + 4 * ((lane & 3) ^ ((lane >> 4) & 3));
+        }
+      } else {
+        int n2 = n0 + 4 * lane;
+        if (n2 >= p.N) n2 = 0;
+        gp[j] = Bb + (long long)q * p.ldb + n2;
+      }
+    }
+  };
+  const unsigned smem_base = (unsigned)(uintptr_t)smem;
+  auto issue = [&](int stage_) {     // the cursor's k-tile -> stage_, cursor + 1
+    const bool last = issue_kt + 1 == KT;
+    // the cursor's tile ends with this group: draw the next tile IN FRONT of the group, so that the counted wait that
+    // lets this group be the only one outstanding (next iteration, or the wait before a tile's stores) covers the draw
+    if (last && tid == 0) ticket_reg = tg_ticket_nowait(p.ticket);
+#pragma unroll
+    for (int j = 0; j < NPIECE; ++j) {
+      tg_glds16(gp[j], smem_base + (unsigned)(stage_ * TG_STAGE_FLOATS * 4) + dst[j]);
+      gp[j] += kstep[j];
+    }
+    if (last) { issue_kt = 0; issue_t = -2; } else ++issue_kt;
+  };
+  auto publish_drawn = [&]() {       // thread 0, after that counted wait and in front of a barrier
+    if (tid == 0) {
+      s_next[drawn & 1] = (long long)G + ticket_reg;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  };
+  auto take_drawn = [&]() {          // after that barrier
+    const long long t = *reinterpret_cast<volatile long long*>(&s_next[drawn & 1]);
+    ++drawn;
+    issue_t = t < total ? t : -1;
+    if (issue_t >= 0) set_issue_tile(issue_t);
+  };
+  const int sw = (fr >> 2) & 3;
+  int offA[2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) offA[kk] = (wm * 64 + fr) * TG_BK + 4 * ((2 * kk + fh) ^ sw);
+  const int kmA = 4 * fh * TG_BM + wm * 64 + fr;
+  const int kmB = TG_BM * TG_BK + 4 * fh * TG_BN + wn * WN_COLS + fr;
+
+  set_issue_tile(issue_t);
+  issue(0);
+  issue(1);                          // (KT >= 2: still the first tile; a draw is pending afterwards when KT == 2)
+  int stage = 0;
+  long long cur_t = bid, next_t = -1;          // tile being computed; the one after it, once known
+  while (cur_t >= 0) {
+    tg_f32x16 acc[2][TNI];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < TNI; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+    const bool first = cur_t == bid;
+    for (int kt = 0; kt < KT; ++kt) {
+      // this k-tile's loads are complete when at most the NEWER group (if one was issued) is outstanding; right after a
+      // tile's stores the wait was made before them (below), so that the stores are not waited for here.
+      // Groups are issued two k-tiles ahead: a newer one exists unless the cursor ran out of tiles before reaching it.
+      const bool newer = kt + 1 < KT || next_t >= 0;
+      if (kt != 0 || first) {
+        if (newer) tg_wait<NPIECE>(); else tg_wait<0>();
+      }
+      if (issue_t == -2) publish_drawn();
+      asm volatile("s_barrier" ::: "memory");
+      if (issue_t == -2) {
+        take_drawn();
+        if (next_t < 0) next_t = issue_t;        // (the cursor is at most one tile ahead of the computation)
+      }
+      if (issue_t >= 0) { int ns = stage + 2; if (ns >= TG_STAGES) ns -= TG_STAGES; issue(ns); }
+      {
+        const float* st = smem + stage * TG_STAGE_FLOATS;
+        float a[2][2][4], b[2][TNI][4];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi) {
+            if (A_KMAJ) {
+#pragma unroll
+              for (int t = 0; t < 4; ++t) a[kk][mi][t] = st[kmA + (8 * kk + t) * TG_BM + 32 * mi];
+            } else {
+              const float4 v = *reinterpret_cast<const float4*>(st + offA[kk] + mi * 32 * TG_BK);
+              a[kk][mi][0] = v.x; a[kk][mi][1] = v.y; a[kk][mi][2] = v.z; a[kk][mi][3] = v.w;
+            }
+          }
+#pragma unroll
+          for (int ni = 0; ni < TNI; ++ni) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) b[kk][ni][t] = st[kmB + (8 * kk + t) * TG_BN + 32 * ni];
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+              for (int ni = 0; ni < TNI; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk][mi][t], b[kk][ni][t], acc[mi][ni], 0, 0, 0);
+      }
+      if (++stage == TG_STAGES) stage = 0;
+    }
+    // ---- the next tile's first k-tile (issued two k-tiles ago) before this tile's stores enter the queue behind it
+    if (next_t >= 0) tg_wait<NPIECE>();        // (its second k-tile is the one group that may still be outstanding: KT >= 2)
+    {
+      const long long t = cur_t;
+      const int batch = (int)(t / tiles), r0 = (int)(t - (long long)batch * tiles);
+      const int tn = r0 / p.tiles_m, tm = r0 - tn * p.tiles_m;
+      const int m0 = tm * TG_BM, n0 = tn * TG_BN;
+      float* Cb = p.C + batch * p.c_batch;
+#pragma unroll
+      for (int ni = 0; ni < TNI; ++ni) {
+        const int col = n0 + wn * WN_COLS + ni * 32 + fr;
+        const bool col_ok = col < p.N;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+          const int row0 = m0 + wm * 64 + mi * 32 + 4 * fh;
+          float* cp = Cb + (long long)row0 * p.ldc + col;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = row0 + (r & 3) + 8 * (r >> 2);
+            if (col_ok && row < p.M) *cp = acc[mi][ni][r];
+            cp += ((r & 3) == 3) ? 5 * p.ldc : p.ldc;
+          }
+        }
+      }
+    }
+    cur_t = next_t;
+    next_t = -1;
+  }
+}
+
 // out[i] = sum_s part[s][i], slices added in index order
 __global__ __launch_bounds__(256) void tg_reduce_kernel(const float* __restrict__ part, int S, long long n,
                                                         float* __restrict__ out) {
@@ -230,14 +438,36 @@ static int tg_launch(TgArgs a, long long batches, hipStream_t st) {
   return REGNET_OK;
 }
 
+template <bool A_KMAJ>
+static int tg_launch_stream(TgArgs a, long long batches, int32_t* ticket, hipStream_t st) {
+  a.tiles_m = (a.M + TG_BM - 1) / TG_BM;
+  a.tiles_n = (a.N + 255) / 256;
+  a.batches = (int)batches;
+  a.ticket = ticket;
+  const long long total = (long long)a.tiles_m * a.tiles_n * batches;
+  if (total <= 0) return REGNET_OK;
+  if (total >= (1ll << 31) - 4096 || batches >= (1ll << 31)) return REGNET_ERR_UNSUPPORTED;
+  static int slots = 0;                  // two workgroups per CU (73.7 KB of LDS each)
+  if (slots == 0) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+      cus = 256;
+    slots = 2 * cus;
+  }
+  const unsigned grid = (unsigned)(total < slots ? total : slots);
+  hipLaunchKernelGGL((tgemm_stream_kernel<A_KMAJ>), dim3(grid), dim3(TG_THREADS), 0, st, a);
+  REGNET_LAUNCH_CHECK();
+  return REGNET_OK;
+}
+
 // Shapes this build handles (everything else: the caller keeps its library path): channel counts multiples of 16,
 // points a multiple of 4, 16-byte aligned buffers.
 extern "C" int regnet_conv1x1_train_supported(int64_t Co, int64_t Ci, int64_t L) {
   return Co >= 32 && Ci >= 32 && (Co % 16) == 0 && (Ci % 16) == 0 && L >= 64 && (L % 4) == 0;
 }
 
-extern "C" int regnet_conv1x1_fwd_f32(const float* W, const float* X, float* Y, int64_t B, int64_t Co, int64_t Ci,
-                                      int64_t L, void* stream) {
+static int tg_fwd(const float* W, const float* X, float* Y, int64_t B, int64_t Co, int64_t Ci, int64_t L, int32_t* ticket,
+                  void* stream) {
   if (B < 0 || !regnet_conv1x1_train_supported(Co, Ci, L)) return REGNET_ERR_SHAPE;
   if (B == 0) return REGNET_OK;
   if (!W || !X || !Y) return REGNET_ERR_NULL;
@@ -247,11 +477,22 @@ extern "C" int regnet_conv1x1_fwd_f32(const float* W, const float* X, float* Y, 
   a.B = X; a.ldb = L; a.b_batch = Ci * L;                // kmaj: (l, i) at X[b] + i * L + l
   a.C = Y; a.ldc = L; a.c_batch = Co * L;
   a.M = (int)Co; a.N = (int)L; a.K = (int)Ci; a.slices = 1;
-  return tg_launch<false, true, 256>(a, B, as_stream(stream));
+  return ticket ? tg_launch_stream<false>(a, B, ticket, as_stream(stream)) : tg_launch<false, true, 256>(a, B, as_stream(stream));
 }
 
-extern "C" int regnet_conv1x1_dgrad_f32(const float* W, const float* dY, float* dX, int64_t B, int64_t Co, int64_t Ci,
-                                        int64_t L, void* stream) {
+extern "C" int regnet_conv1x1_fwd_f32(const float* W, const float* X, float* Y, int64_t B, int64_t Co, int64_t Ci,
+                                      int64_t L, void* stream) {
+  return tg_fwd(W, X, Y, B, Co, Ci, L, nullptr, stream);
+}
+
+extern "C" int regnet_conv1x1_fwd_stream_f32(const float* W, const float* X, float* Y, int64_t B, int64_t Co, int64_t Ci,
+                                             int64_t L, int32_t* ticket, void* stream) {
+  if (!ticket) return REGNET_ERR_NULL;
+  return tg_fwd(W, X, Y, B, Co, Ci, L, ticket, stream);
+}
+
+static int tg_dgrad(const float* W, const float* dY, float* dX, int64_t B, int64_t Co, int64_t Ci, int64_t L, int32_t* ticket,
+                    void* stream) {
   if (B < 0 || !regnet_conv1x1_train_supported(Co, Ci, L)) return REGNET_ERR_SHAPE;
   if (B == 0) return REGNET_OK;
   if (!W || !dY || !dX) return REGNET_ERR_NULL;
@@ -261,7 +502,18 @@ extern "C" int regnet_conv1x1_dgrad_f32(const float* W, const float* dY, float* 
   a.B = dY; a.ldb = L; a.b_batch = Co * L;               // kmaj: (l, o) at dY[b] + o * L + l
   a.C = dX; a.ldc = L; a.c_batch = Ci * L;
   a.M = (int)Ci; a.N = (int)L; a.K = (int)Co; a.slices = 1;
-  return tg_launch<true, true, 256>(a, B, as_stream(stream));
+  return ticket ? tg_launch_stream<true>(a, B, ticket, as_stream(stream)) : tg_launch<true, true, 256>(a, B, as_stream(stream));
+}
+
+extern "C" int regnet_conv1x1_dgrad_f32(const float* W, const float* dY, float* dX, int64_t B, int64_t Co, int64_t Ci,
+                                        int64_t L, void* stream) {
+  return tg_dgrad(W, dY, dX, B, Co, Ci, L, nullptr, stream);
+}
+
+extern "C" int regnet_conv1x1_dgrad_stream_f32(const float* W, const float* dY, float* dX, int64_t B, int64_t Co, int64_t Ci,
+                                               int64_t L, int32_t* ticket, void* stream) {
+  if (!ticket) return REGNET_ERR_NULL;
+  return tg_dgrad(W, dY, dX, B, Co, Ci, L, ticket, stream);
 }
 
 // Slices of the point axis for the weight gradient: enough (slice x tile) workgroups to fill the chip, slices of at

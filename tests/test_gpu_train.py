@@ -250,6 +250,18 @@ def test_gemm_conv1x1_matches_torch_convolution(shape, co):
         yc = conv1x1_train.conv1x1(conv, xc)
         yc.backward(up)
         assert torch.equal(yc, ya) and torch.equal(xc.grad, xa.grad) and torch.equal(conv.weight.grad, ga)
+        # ... and the persistent ticket-driven kernel (conv1x1_train.STREAM, the default) computes every tile exactly as the
+        # one-workgroup-per-tile kernel does
+        assert conv1x1_train.STREAM
+        conv1x1_train.STREAM = False
+        try:
+            xd = xa.detach().clone().requires_grad_(True)
+            conv.weight.grad = None
+            yd = conv1x1_train.conv1x1(conv, xd)
+            yd.backward(up)
+        finally:
+            conv1x1_train.STREAM = True
+        assert torch.equal(yd, ya) and torch.equal(xd.grad, xa.grad) and torch.equal(conv.weight.grad, ga)
 
 
 def test_training_first_layer_before_gather_matches_plain_path():
