@@ -58,6 +58,8 @@ def parse():
     ap.add_argument("--exclusive-steps", type=int, default=48,
                     help="with --mlp-streams > 1: extra steps (outside the timed region) with one feature-stage stream for "
                          "per-kernel accounting (roofline_exclusive); 0 = skip")
+    ap.add_argument("--gc-interval", type=int, default=TRAIN_GC_INTERVAL,
+                    help="--train: iterations between the trainer's own garbage collections (RefineTrainer(gc_interval=...))")
     ap.add_argument("--mlp-streams", type=int, default=1, help="feature-stage streams (batches whose MFMA kernels may overlap): 2 is ~6 %% faster (875 scenes/s) but "
                          "time-shares the launches, so per-kernel durations stop being a kernel property (DESIGN.md par. 7)")
     ap.add_argument("--fps-streams", type=int, default=2, help="level-1 sampling launches in flight")
@@ -352,7 +354,7 @@ def measure_train(args, rank, world, dev, steps, warmup, batch):
     import gc
     gc_was_on = gc.isenabled()
     trainer = RefineTrainer(score_net.to(dev), region_net.to(dev), pipeline.PARAMS, pipeline.GRIPPER_PARAMS,
-                            gc_interval=TRAIN_GC_INTERVAL)
+                            gc_interval=args.gc_interval)
     pc = pc_cpu.to(dev)
     np.random.seed(rank)
     # HIP events around the native 1x1-convolution kernels (forward / input gradient / weight gradient: the MFMA work of
@@ -411,8 +413,8 @@ def measure_train(args, rank, world, dev, steps, warmup, batch):
             "allreduce_ms": round(sum(allreduce_ms) / len(allreduce_ms), 4) if allreduce_ms else None,
             # CPython's automatic cyclic collector is off during training (RefineTrainer(gc_interval=N) collects every N
             # iterations itself: left on, it stalls every ~10th iteration by 60-100 ms); the amortised cost is in this figure
-            "gc": {"interval_iterations": TRAIN_GC_INTERVAL, "one_collection_ms": round(gc_ms, 2),
-                   "ms_per_step_incl_amortised_gc": round(dt / steps * 1e3 + gc_ms / TRAIN_GC_INTERVAL, 3)},
+            "gc": {"interval_iterations": args.gc_interval, "one_collection_ms": round(gc_ms, 2),
+                   "ms_per_step_incl_amortised_gc": round(dt / steps * 1e3 + (gc_ms / args.gc_interval if steps < args.gc_interval else 0.0), 3)},
             "config": {"workload": "%s: training iteration (forward with labels, stage-2 + refine losses, backward, "
                                    "two Adam steps), %d-pt synthetic scenes, batch=%d per GPU" % (
                                        "configs[4]" if N == 51200 else "configs[3]", N, B),

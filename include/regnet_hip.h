@@ -376,6 +376,15 @@ int regnet_bn_relu_train_bwd_f32(const float* x, const float* y, const float* dy
                                  const float* save_invstd, int relu, int64_t pool_group, float* dx, float* dgamma,
                                  float* dbeta, void* workspace, void* stream);
 
+/* The statistics half of regnet_bn_relu_train_fwd_f32 alone, plus the normalisation as a per-channel affine
+ * (scale = gamma * invstd, shift = beta - mean * scale), for the convolution that consumes the BatchNorm's output and applies
+ * it to its own operand (regnet_conv1x1_fwd_bnrelu_stream_f32 / regnet_conv1x1_wgrad_bnrelu_f32 below): conv -> bn -> relu ->
+ * conv of nn/modules/mlp.py:95-107 without writing the normalised activation.  The backward is regnet_bn_relu_train_bwd_f32
+ * on the input gradient of that convolution.                                                                           */
+int regnet_bn_train_stats_f32(const float* x, int64_t B, int64_t C, int64_t L, const float* gamma, const float* beta, float eps,
+                              float momentum, float* running_mean, float* running_var, float* save_mean, float* save_invstd,
+                              float* scale, float* shift, void* workspace, void* stream);
+
 /* ---- set-abstraction layers 1+2 with layer 1 evaluated per SOURCE point ---------------------------
  * The first SharedMLP layer of a set-abstraction block (pn2_utils/modules.py:44-55: conv over
  * [xyz_j - xyz_c | feature_j]) is linear in the gathered row, so
@@ -510,6 +519,15 @@ int regnet_conv1x1_fwd_stream_f32(const float* W, const float* X, float* Y, int6
                                   int32_t* ticket, void* stream);
 int regnet_conv1x1_dgrad_stream_f32(const float* W, const float* dY, float* dX, int64_t B, int64_t Co, int64_t Ci, int64_t L,
                                     int32_t* ticket, void* stream);
+/* ..._bnrelu: the convolution's input is [relu](scale[i] * X[., i, .] + shift[i]) -- a training BatchNorm (+ ReLU) given as
+ * its per-channel affine (regnet_bn_train_stats_f32) -- applied to the operand fragments inside the contraction; X itself
+ * is the BatchNorm's INPUT.  regnet_conv1x1_bnrelu_supported: train_supported, Ci <= 512 (the affine table lives in LDS),
+ * L % 16 == 0.                                                                                                         */
+int regnet_conv1x1_bnrelu_supported(int64_t Co, int64_t Ci, int64_t L);
+int regnet_conv1x1_fwd_bnrelu_stream_f32(const float* W, const float* X, float* Y, int64_t B, int64_t Co, int64_t Ci, int64_t L,
+                                         const float* scale, const float* shift, int relu, int32_t* ticket, void* stream);
+int regnet_conv1x1_wgrad_bnrelu_f32(const float* dY, const float* X, float* dW, int64_t B, int64_t Co, int64_t Ci, int64_t L,
+                                    const float* scale, const float* shift, int relu, void* workspace, void* stream);
 int64_t regnet_conv1x1_wgrad_slices(int64_t B, int64_t Co, int64_t Ci, int64_t L);
 int64_t regnet_conv1x1_wgrad_workspace_bytes(int64_t B, int64_t Co, int64_t Ci, int64_t L);
 int regnet_conv1x1_wgrad_f32(const float* dY, const float* X, float* dW, int64_t B, int64_t Co, int64_t Ci, int64_t L,

@@ -84,6 +84,57 @@ class _BnReluTrain(torch.autograd.Function):
         return dx, dgamma, dbeta, None, None, None, None, None, None
 
 
+class Pending:
+    """A training BatchNorm (+ ReLU) whose statistics exist but whose output does not: ``x`` is its INPUT, ``scale`` / ``shift``
+    the normalisation as a per-channel affine.  The convolution that consumes it applies the affine to its own operand
+    (conv1x1_train.conv1x1_of_pending) and runs this BatchNorm's backward on its input gradient."""
+    __slots__ = ("x", "gamma", "beta", "mean", "invstd", "scale", "shift", "relu")
+
+
+def bn_stats(bn, x, relu=True):
+    """Batch statistics of ``bn`` over ``x`` (running statistics and ``num_batches_tracked`` updated as the module's forward
+    would) -> Pending; check ``supported`` first."""
+    if not supported(bn, x):
+        raise RuntimeError("bn_train.bn_stats: unsupported module / input (call supported() first)")
+    bn.num_batches_tracked.add_(1)
+    xc = _aligned(x)
+    B, C = xc.shape[0], xc.shape[1]
+    L = xc.numel() // (B * C)
+    dev = xc.device
+    p = Pending()
+    with torch.cuda.device(dev):
+        ws = torch.empty((_L.regnet_bn_workspace_bytes(C),), dtype=torch.uint8, device=dev)
+        out = torch.empty((4, C), dtype=torch.float32, device=dev)
+        p.mean, p.invstd, p.scale, p.shift = out[0], out[1], out[2], out[3]
+        p.gamma, p.beta = bn.weight, bn.bias
+        g, b = bn.weight.detach().contiguous(), bn.bias.detach().contiguous()
+        _check(_L.regnet_bn_train_stats_f32(xc.data_ptr(), B, C, L, g.data_ptr(), b.data_ptr(), float(bn.eps),
+                                            float(bn.momentum), bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
+                                            p.mean.data_ptr(), p.invstd.data_ptr(), p.scale.data_ptr(), p.shift.data_ptr(),
+                                            ws.data_ptr(), torch.cuda.current_stream(dev).cuda_stream), "bn_train_stats")
+    p.x, p.relu = xc, int(relu)
+    return p
+
+
+def bn_backward(x, dz, gamma, beta, mean, invstd, relu):
+    """Training BatchNorm (+ ReLU) backward given the gradient ``dz`` of its output: -> (dx, dgamma, dbeta)."""
+    B, C = x.shape[0], x.shape[1]
+    L = x.numel() // (B * C)
+    dev = x.device
+    dz = _aligned(dz)
+    gamma, beta = gamma.detach().contiguous(), beta.detach().contiguous()
+    with torch.cuda.device(dev):
+        ws = torch.empty((_L.regnet_bn_workspace_bytes(C),), dtype=torch.uint8, device=dev)
+        dx = torch.empty_like(x)
+        dgamma = torch.empty((C,), dtype=torch.float32, device=dev)
+        dbeta = torch.empty((C,), dtype=torch.float32, device=dev)
+        _check(_L.regnet_bn_relu_train_bwd_f32(x.data_ptr(), None, dz.data_ptr(), None, B, C, L, gamma.data_ptr(), beta.data_ptr(),
+                                               mean.data_ptr(), invstd.data_ptr(), int(relu), 0, dx.data_ptr(), dgamma.data_ptr(),
+                                               dbeta.data_ptr(), ws.data_ptr(), torch.cuda.current_stream(dev).cuda_stream),
+               "bn_relu_train_bwd")
+    return dx, dgamma, dbeta
+
+
 def bn_relu(bn, x, relu=True, pool_group=0):
     """``[max over the last axis of] [relu](bn(x))`` for a BatchNorm module in training mode; check ``supported`` first."""
     if not supported(bn, x, pool_group):

@@ -18,6 +18,11 @@ ENABLED = True     # module switches (bench.py --set conv1x1_train.ENABLED=0); n
 NATIVE = True
 # forward / input gradient by the persistent ticket-driven kernel (csrc/tgemm.hip: tgemm_stream_kernel); 0: one workgroup per tile
 STREAM = True
+# conv -> bn -> relu -> conv inside a shared-MLP stack without the normalised activation: the first convolution's BatchNorm is
+# evaluated as statistics only, the second convolution applies the normalisation + ReLU to its operand fragments (forward and
+# weight gradient) and runs the BatchNorm's backward on its input gradient (csrc/tgemm.hip B_AFFINE, bn_train.Pending)
+DEFER_BN = True
+DEFERRED = {"layers": 0}     # convolutions that consumed a pending BatchNorm since import (tests, bench)
 
 
 def _native_ok(B, Co, Ci, L, wgrad=False):
@@ -152,6 +157,69 @@ class _Conv1x1(torch.autograd.Function):
                 torch.bmm(ds, xs, out=part[b])
             dw = part.sum((0, 1)) if B * S > 1 else part.view(Co, Ci)
         return dx, dw
+
+
+class _BnReluConv(torch.autograd.Function):
+    """y = W . [relu](bn(x)) with bn in training mode, given bn's statistics (bn_train.Pending): one node for the BatchNorm's
+    apply, the ReLU and the convolution; [relu](bn(x)) is never stored."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, w, mean, invstd, scale, shift, relu):
+        from . import _lib, fused
+        B, Ci, L = x.shape
+        Co = w.shape[0]
+        w = w.contiguous()
+        y = torch.empty((B, Co, L), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib.regnet_conv1x1_fwd_bnrelu_stream_f32(w.data_ptr(), x.data_ptr(), y.data_ptr(), B, Co, Ci, L,
+                                                                     scale.data_ptr(), shift.data_ptr(), relu,
+                                                                     fused._tickets(x.device).data_ptr(), _stream(x)),
+                       "conv1x1_fwd_bnrelu")
+        ctx.save_for_backward(x, gamma, beta, w, mean, invstd, scale, shift)
+        ctx.relu = relu
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import _lib, bn_train
+        x, gamma, beta, w, mean, invstd, scale, shift = ctx.saved_tensors
+        dy = dy.contiguous()
+        B, Ci, L = x.shape
+        Co = w.shape[0]
+        dz = native_dgrad(w, dy)
+        dw = None
+        if ctx.needs_input_grad[3]:
+            L_ = _lib.lib
+            dw = torch.empty((Co, Ci), dtype=torch.float32, device=x.device)
+            ws_bytes = L_.regnet_conv1x1_wgrad_workspace_bytes(B, Co, Ci, L)
+            ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=x.device) if ws_bytes else None
+            with torch.cuda.device(x.device):
+                _lib.check(L_.regnet_conv1x1_wgrad_bnrelu_f32(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), B, Co, Ci, L,
+                                                              scale.data_ptr(), shift.data_ptr(), ctx.relu,
+                                                              ws.data_ptr() if ws is not None else None, _stream(x)),
+                           "conv1x1_wgrad_bnrelu")
+        dx, dgamma, dbeta = bn_train.bn_backward(x, dz, gamma, beta, mean, invstd, ctx.relu)
+        return dx, dgamma, dbeta, dw, None, None, None, None, None
+
+
+def pending_ok(conv, x):
+    """``conv`` can consume a bn_train.Pending whose BatchNorm input is ``x`` (shape of the activation)."""
+    if not (DEFER_BN and STREAM and NATIVE and supported(conv, x)):
+        return False
+    from . import _lib
+    B, Ci = x.shape[0], x.shape[1]
+    return bool(_lib.lib.regnet_conv1x1_bnrelu_supported(conv.weight.shape[0], Ci, x.numel() // max(B * Ci, 1)))
+
+
+def conv1x1_of_pending(conv, pending, shape):
+    """``conv([relu](bn(x)))`` for a bn_train.Pending of that BatchNorm; ``shape``: of x as the stack sees it ((B,C,N) or
+    (B,C,N,K)); check ``pending_ok`` first."""
+    B, Ci = shape[0], shape[1]
+    Co = conv.weight.shape[0]
+    DEFERRED["layers"] += 1
+    y = _BnReluConv.apply(pending.x.view(B, Ci, -1), pending.gamma, pending.beta, conv.weight.view(Co, Ci), pending.mean,
+                          pending.invstd, pending.scale, pending.shift, pending.relu)
+    return y.view(B, Co, *shape[2:])
 
 
 def gemm_conv(x, w):

@@ -69,7 +69,9 @@ __global__ __launch_bounds__(BN_T) void bn_stats_kernel(const float* __restrict_
 // the unbiased variance, as torch)
 __global__ void bn_finalize_kernel(const double* __restrict__ sums, double n, float eps, float momentum, int C,
                                    float* __restrict__ running_mean, float* __restrict__ running_var,
-                                   float* __restrict__ save_mean, float* __restrict__ save_invstd) {
+                                   float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                                   const float* __restrict__ gamma = nullptr, const float* __restrict__ beta = nullptr,
+                                   float* __restrict__ scale = nullptr, float* __restrict__ shift = nullptr) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   const double mean = sums[2 * c] / n;
@@ -77,6 +79,11 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, double n, fl
   if (var < 0) var = 0;
   save_mean[c] = (float)mean;
   save_invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (scale) {      // y = scale * x + shift: the normalisation as the affine a consuming contraction applies to its operand
+    const float sc = gamma[c] * save_invstd[c];
+    scale[c] = sc;
+    shift[c] = beta[c] - save_mean[c] * sc;
+  }
   if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
   if (running_var) {
     const double unbiased = n > 1 ? var * n / (n - 1) : var;
@@ -335,6 +342,28 @@ extern "C" int regnet_bn_relu_train_bwd_f32(const float* x, const float* y, cons
                        relu, sums, n, dx);
   }
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)((C + 127) / 128)), dim3(128), 0, st, sums, (int)C, dgamma, dbeta);
+  REGNET_LAUNCH_CHECK();
+  return REGNET_OK;
+}
+
+// The statistics half of the forward alone: batch mean / inverse std (+ running statistics), and the normalisation as a
+// per-channel affine (scale = gamma * invstd, shift = beta - mean * scale) for a consumer that applies it itself
+// (regnet_conv1x1_fwd_bnrelu_stream_f32 / regnet_conv1x1_wgrad_bnrelu_f32): the normalised activation is never written.
+extern "C" int regnet_bn_train_stats_f32(const float* x, int64_t B, int64_t C, int64_t L, const float* gamma, const float* beta,
+                                         float eps, float momentum, float* running_mean, float* running_var, float* save_mean,
+                                         float* save_invstd, float* scale, float* shift, void* workspace, void* stream) {
+  if (B < 0 || C < 0 || L < 0) return REGNET_ERR_SHAPE;
+  if (B == 0 || C == 0 || L == 0) return REGNET_OK;
+  if (!x || !gamma || !beta || !save_mean || !save_invstd || !scale || !shift || !workspace) return REGNET_ERR_NULL;
+  if (!bn_dims_ok(B, C, L)) return REGNET_ERR_UNSUPPORTED;
+  hipStream_t st = as_stream(stream);
+  double* sums = static_cast<double*>(workspace);
+  hipError_t e = hipMemsetAsync(sums, 0, regnet_bn_workspace_bytes(C), st);
+  if (e != hipSuccess) return (int)e;
+  dim3 grid((unsigned)((L + BN_CHUNK - 1) / BN_CHUNK), (unsigned)C, (unsigned)B);
+  hipLaunchKernelGGL(bn_stats_kernel, grid, dim3(BN_T), 0, st, x, (int)C, L, sums);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((C + 127) / 128)), dim3(128), 0, st, sums, (double)B * (double)L,
+                     eps, momentum, (int)C, running_mean, running_var, save_mean, save_invstd, gamma, beta, scale, shift);
   REGNET_LAUNCH_CHECK();
   return REGNET_OK;
 }

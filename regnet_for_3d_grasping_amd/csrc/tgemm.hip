@@ -33,6 +33,7 @@ typedef float tg_f32x16 __attribute__((ext_vector_type(16)));
 #define TG_BK 16
 #define TG_STAGES 3
 #define TG_THREADS 512
+#define TG_AFF_MAXK 512       // B_AFFINE forward: channels whose (scale, shift) fit the workgroup's LDS table (2 workgroups per CU)
 #ifndef TG_WGRAD_BLOCKS
 #define TG_WGRAD_BLOCKS 256    // weight gradient: (slice x tile x scene) workgroups to aim for -- one per CU: every slice costs a partial matrix and a
                                // shorter K loop; measured over a training iteration (8 x 25 600): 1024 -> 29.7 ms of tgemm, 512 -> 28.6, 256 -> 27.4, 128 -> 33.3
@@ -46,6 +47,9 @@ struct TgArgs {
   int tiles_m, tiles_n, slices;                       // grid = tiles_m * tiles_n * slices * batches
   int batches;                                        // tgemm_stream_kernel only (its grid does not encode them)
   int* ticket;                                        // tgemm_stream_kernel: next tile to hand out - gridDim.x (zeroed by the caller)
+  // B_AFFINE: the B operand is used as max(bscale[c] * x + bshift[c], brelu ? 0 : -inf), c = its channel -- the BatchNorm (+ ReLU)
+  // between two convolutions of a shared-MLP block applied on the fragment, so that its output is never written (see the ABI)
+  const float* bscale; const float* bshift; int brelu;
 };
 
 __device__ __forceinline__ void tg_glds16(const float* gsrc, unsigned lds_dst) {
@@ -59,8 +63,9 @@ template <int N> __device__ __forceinline__ void tg_wait_barrier() {
 
 // TG_BN = 256 (wave tile 64 x 64) or 128 (64 x 32: the weight gradient of layers with <= 128 input channels, whose N
 // axis is only that wide).
-template <bool A_KMAJ, bool B_KMAJ, int TG_BN>
+template <bool A_KMAJ, bool B_KMAJ, int TG_BN, bool B_AFFINE = false>
 __global__ __launch_bounds__(TG_THREADS, 4) void tgemm_kernel(const TgArgs p) {
+  static_assert(!(B_AFFINE && B_KMAJ), "tgemm_kernel applies the affine to row-layout B operands (the weight gradient)");
   constexpr int TG_STAGE_FLOATS = (TG_BM + TG_BN) * TG_BK;
   constexpr int TNI = TG_BN / 128;                      // 32-column accumulators per wave along N
   constexpr int WN_COLS = TG_BN / 4;                    // columns per wave
@@ -118,6 +123,17 @@ __global__ __launch_bounds__(TG_THREADS, 4) void tgemm_kernel(const TgArgs p) {
       }
     }
   }
+  // B_AFFINE: a lane's B fragments are rows n0 + wn * WN_COLS + 32 ni + fr of the operand: one (scale, shift) per ni
+  float bsc[TNI], bsh[TNI];
+  const float blo = (B_AFFINE && !p.brelu) ? -INFINITY : 0.f;
+  if (B_AFFINE) {
+#pragma unroll
+    for (int ni = 0; ni < TNI; ++ni) {
+      int r = n0 + wn * WN_COLS + 32 * ni + fr;
+      if (r >= p.N) r = 0;
+      bsc[ni] = p.bscale[r]; bsh[ni] = p.bshift[r];
+    }
+  }
   const unsigned smem_base = (unsigned)(uintptr_t)smem;
 #define TG_ISSUE(KT_, STAGE_)                                                                         \
   _Pragma("unroll") for (int j = 0; j < NPIECE; ++j)                                                   \
@@ -161,6 +177,10 @@ __global__ __launch_bounds__(TG_THREADS, 4) void tgemm_kernel(const TgArgs p) {
         } else {                                                                                                   \
           const float4 v = *reinterpret_cast<const float4*>(st + offB[kk] + ni * 32 * TG_BK);                      \
           b[kk][ni][0] = v.x; b[kk][ni][1] = v.y; b[kk][ni][2] = v.z; b[kk][ni][3] = v.w;                          \
+          if (B_AFFINE) {                                                                                          \
+            _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                          \
+              b[kk][ni][t] = fmaxf(fmaf(b[kk][ni][t], bsc[ni], bsh[ni]), blo);                                     \
+          }                                                                                                        \
         }                                                                                                          \
       }                                                                                                            \
     }                                                                                                              \
@@ -227,7 +247,7 @@ __device__ __forceinline__ int tg_ticket_nowait(int* p) {
 // panel run at the same time), treating their k-tiles as ONE sequence through the 3-stage ring.  Tickets, not a fixed
 // stride: in the training iteration the next batch's sampling holds eight CUs for 4 ms at a time; a workgroup that cannot
 // start there must not own tiles (measured with a fixed stride: 5 % faster on an idle chip, 3 % slower in the iteration).
-template <bool A_KMAJ>
+template <bool A_KMAJ, bool B_AFFINE = false>
 __global__ __launch_bounds__(TG_THREADS, 4) void tgemm_stream_kernel(const TgArgs p) {
   constexpr int TG_BN = 256, TNI = 2, WN_COLS = 64, NPIECE = 3;
   constexpr int TG_STAGE_FLOATS = (TG_BM + TG_BN) * TG_BK;
@@ -241,6 +261,12 @@ __global__ __launch_bounds__(TG_THREADS, 4) void tgemm_stream_kernel(const TgArg
   const int G = gridDim.x, bid = blockIdx.x;
   if (bid >= total) return;
   __shared__ long long s_next[2];                                 // tiles drawn from the counter, by parity of their number
+  __shared__ __attribute__((aligned(16))) float btab[B_AFFINE ? 2 * TG_AFF_MAXK : 4];   // B_AFFINE: (scale, shift) per channel of K
+  if (B_AFFINE) {
+    for (int i = tid; i < p.K; i += TG_THREADS) { btab[2 * i] = p.bscale[i]; btab[2 * i + 1] = p.bshift[i]; }
+    __syncthreads();
+  }
+  const float blo = (B_AFFINE && !p.brelu) ? -INFINITY : 0.f;
   const int KT = p.K / TG_BK;                                     // >= 2 (launcher)
 
   // ---- LDS-DMA pieces of this wave (as tgemm_kernel: pieces 0..7 = A, 8..23 = B; piece = 1 KiB): tile-independent parts
@@ -367,6 +393,17 @@ __global__ __launch_bounds__(TG_THREADS, 4) void tgemm_stream_kernel(const TgArg
 #pragma unroll
             for (int t = 0; t < 4; ++t) b[kk][ni][t] = st[kmB + (8 * kk + t) * TG_BN + 32 * ni];
           }
+          if (B_AFFINE) {      // fragment element t is channel 16 kt + 8 kk + 4 fh + t of the operand
+            const float4 c01 = *reinterpret_cast<const float4*>(&btab[2 * (TG_BK * kt + 8 * kk + 4 * fh)]);
+            const float4 c23 = *reinterpret_cast<const float4*>(&btab[2 * (TG_BK * kt + 8 * kk + 4 * fh) + 4]);
+#pragma unroll
+            for (int ni = 0; ni < TNI; ++ni) {
+              b[kk][ni][0] = fmaxf(fmaf(b[kk][ni][0], c01.x, c01.y), blo);
+              b[kk][ni][1] = fmaxf(fmaf(b[kk][ni][1], c01.z, c01.w), blo);
+              b[kk][ni][2] = fmaxf(fmaf(b[kk][ni][2], c23.x, c23.y), blo);
+              b[kk][ni][3] = fmaxf(fmaf(b[kk][ni][3], c23.z, c23.w), blo);
+            }
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -426,19 +463,19 @@ __global__ __launch_bounds__(256) void tg_reduce_kernel(const float* __restrict_
 
 static bool tg_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-template <bool A_KMAJ, bool B_KMAJ, int TG_BN>
+template <bool A_KMAJ, bool B_KMAJ, int TG_BN, bool B_AFFINE = false>
 static int tg_launch(TgArgs a, long long batches, hipStream_t st) {
   a.tiles_m = (a.M + TG_BM - 1) / TG_BM;
   a.tiles_n = (a.N + TG_BN - 1) / TG_BN;
   const long long blocks = (long long)a.tiles_m * a.tiles_n * a.slices * batches;
   if (blocks <= 0) return REGNET_OK;
   if (blocks >= (1ll << 31)) return REGNET_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL((tgemm_kernel<A_KMAJ, B_KMAJ, TG_BN>), dim3((unsigned)blocks), dim3(TG_THREADS), 0, st, a);
+  hipLaunchKernelGGL((tgemm_kernel<A_KMAJ, B_KMAJ, TG_BN, B_AFFINE>), dim3((unsigned)blocks), dim3(TG_THREADS), 0, st, a);
   REGNET_LAUNCH_CHECK();
   return REGNET_OK;
 }
 
-template <bool A_KMAJ>
+template <bool A_KMAJ, bool B_AFFINE = false>
 static int tg_launch_stream(TgArgs a, long long batches, int32_t* ticket, hipStream_t st) {
   a.tiles_m = (a.M + TG_BM - 1) / TG_BM;
   a.tiles_n = (a.N + 255) / 256;
@@ -455,7 +492,7 @@ static int tg_launch_stream(TgArgs a, long long batches, int32_t* ticket, hipStr
     slots = 2 * cus;
   }
   const unsigned grid = (unsigned)(total < slots ? total : slots);
-  hipLaunchKernelGGL((tgemm_stream_kernel<A_KMAJ>), dim3(grid), dim3(TG_THREADS), 0, st, a);
+  hipLaunchKernelGGL((tgemm_stream_kernel<A_KMAJ, B_AFFINE>), dim3(grid), dim3(TG_THREADS), 0, st, a);
   REGNET_LAUNCH_CHECK();
   return REGNET_OK;
 }
@@ -489,6 +526,26 @@ extern "C" int regnet_conv1x1_fwd_stream_f32(const float* W, const float* X, flo
                                              int64_t L, int32_t* ticket, void* stream) {
   if (!ticket) return REGNET_ERR_NULL;
   return tg_fwd(W, X, Y, B, Co, Ci, L, ticket, stream);
+}
+
+extern "C" int regnet_conv1x1_bnrelu_supported(int64_t Co, int64_t Ci, int64_t L) {
+  return regnet_conv1x1_train_supported(Co, Ci, L) && Ci <= TG_AFF_MAXK && (L % 16) == 0;
+}
+
+extern "C" int regnet_conv1x1_fwd_bnrelu_stream_f32(const float* W, const float* X, float* Y, int64_t B, int64_t Co, int64_t Ci,
+                                                    int64_t L, const float* scale, const float* shift, int relu,
+                                                    int32_t* ticket, void* stream) {
+  if (B < 0 || !regnet_conv1x1_bnrelu_supported(Co, Ci, L)) return REGNET_ERR_SHAPE;
+  if (B == 0) return REGNET_OK;
+  if (!W || !X || !Y || !scale || !shift || !ticket) return REGNET_ERR_NULL;
+  if (!tg_aligned16(W) || !tg_aligned16(X) || !tg_aligned16(Y)) return REGNET_ERR_SHAPE;
+  TgArgs a = {};
+  a.A = W; a.lda = Ci;
+  a.B = X; a.ldb = L; a.b_batch = Ci * L;
+  a.C = Y; a.ldc = L; a.c_batch = Co * L;
+  a.M = (int)Co; a.N = (int)L; a.K = (int)Ci; a.slices = 1;
+  a.bscale = scale; a.bshift = shift; a.brelu = relu;
+  return tg_launch_stream<false, true>(a, B, ticket, as_stream(stream));
 }
 
 static int tg_dgrad(const float* W, const float* dY, float* dX, int64_t B, int64_t Co, int64_t Ci, int64_t L, int32_t* ticket,
@@ -530,8 +587,8 @@ extern "C" int64_t regnet_conv1x1_wgrad_workspace_bytes(int64_t B, int64_t Co, i
   return n > 1 ? n * Co * Ci * (int64_t)sizeof(float) : 0;
 }
 
-extern "C" int regnet_conv1x1_wgrad_f32(const float* dY, const float* X, float* dW, int64_t B, int64_t Co, int64_t Ci,
-                                        int64_t L, void* workspace, void* stream) {
+static int tg_wgrad(const float* dY, const float* X, float* dW, int64_t B, int64_t Co, int64_t Ci, int64_t L,
+                    const float* scale, const float* shift, int relu, bool affine, void* workspace, void* stream) {
   if (B <= 0 || !regnet_conv1x1_train_supported(Co, Ci, L) || (L % 16)) return REGNET_ERR_SHAPE;
   if (!dY || !X || !dW) return REGNET_ERR_NULL;
   const int64_t S = regnet_conv1x1_wgrad_slices(B, Co, Ci, L), n = B * S;
@@ -542,11 +599,27 @@ extern "C" int regnet_conv1x1_wgrad_f32(const float* dY, const float* X, float* 
   a.B = X;  a.ldb = L; a.b_batch = Ci * L; a.b_slice = L / S;      // row: (i, l)
   a.C = n > 1 ? (float*)workspace : dW; a.ldc = Ci; a.c_batch = S * Co * Ci; a.c_slice = Co * Ci;
   a.M = (int)Co; a.N = (int)Ci; a.K = (int)(L / S); a.slices = (int)S;
-  int rc = Ci <= 128 ? tg_launch<false, false, 128>(a, B, as_stream(stream)) : tg_launch<false, false, 256>(a, B, as_stream(stream));
+  a.bscale = scale; a.bshift = shift; a.brelu = relu;
+  int rc = affine ? (Ci <= 128 ? tg_launch<false, false, 128, true>(a, B, as_stream(stream))
+                               : tg_launch<false, false, 256, true>(a, B, as_stream(stream)))
+                  : (Ci <= 128 ? tg_launch<false, false, 128>(a, B, as_stream(stream))
+                               : tg_launch<false, false, 256>(a, B, as_stream(stream)));
   if (rc || n == 1) return rc;
   const long long total = Co * Ci;                                 // multiple of 4 (both multiples of 16)
   hipLaunchKernelGGL(tg_reduce_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, as_stream(stream),
                      (const float*)workspace, (int)n, total, dW);
   REGNET_LAUNCH_CHECK();
   return REGNET_OK;
+}
+
+extern "C" int regnet_conv1x1_wgrad_f32(const float* dY, const float* X, float* dW, int64_t B, int64_t Co, int64_t Ci,
+                                        int64_t L, void* workspace, void* stream) {
+  return tg_wgrad(dY, X, dW, B, Co, Ci, L, nullptr, nullptr, 0, false, workspace, stream);
+}
+
+extern "C" int regnet_conv1x1_wgrad_bnrelu_f32(const float* dY, const float* X, float* dW, int64_t B, int64_t Co, int64_t Ci,
+                                               int64_t L, const float* scale, const float* shift, int relu, void* workspace,
+                                               void* stream) {
+  if (!scale || !shift) return REGNET_ERR_NULL;
+  return tg_wgrad(dY, X, dW, B, Co, Ci, L, scale, shift, relu, true, workspace, stream);
 }

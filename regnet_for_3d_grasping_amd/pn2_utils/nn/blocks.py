@@ -25,13 +25,15 @@ class _AffineBNReLU(nn.Module):
 
     def forward(self, x, pool_max=False):
         """``pool_max``: also take the max over the last axis (the set-abstraction reduction, modules.py:245)."""
+        return self.after_affine(self.affine_only(x), pool_max)
+
+    def affine_only(self, x):
+        """The block's convolution / linear layer alone."""
         affine = getattr(self, self._affine_name)
         if self.training and x.is_cuda and self._affine_name == "conv":
             from ... import conv1x1_train
-            x = conv1x1_train.conv1x1(affine, x) if conv1x1_train.supported(affine, x) else affine(x)
-        else:
-            x = affine(x)
-        return self.after_affine(x, pool_max)
+            return conv1x1_train.conv1x1(affine, x) if conv1x1_train.supported(affine, x) else affine(x)
+        return affine(x)
 
     def after_affine(self, x, pool_max=False):
         """BatchNorm -> ReLU (-> max over the last axis) of the block, given the affine layer's output.  Callers that
@@ -100,17 +102,35 @@ class _Stack(nn.ModuleList):
         first block's convolution (evaluated by the caller before a gather / interpolation, which it commutes with)."""
         last = len(self) - 1
         dropout = self.training and self.dropout_prob > 0.0
+        pending = None          # (bn_train.Pending, activation shape): the previous block's BatchNorm + ReLU, not applied yet
         for i, block in enumerate(self):
             fuse = pool_max and i == last and not dropout
-            if i == 0 and first_affine_done:
-                x = block.after_affine(x, pool_max=fuse)
-            else:
-                x = block(x, pool_max=True) if fuse else block(x)
+            if pending is not None:
+                from ... import conv1x1_train
+                x = conv1x1_train.conv1x1_of_pending(block.conv, pending[0], pending[1])
+                pending = None
+            elif not (i == 0 and first_affine_done):
+                x = block.affine_only(x)
+            # x is the block's convolution output.  conv -> bn -> relu -> conv without the normalised activation in between
+            # (training on the GPU): this block only takes the batch statistics, the next block's convolution applies them
+            if i < last and not dropout and self._defers(block, self[i + 1], x):
+                from ... import bn_train
+                pending = (bn_train.bn_stats(block.bn, x, block.relu is not None), x.shape)
+                continue
+            x = block.after_affine(x, pool_max=fuse)
             if dropout:
                 x = self._dropout(x)
         if pool_max and (dropout or last < 0):
             x = torch.max(x, x.dim() - 1)[0]
         return x
+
+    @staticmethod
+    def _defers(block, nxt, x):
+        if not (block.training and x.is_cuda and x.dtype == torch.float32 and block.bn is not None
+                and block._affine_name == "conv" and nxt._affine_name == "conv"):
+            return False
+        from ... import bn_train, conv1x1_train
+        return bn_train.supported(block.bn, x) and conv1x1_train.pending_ok(nxt.conv, x)
 
     def init_weights(self, init_fn=None):
         for block in self:

@@ -107,6 +107,55 @@ def test_shared_mlp_training_uses_the_fused_passes_and_matches_torch():
         _close(p.float(), q.float())
 
 
+@pytest.mark.parametrize("shape,channels,pool,deferred", [
+    ((2, 64, 300, 64), (64, 128, 128), True, 2),      # L = 19 200: ragged last point tile
+    ((3, 128, 4112), (128, 64, 256), False, 2),       # 1-D, L % 256 = 16
+    ((8, 32, 2048, 64), (64, 64), True, 1),           # many point tiles per workgroup
+    ((1, 256, 640), (512, 256, 128), False, 2),       # fewer tiles than workgroup slots
+    ((2, 6, 128, 64), (64, 64, 128), True, 2),        # first layer off the native kernels (6 channels): its BatchNorm still deferred
+    ((2, 512, 1024), (1024, 256, 128), False, 1),     # second layer has 1 024 input channels: its BatchNorm the plain way
+    ((2, 128, 1000), (128, 128), False, 0)])          # L % 16 != 0: nothing deferred
+def test_deferred_batchnorm_between_convolutions(shape, channels, pool, deferred):
+    """conv1x1_train.DEFER_BN: conv -> bn -> relu -> conv of a shared-MLP stack with the BatchNorm taken as statistics only
+    and applied by the NEXT convolution to its operand fragments, forward and weight gradient (csrc/tgemm.hip B_AFFINE): the
+    same outputs, running statistics and gradients as with the activation written out, and as torch's own modules in float64
+    (nn/modules/conv.py:30-36, mlp.py:95-107)."""
+    from regnet_for_3d_grasping_amd import conv1x1_train
+    from regnet_for_3d_grasping_amd.pn2_utils.nn import SharedMLP
+    torch.manual_seed(sum(shape))
+    a = SharedMLP(shape[1], channels, ndim=len(shape) - 2).to(DEV).train()
+    for blk in a:                                       # non-trivial affine parameters, some negative gammas
+        blk.bn.weight.data.uniform_(-1.0, 1.5)
+        blk.bn.bias.data.uniform_(-0.5, 0.5)
+    b, c = copy.deepcopy(a), copy.deepcopy(a).double()
+    x = torch.randn(shape, device=DEV) * 2 + 0.3
+    xa, xb, xc = (x.clone().requires_grad_(True), x.clone().requires_grad_(True), x.double().requires_grad_(True))
+    before = conv1x1_train.DEFERRED["layers"]
+    ya = a(xa, pool_max=pool)
+    up = torch.randn_like(ya)
+    ya.backward(up)
+    assert conv1x1_train.DEFERRED["layers"] - before == deferred
+    old, conv1x1_train.DEFER_BN = conv1x1_train.DEFER_BN, False
+    try:
+        yb = b(xb, pool_max=pool)
+        yb.backward(up)
+    finally:
+        conv1x1_train.DEFER_BN = old
+    assert conv1x1_train.DEFERRED["layers"] - before == deferred
+    yc = c(xc)                                          # torch's modules in float64
+    if pool:
+        yc = yc.max(-1)[0]
+    yc.backward(up.double())
+    _close(ya, yb, 2e-5), _close(ya, yc.float(), 1e-4)
+    _close_most(xa.grad, xb.grad, 1e-4), _close_most(xa.grad, xc.grad.float(), 2e-4)
+    for (k, p), (_, q), (_, r) in zip(a.named_parameters(), b.named_parameters(), c.named_parameters()):
+        scale = max(1.0, float(r.grad.abs().max()))
+        assert float((p.grad - q.grad).abs().max()) <= 3e-4 * scale, k          # (fp32 sums over up to 2.1 M points)
+        assert float((p.grad.double() - r.grad).abs().max()) <= 3e-4 * scale, k
+    for (k, p), (_, q), (_, r) in zip(a.named_buffers(), b.named_buffers(), c.named_buffers()):
+        _close(p.float(), q.float(), 1e-5), _close(p.float(), r.float(), 1e-5)
+
+
 def test_unsupported_inputs_are_rejected_not_silently_wrong():
     from regnet_for_3d_grasping_amd import bn_train
     bn = nn.BatchNorm1d(4).to(DEV).train()
