@@ -206,6 +206,7 @@ def _mlp_layer_kernel(d):
 
 
 KERNEL_OF = {"native_fwd": "tgemm_kernel", "native_dgrad": "tgemm_kernel", "native_wgrad": "tgemm_kernel",
+             "native_fwd_bnrelu": "tgemm_kernel", "native_wgrad_bnrelu": "tgemm_kernel",   # (the family: tgemm_kernel / tgemm_stream_kernel)
              "mlp_layer": _mlp_layer_kernel, "sa_layer1": "mlp_gemm_kernel", "sa_layer12": "mlp_gemm_kernel",
              "sa_premul_layer": "mlp_gemm_kernel<3>", "sa_chain3": "sa_chain_kernel", "fp_head_chain": "fp_head_chain_kernel", "fp_head_chain_interp": "fp_head_chain_kernel", "sa_premul_chain": "sa_premul_chain_kernel", "sa3_premul_chain": "sa3_premul_chain_kernel",
              "farthest_point_sample": "fps_kernel", "ball_query": "ball_query_kernel",

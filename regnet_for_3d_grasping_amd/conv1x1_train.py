@@ -97,8 +97,44 @@ def native_wgrad(dy, x):
     return dw
 
 
+def native_fwd_bnrelu(x, w, scale, shift, relu):
+    """Y = W . [relu](scale * x + shift) (per input channel), x (B, Ci, L) contiguous: the forward of a convolution that
+    consumes a pending training BatchNorm (csrc/tgemm.hip: tgemm_stream_kernel<.., B_AFFINE>)."""
+    from . import _lib, fused
+    B, Ci, L = x.shape
+    Co = w.shape[0]
+    y = torch.empty((B, Co, L), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib.regnet_conv1x1_fwd_bnrelu_stream_f32(w.data_ptr(), x.data_ptr(), y.data_ptr(), B, Co, Ci, L,
+                                                                 scale.data_ptr(), shift.data_ptr(), relu,
+                                                                 fused._tickets(x.device).data_ptr(), _stream(x)),
+                   "conv1x1_fwd_bnrelu")
+    return y
+
+
+def native_wgrad_bnrelu(dy, x, scale, shift, relu):
+    """dW = sum_b dY[b] . ([relu](scale * x[b] + shift))^T: the weight gradient of that convolution."""
+    from . import _lib
+    L_ = _lib.lib
+    B, Co, L = dy.shape
+    Ci = x.shape[1]
+    dw = torch.empty((Co, Ci), dtype=torch.float32, device=x.device)
+    ws_bytes = L_.regnet_conv1x1_wgrad_workspace_bytes(B, Co, Ci, L)
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=x.device) if ws_bytes else None
+    with torch.cuda.device(x.device):
+        _lib.check(L_.regnet_conv1x1_wgrad_bnrelu_f32(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), B, Co, Ci, L,
+                                                      scale.data_ptr(), shift.data_ptr(), relu,
+                                                      ws.data_ptr() if ws is not None else None, _stream(x)),
+                   "conv1x1_wgrad_bnrelu")
+    return dw
+
+
 # what bench.py --train brackets: name -> meta(args)
 TIMED_OPS = {
+    "native_fwd_bnrelu": lambda x, w, scale, shift, relu: "B%d Co%d Ci%d L%d flop%d" % (
+        x.shape[0], w.shape[0], x.shape[1], x.shape[2], 2 * x.shape[0] * w.shape[0] * x.shape[1] * x.shape[2]),
+    "native_wgrad_bnrelu": lambda dy, x, scale, shift, relu: "B%d Co%d Ci%d L%d flop%d" % (
+        dy.shape[0], dy.shape[1], x.shape[1], x.shape[2], 2 * dy.shape[0] * dy.shape[1] * x.shape[1] * x.shape[2]),
     "native_fwd": lambda x, w: "B%d Co%d Ci%d L%d flop%d" % (x.shape[0], w.shape[0], x.shape[1], x.shape[2],
                                                              2 * x.shape[0] * w.shape[0] * x.shape[1] * x.shape[2]),
     "native_dgrad": lambda w, dy: "B%d Co%d Ci%d L%d flop%d" % (dy.shape[0], w.shape[0], w.shape[1], dy.shape[2],
@@ -165,39 +201,19 @@ class _BnReluConv(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, gamma, beta, w, mean, invstd, scale, shift, relu):
-        from . import _lib, fused
-        B, Ci, L = x.shape
-        Co = w.shape[0]
         w = w.contiguous()
-        y = torch.empty((B, Co, L), dtype=torch.float32, device=x.device)
-        with torch.cuda.device(x.device):
-            _lib.check(_lib.lib.regnet_conv1x1_fwd_bnrelu_stream_f32(w.data_ptr(), x.data_ptr(), y.data_ptr(), B, Co, Ci, L,
-                                                                     scale.data_ptr(), shift.data_ptr(), relu,
-                                                                     fused._tickets(x.device).data_ptr(), _stream(x)),
-                       "conv1x1_fwd_bnrelu")
+        y = native_fwd_bnrelu(x, w, scale, shift, relu)
         ctx.save_for_backward(x, gamma, beta, w, mean, invstd, scale, shift)
         ctx.relu = relu
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        from . import _lib, bn_train
+        from . import bn_train
         x, gamma, beta, w, mean, invstd, scale, shift = ctx.saved_tensors
         dy = dy.contiguous()
-        B, Ci, L = x.shape
-        Co = w.shape[0]
         dz = native_dgrad(w, dy)
-        dw = None
-        if ctx.needs_input_grad[3]:
-            L_ = _lib.lib
-            dw = torch.empty((Co, Ci), dtype=torch.float32, device=x.device)
-            ws_bytes = L_.regnet_conv1x1_wgrad_workspace_bytes(B, Co, Ci, L)
-            ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=x.device) if ws_bytes else None
-            with torch.cuda.device(x.device):
-                _lib.check(L_.regnet_conv1x1_wgrad_bnrelu_f32(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), B, Co, Ci, L,
-                                                              scale.data_ptr(), shift.data_ptr(), ctx.relu,
-                                                              ws.data_ptr() if ws is not None else None, _stream(x)),
-                           "conv1x1_wgrad_bnrelu")
+        dw = native_wgrad_bnrelu(dy, x, scale, shift, ctx.relu) if ctx.needs_input_grad[3] else None
         dx, dgamma, dbeta = bn_train.bn_backward(x, dz, gamma, beta, mean, invstd, ctx.relu)
         return dx, dgamma, dbeta, dw, None, None, None, None, None
 

@@ -18,6 +18,8 @@
 
 #define BN_T 256
 #define BN_CHUNK 8192   // elements of one (b, c) row per workgroup: 256 threads x 8 x float4
+#define BN_STATS_CHUNK 32768   // the statistics pass: a workgroup's reduction + two atomics cost as much as reading 32 KB -- measured
+                               // 2.6 TB/s with 8 192-element chunks where the apply pass streams at 5.6
 
 __device__ __forceinline__ float bn_value(float x, float mean, float invstd, float gamma, float beta) {
   return gamma * (x - mean) * invstd + beta;   // association of torch's batch_norm_transform_input
@@ -51,18 +53,34 @@ __global__ __launch_bounds__(BN_T) void bn_stats_kernel(const float* __restrict_
                                                         double* __restrict__ sums) {
   const int c = blockIdx.y;
   const float* row = x + ((int64_t)blockIdx.z * C + c) * L;
-  const int64_t beg = (int64_t)blockIdx.x * BN_CHUNK, end = min(L, beg + BN_CHUNK);
-  float s = 0.f, q = 0.f;
+  const int64_t beg = (int64_t)blockIdx.x * BN_STATS_CHUNK, end = min(L, beg + BN_STATS_CHUNK);
+  double s = 0.0, q = 0.0;          // fp32 over 8 float4 (32 values) at a time, fp64 across them
   if ((L & 3) == 0) {
-    for (int64_t i = beg + threadIdx.x * 4; i < end; i += BN_T * 4) {
-      const float4 v = *reinterpret_cast<const float4*>(row + i);
-      s += (v.x + v.y) + (v.z + v.w);
-      q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    for (int64_t i0 = beg + threadIdx.x * 4; i0 < end; i0 += BN_T * 4 * 8) {
+      float s32 = 0.f, q32 = 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int64_t i = i0 + (int64_t)u * BN_T * 4;
+        if (i < end) {
+          const float4 v = *reinterpret_cast<const float4*>(row + i);
+          s32 += (v.x + v.y) + (v.z + v.w);
+          q32 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+        }
+      }
+      s += (double)s32;
+      q += (double)q32;
     }
   } else {
-    for (int64_t i = beg + threadIdx.x; i < end; i += BN_T) { const float v = row[i]; s += v; q += v * v; }
+    float s32 = 0.f, q32 = 0.f;
+    int n = 0;
+    for (int64_t i = beg + threadIdx.x; i < end; i += BN_T) {
+      const float v = row[i];
+      s32 += v; q32 += v * v;
+      if (++n == 32) { s += (double)s32; q += (double)q32; s32 = q32 = 0.f; n = 0; }
+    }
+    s += (double)s32; q += (double)q32;
   }
-  block_accumulate((double)s, (double)q, sums + 2 * c);
+  block_accumulate(s, q, sums + 2 * c);
 }
 
 // one thread per channel: batch mean / inverse std (saved for the backward), running statistics (momentum update with
@@ -300,7 +318,8 @@ extern "C" int regnet_bn_relu_train_fwd_f32(const float* x, int64_t B, int64_t C
   hipError_t e = hipMemsetAsync(sums, 0, regnet_bn_workspace_bytes(C), st);
   if (e != hipSuccess) return (int)e;
   dim3 grid((unsigned)((L + BN_CHUNK - 1) / BN_CHUNK), (unsigned)C, (unsigned)B);
-  hipLaunchKernelGGL(bn_stats_kernel, grid, dim3(BN_T), 0, st, x, (int)C, L, sums);
+  hipLaunchKernelGGL(bn_stats_kernel, dim3((unsigned)((L + BN_STATS_CHUNK - 1) / BN_STATS_CHUNK), (unsigned)C, (unsigned)B), dim3(BN_T), 0, st,
+                     x, (int)C, L, sums);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((C + 127) / 128)), dim3(128), 0, st, sums, (double)B * (double)L,
                      eps, momentum, (int)C, running_mean, running_var, save_mean, save_invstd);
   if (pool_group)
@@ -361,7 +380,8 @@ extern "C" int regnet_bn_train_stats_f32(const float* x, int64_t B, int64_t C, i
   hipError_t e = hipMemsetAsync(sums, 0, regnet_bn_workspace_bytes(C), st);
   if (e != hipSuccess) return (int)e;
   dim3 grid((unsigned)((L + BN_CHUNK - 1) / BN_CHUNK), (unsigned)C, (unsigned)B);
-  hipLaunchKernelGGL(bn_stats_kernel, grid, dim3(BN_T), 0, st, x, (int)C, L, sums);
+  hipLaunchKernelGGL(bn_stats_kernel, dim3((unsigned)((L + BN_STATS_CHUNK - 1) / BN_STATS_CHUNK), (unsigned)C, (unsigned)B), dim3(BN_T), 0, st,
+                     x, (int)C, L, sums);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((C + 127) / 128)), dim3(128), 0, st, sums, (double)B * (double)L,
                      eps, momentum, (int)C, running_mean, running_var, save_mean, save_invstd, gamma, beta, scale, shift);
   REGNET_LAUNCH_CHECK();

@@ -133,6 +133,10 @@ __global__ __launch_bounds__(TG_THREADS, 4) void tgemm_kernel(const TgArgs p) {
       if (r >= p.N) r = 0;
       bsc[ni] = p.bscale[r]; bsh[ni] = p.bshift[r];
     }
+    // the values must have arrived HERE: left to the compiler, its wait for them (vmcnt(0)) lands at their first use inside the
+    // k loop and drains the ring's loads on every k-tile
+#pragma unroll
+    for (int ni = 0; ni < TNI; ++ni) asm volatile("" : "+v"(bsc[ni]), "+v"(bsh[ni]));
   }
   const unsigned smem_base = (unsigned)(uintptr_t)smem;
 #define TG_ISSUE(KT_, STAGE_)                                                                         \
@@ -231,6 +235,12 @@ __global__ __launch_bounds__(TG_THREADS, 4) void tgemm_kernel(const TgArgs p) {
   }
 }
 
+// the same with a wave-uniform base (SGPR pair) and a 32-bit per-lane byte offset: half the address registers
+__device__ __forceinline__ void tg_glds16_s(const float* sbase, unsigned voff, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
 template <int N> __device__ __forceinline__ void tg_wait() { asm volatile("s_waitcnt vmcnt(%0)" :: "i"(N) : "memory"); }
 // *p += 1, old value -> the returned register ONCE A LATER COUNTED WAIT HAS PASSED IT (no wait here: the compiler's own
 // vmcnt(0) in front of an atomic's result would also drain the k-tile loads in flight)
@@ -271,16 +281,18 @@ __global__ __launch_bounds__(TG_THREADS, 4) void tgemm_stream_kernel(const TgArg
 
   // ---- LDS-DMA pieces of this wave (as tgemm_kernel: pieces 0..7 = A, 8..23 = B; piece = 1 KiB): tile-independent parts
   unsigned dst[NPIECE];
-  long long kstep[NPIECE];
+  unsigned kstep[NPIECE];           // bytes per k-tile (a batch's operand is < 4 GiB: launcher)
 #pragma unroll
   for (int j = 0; j < NPIECE; ++j) {
     const int piece = wave + 8 * j;
     const bool isA = piece < 8;
     const int q = isA ? piece : piece - 8;
     dst[j] = (unsigned)((isA ? 0 : TG_BM * TG_BK * 4) + q * 1024);
-    kstep[j] = isA ? (A_KMAJ ? (long long)TG_BK * p.lda : (long long)TG_BK) : (long long)TG_BK * p.ldb;
+    kstep[j] = 4u * (unsigned)(isA ? (A_KMAJ ? TG_BK * p.lda : (long long)TG_BK) : TG_BK * p.ldb);
   }
-  const float* gp[NPIECE];          // issue cursor: this lane's source of the cursor's k-tile, per piece
+  unsigned gp[NPIECE];              // issue cursor: this lane's byte offset of the cursor's k-tile from its operand's batch base
+  const float* baseA = p.A;         // wave-uniform bases of the cursor's batch
+  const float* baseB = p.B;
   int issue_kt = 0;                 // cursor = k-tile issue_kt of tile issue_t (-1: no tile left)
   long long issue_t = bid;
   int drawn = 0;                    // tiles drawn so far; a draw is pending while issue_t == -2
@@ -289,8 +301,8 @@ __global__ __launch_bounds__(TG_THREADS, 4) void tgemm_stream_kernel(const TgArg
     const int batch = (int)(t / tiles), r = (int)(t - (long long)batch * tiles);
     const int tn = r / p.tiles_m, tm = r - tn * p.tiles_m;
     const int m0 = tm * TG_BM, n0 = tn * TG_BN;
-    const float* Ab = p.A + batch * p.a_batch;
-    const float* Bb = p.B + batch * p.b_batch;
+    baseA = p.A + batch * p.a_batch;
+    baseB = p.B + batch * p.b_batch;
 #pragma unroll
     for (int j = 0; j < NPIECE; ++j) {
       const int piece = wave + 8 * j;
@@ -299,16 +311,16 @@ __global__ __launch_bounds__(TG_THREADS, 4) void tgemm_stream_kernel(const TgArg
         if (A_KMAJ) {
           int m = m0 + 4 * (lane & 31);
           if (m >= p.M) m = 0;
-          gp[j] = Ab + (long long)(2 * q + (lane >> 5)) * p.lda + m;
+          gp[j] = 4u * (unsigned)((2 * q + (lane >> 5)) * (int)p.lda + m);
         } else {
           int r2 = m0 + 16 * q + (lane >> 2);
           if (r2 >= p.M) r2 = 0;
-          gp[j] = Ab + (long long)r2 * p.lda + 4 * ((lane & 3) ^ ((lane >> 4) & 3));
+          gp[j] = 4u * (unsigned)(r2 * (int)p.lda + 4 * ((lane & 3) ^ ((lane >> 4) & 3)));
         }
       } else {
         int n2 = n0 + 4 * lane;
         if (n2 >= p.N) n2 = 0;
-        gp[j] = Bb + (long long)q * p.ldb + n2;
+        gp[j] = 4u * ((unsigned)q * (unsigned)p.ldb + (unsigned)n2);
       }
     }
   };
@@ -320,7 +332,7 @@ __global__ __launch_bounds__(TG_THREADS, 4) void tgemm_stream_kernel(const TgArg
     if (last && tid == 0) ticket_reg = tg_ticket_nowait(p.ticket);
 #pragma unroll
     for (int j = 0; j < NPIECE; ++j) {
-      tg_glds16(gp[j], smem_base + (unsigned)(stage_ * TG_STAGE_FLOATS * 4) + dst[j]);
+      tg_glds16_s(wave + 8 * j < 8 ? baseA : baseB, gp[j], smem_base + (unsigned)(stage_ * TG_STAGE_FLOATS * 4) + dst[j]);
       gp[j] += kstep[j];
     }
     if (last) { issue_kt = 0; issue_t = -2; } else ++issue_kt;
@@ -332,7 +344,8 @@ __global__ __launch_bounds__(TG_THREADS, 4) void tgemm_stream_kernel(const TgArg
     }
   };
   auto take_drawn = [&]() {          // after that barrier
-    const long long t = *reinterpret_cast<volatile long long*>(&s_next[drawn & 1]);
+    const volatile int* word = reinterpret_cast<volatile int*>(&s_next[drawn & 1]);
+    const long long t = ((long long)__builtin_amdgcn_readfirstlane(word[1]) << 32) | (unsigned)__builtin_amdgcn_readfirstlane(word[0]);
     ++drawn;
     issue_t = t < total ? t : -1;
     if (issue_t >= 0) set_issue_tile(issue_t);
@@ -484,6 +497,8 @@ static int tg_launch_stream(TgArgs a, long long batches, int32_t* ticket, hipStr
   const long long total = (long long)a.tiles_m * a.tiles_n * batches;
   if (total <= 0) return REGNET_OK;
   if (total >= (1ll << 31) - 4096 || batches >= (1ll << 31)) return REGNET_ERR_UNSUPPORTED;
+  if ((long long)a.K * a.ldb * 4 >= (1ll << 32) || (long long)(a.M > a.K ? a.M : a.K) * a.lda * 4 >= (1ll << 32))
+    return REGNET_ERR_UNSUPPORTED;       // 32-bit byte offsets inside one batch's operands
   static int slots = 0;                  // two workgroups per CU (73.7 KB of LDS each)
   if (slots == 0) {
     int dev = 0, cus = 0;
