@@ -285,6 +285,28 @@ int regnet_rowsum_neg_f32(const float* x, int64_t rows, int64_t K, float* out, v
 int regnet_heads_chain_f32(const float* x, int64_t ldx, int64_t Kx, int64_t n, const int64_t* descr, int64_t layers,
                            float* out_a, int64_t lda, float* out_b, int64_t ldb, void* stream);
 
+/* The same heads in TRAINING mode, one layer per call (pointnet2.py:174-188, :240-253: nn.Conv1d(K, N, 1) with bias ->
+ * nn.BatchNorm1d(N) on batch statistics -> [ReLU], on the R labelled centres / valid crops of the iteration): six launches
+ * per layer forward and seven backward through torch, on a stream the host paces.
+ * regnet_head_layer_train_supported: 2 <= R <= 1024, K a multiple of 64, N >= 1.
+ * regnet_head_layer_train_fwd_f32: X (R, K) rows with stride ldx (multiple of 4; X and W 16-byte aligned), W (N, K), bias
+ *   (N) or NULL -> xhat (R, N) the normalised pre-affine activation, Y (R, N) = [relu](gamma * xhat + beta), save_invstd (N);
+ *   running_mean / running_var (both or neither) are updated in place with `momentum` (running_var from the unbiased
+ *   variance, running_mean from mean(X . W^T) + bias), *num_batches_tracked (device int64, may be NULL) is incremented.
+ * regnet_head_layer_train_bwd_f32: dY (R, N) with row stride lddy = the gradient of Y; Y is read for the ReLU mask only
+ *   (may be NULL when relu == 0) -> dZ (R, N) the gradient of the convolution's output (workspace of the call), dW (N, K),
+ *   dbias (N, may be NULL), dgamma (N), dbeta (N), and, when dX != NULL, dX (R, K) with row stride lddx = dZ . W, ADDED to
+ *   its contents when accumulate_dx != 0 (the second branch of a fork).  Deterministic: fixed summation orders. */
+int regnet_head_layer_train_supported(int64_t R, int64_t K, int64_t N);
+int regnet_head_layer_train_fwd_f32(const float* X, int64_t ldx, const float* W, const float* bias, const float* gamma,
+                                    const float* beta, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                                    float momentum, float eps, int64_t R, int64_t K, int64_t N, int relu, float* xhat, float* Y,
+                                    float* save_invstd, void* stream);
+int regnet_head_layer_train_bwd_f32(const float* dY, int64_t lddy, const float* Y, const float* xhat, const float* gamma,
+                                    const float* save_invstd, const float* X, int64_t ldx, const float* W, int64_t R, int64_t K,
+                                    int64_t N, int relu, float* dZ, float* dW, float* dbias, float* dgamma, float* dbeta,
+                                    float* dX, int64_t lddx, int accumulate_dx, void* stream);
+
 /* Decodes of the two grasp heads WITHOUT labels (inference), one launch each instead of ~25 / ~12 small tensor ops.
  * regnet_stage2_decode_f32 (gripper_region_network.py:69-90, `ground is None`): cls (n,A), reg (n,A,C >= 7), centre rows
  * (n, centre_ld >= 3), tmpl (A,4) = the anchors' [r | theta] -> out (n,C): the arg-max anchor's regression turned into

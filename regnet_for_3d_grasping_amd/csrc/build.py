@@ -24,6 +24,7 @@ SOURCES = [
     ("sa_chain.hip", ["-fno-slp-vectorize"]),   # SLP turns the layer-1 FMAs into v_pk_mul + separate adds
     ("rowchain.hip", ["-fno-slp-vectorize"]),
     ("heads.hip", []),
+    ("heads_train.hip", []),
     ("losses.hip", ["-ffp-contract=off"]),
     ("tgemm.hip", []),
     ("bn_train.hip", []),

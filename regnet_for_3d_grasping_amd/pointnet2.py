@@ -240,8 +240,15 @@ class PointNet2TwoStage(nn.Module):
         mp_x = xyz if pooled else self.mp1(xyz)
         if feature is not None:
             mp_x = torch.cat((mp_x, feature.view(feature.shape[0], feature.shape[1], 1)), dim=1)
-        from . import fused
+        from . import fused, heads_train
         self.reg_is_raw = False
+        if self.training and mp_x.is_cuda:
+            layers = heads_train._layers_twostage(self)
+            if heads_train.supported(layers, mp_x):      # training on the GPU: the head as one autograd node (csrc/heads_train.hip)
+                x_cls, x_reg = heads_train.twostage(self, mp_x)
+                x_reg = x_reg.view(x_reg.shape[0], -1, self.k_reg_no_anchor)
+                x_reg[:, :, 7:] = self.sigmod(x_reg[:, :, 7:])
+                return x_cls, x_reg, mp_x
         if fused.usable(self, mp_x) and mp_x.shape[1] % 4 == 0:
             x_cls, x_reg = fused.twostage_forward(self, mp_x, raw_reg=raw_reg)
             self.reg_is_raw = bool(raw_reg)
@@ -285,7 +292,11 @@ class PointNet2Refine(nn.Module):
         x = gripper_feature if pooled else self.mp1(gripper_feature)
         if group_feature is not None:
             x = torch.cat((x, group_feature.view(group_feature.shape[0], group_feature.shape[1], 1)), dim=1)
-        from . import fused
+        from . import fused, heads_train
+        if self.training and x.is_cuda:
+            layers = heads_train._layers_refine(self)
+            if heads_train.supported(layers, x):
+                return heads_train.refine(self, x)
         if fused.usable(self, x) and x.shape[1] % 4 == 0:
             return fused.refine_forward(self, x)
         x = _head_layer(self.conv_formal, self.bn_formal, x, True)

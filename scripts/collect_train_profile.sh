@@ -12,5 +12,7 @@ rocprofv3 --kernel-trace --output-format csv -d $OUT/prof_train -o train -- pyth
 cd $REPO
 python scripts/trace_tail.py $OUT/prof_train 600 60 > $OUT/train_steady_state_kernels.txt
 python scripts/trace_gaps.py $OUT/prof_train 600 40 > $OUT/train_steady_state_gaps.txt
+# keep the raw kernel trace (compact: start, end, stream/queue, grid, kernel name) for offline analysis
+python scripts/trace_compact.py $OUT/prof_train $OUT/train_trace_compact.csv.gz
 rm -rf $OUT/prof_train
 head -12 $OUT/train_steady_state_kernels.txt; cat $OUT/train_steady_state_gaps.txt

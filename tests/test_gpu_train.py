@@ -201,7 +201,8 @@ def test_prefetched_geometry_plan_gives_the_same_training_forward():
     assert all(not t.requires_grad for t in handle["tensors"])
     net.load_state_dict(stats, strict=False)
     feat1, score1, loss1 = net(pc, target, plan=plan)
-    assert torch.equal(score0, score1) and torch.equal(feat0, feat1) and torch.equal(loss0, loss1)
+    for what, a, b in (("feature", feat0, feat1), ("score", score0, score1), ("loss", loss0, loss1)):
+        assert torch.equal(a, b), (what, float((a - b).abs().max()), int((a != b).sum()), a.numel())
     loss1.backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all()
                for k, p in net.named_parameters() if "sa_modules" in k or "fp_modules" in k)
