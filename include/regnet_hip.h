@@ -272,6 +272,13 @@ int regnet_grasp_antipodal_stats_f32(const float* points, int64_t pn, int64_t pc
  * 4..256): the gradient of the per-centre term of a pre-multiplied first layer (dV = -sum over the K neighbours of dY). */
 int regnet_gather_max_arg_f32(const float* feat, int64_t num_rows, int64_t F, const int64_t* rows, int64_t R, int64_t G,
                               float* out, int64_t* arg, void* stream);
+/* regnet_scatter_max_grad_f32: the backward of regnet_gather_max_arg_f32 -- grad[arg[r][f]][f] += dy[r][f] for dy, arg (R, F)
+ * (arg < 0: nothing), by float atomics.  Row `row` is scene b = row / scene_rows, point n = row % scene_rows and lands at
+ * grad + b * batch_stride + n * row_stride + f * ch_stride: (scene_rows = total rows, row_stride F, ch_stride 1) for a
+ * (rows, F) matrix, (scene_rows N, batch_stride F * N, row_stride 1, ch_stride N) for the channel-first (B, F, N) gradient
+ * of the feature map itself.  grad is ADDED to (zero it, or hand in a gradient that is to receive this one).           */
+int regnet_scatter_max_grad_f32(const float* dy, const int64_t* arg, int64_t R, int64_t F, int64_t scene_rows,
+                                int64_t batch_stride, int64_t row_stride, int64_t ch_stride, float* grad, void* stream);
 int regnet_rowsum_neg_f32(const float* x, int64_t rows, int64_t K, float* out, void* stream);
 
 /* regnet_heads_chain_f32: a small tree of conv(1x1) + folded eval BatchNorm (+ ReLU) layers over FEW rows in one launch -- the
@@ -333,6 +340,16 @@ int regnet_refine_decode_f32(const float* grasp, int64_t grasp_ld, const float* 
  * regnet_refine_loss_rows_f32: grasp rows (m, ld), cls (m,2), reg (m,10), label rows -> final_grasp (m,10), flags (3,m) uint8
  *   [class 1 | class 1 and score kept | label-positive], terms (m,20) = [4 regression terms of positive rows | 3 x 4
  *   monitoring terms | 4 confusion counts], dreg (m,10) = SL1' of the positive rows' residuals (unscaled).            */
+/* regnet_label_match_f32: the training labels of the centres (dataset_utils/get_regiondataset.py:45-134, :136-199 with
+ * use_theta): packed (B, Gmax, 19) = the scenes' ground-truth grasps padded to the longest record [16 row-major entries of the
+ * 4x4 frame | score | antipodal score | centre score], gcount (B) their counts, centre rows at centre + b * centre_sb + c *
+ * centre_sn (xyz first) -> out (B, Nc, 10) = [grasp centre | closing axis with x >= 0 | angle in (-pi, pi] | 3 scores] of the
+ * grasp whose contact point is nearest (the reference's fp32 expansion compared as float64, first minimum), or the reference's
+ * filler (-1, axis +1) when that squared distance exceeds max_sq; wide_row (B * Nc) = 1 where the row's antipodal score is not
+ * -1 (the reference returns 8 channels when none is).  Replaces ~60 tensor launches. */
+int regnet_label_match_f32(const float* packed, const int32_t* gcount, int64_t Gmax, const float* centre, int64_t centre_sb,
+                           int64_t centre_sn, int64_t B, int64_t Nc, float depth, double max_sq, float* out,
+                           int32_t* wide_row, void* stream);
 int regnet_stage2_loss_rows_f32(const float* cls, const float* reg, int64_t A, int64_t C, const float* centre,
                                 int64_t centre_ld, const float* tmpl, const float* label, int64_t label_ld, float radius,
                                 const float* weights4, const int64_t* rows, int64_t m, float* next_grasp, int32_t* pick,
@@ -541,6 +558,11 @@ int regnet_conv1x1_fwd_stream_f32(const float* W, const float* X, float* Y, int6
                                   int32_t* ticket, void* stream);
 int regnet_conv1x1_dgrad_stream_f32(const float* W, const float* dY, float* dX, int64_t B, int64_t Co, int64_t Ci, int64_t L,
                                     int32_t* ticket, void* stream);
+/* regnet_conv1x1_stream_reserve_slots: the persistent kernels above hold every CU's register file for a whole launch (two
+ * workgroups per CU); `slots` of those 2 x CUs workgroup slots stay empty from now on (at most half of them; negative: query
+ * only), so that small kernels of ANOTHER stream -- the region stage beside the segmentation head's backward -- find CUs to
+ * start on instead of advancing one launch per persistent launch.  Process-wide; returns the previous value.            */
+int regnet_conv1x1_stream_reserve_slots(int slots);
 /* ..._bnrelu: the convolution's input is [relu](scale[i] * X[., i, .] + shift[i]) -- a training BatchNorm (+ ReLU) given as
  * its per-channel affine (regnet_bn_train_stats_f32) -- applied to the operand fragments inside the contraction; X itself
  * is the BatchNorm's INPUT.  regnet_conv1x1_bnrelu_supported: train_supported, Ci <= 512 (the affine table lives in LDS),

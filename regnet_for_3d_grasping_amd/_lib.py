@@ -44,6 +44,7 @@ SIGNATURES = {
     "regnet_gripper_frame_f32": (_int, [_vp, _i64, _i64, _vp, _vp, _vp]),
     "regnet_stage2_loss_rows_f32": (_int, [_vp, _vp, _i64, _i64, _vp, _i64, _vp, _vp, _i64, _f32, _vp, _vp, _i64, _vp, _vp, _vp,
                                            _vp, _vp, _vp, _vp]),
+    "regnet_label_match_f32": (_int, [_vp, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _f32, _f64, _vp, _vp, _vp]),
     "regnet_ce_rows_f32": (_int, [_vp, _i64, _vp, _vp, _vp, _i64, _f32, _vp, _vp, _vp]),
     "regnet_refine_loss_rows_f32": (_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _f32, _f32, _i64, _vp, _vp, _vp, _vp, _vp]),
     "regnet_heads_chain_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
@@ -56,6 +57,7 @@ SIGNATURES = {
     "regnet_refine_decode_f32": (_int, [_vp, _i64, _vp, _vp, _i64, _f32, _f32, _i64, _vp, _vp, _vp]),
     "regnet_crop_pick": (_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _vp, _vp, _vp]),
     "regnet_gather_max_arg_f32": (_int, [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _vp]),
+    "regnet_scatter_max_grad_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp]),
     "regnet_rowsum_neg_f32": (_int, [_vp, _i64, _i64, _vp, _vp]),
     "regnet_mlp_layer_f32": (_int, [_vp, _i64, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _int, _int, _vp]),
     "regnet_mlp_splitk_workspace_bytes": (_i64, [_i64, _i64, _i64]),
@@ -107,6 +109,7 @@ SIGNATURES = {
     "regnet_conv1x1_dgrad_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp]),
     "regnet_conv1x1_fwd_stream_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
     "regnet_conv1x1_dgrad_stream_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
+    "regnet_conv1x1_stream_reserve_slots": (_int, [_int]),
     "regnet_conv1x1_bnrelu_supported": (_int, [_i64, _i64, _i64]),
     "regnet_conv1x1_fwd_bnrelu_stream_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _int, _vp, _vp]),
     "regnet_conv1x1_wgrad_bnrelu_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _int, _vp, _vp]),

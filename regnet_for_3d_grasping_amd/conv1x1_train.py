@@ -25,6 +25,13 @@ DEFER_BN = True
 DEFERRED = {"layers": 0}     # convolutions that consumed a pending BatchNorm since import (tests, bench)
 
 
+def reserve_stream_slots(slots):
+    """Leave ``slots`` of the persistent kernels' 2 x CUs workgroup slots empty from now on (csrc/tgemm.hip); returns the
+    previous value.  ``train_step`` reserves some while the segmentation head's backward runs beside the region stage."""
+    from . import _lib
+    return int(_lib.lib.regnet_conv1x1_stream_reserve_slots(int(slots)))
+
+
 def _native_ok(B, Co, Ci, L, wgrad=False):
     if not NATIVE:
         return False

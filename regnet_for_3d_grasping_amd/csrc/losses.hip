@@ -248,3 +248,89 @@ extern "C" int regnet_refine_loss_rows_f32(const float* grasp, int64_t grasp_ld,
   REGNET_LAUNCH_CHECK();
   return REGNET_OK;
 }
+
+
+// Training labels of the centres (dataset_utils/get_regiondataset.py:45-134 + :136-199, `use_theta`): every centre is matched to
+// the ground-truth grasp whose contact point is nearest -- squared distance by the reference's expansion -2 a.b + |b|^2 + |a|^2 in
+// fp32, compared as float64, first minimum -- kept when that distance is <= max_sq, and the grasp's 4x4 frame [x | y | z | c] is
+// re-expressed as (c, y with y_x >= 0, theta = atan2(x_z, z_z) mirrored to pi - theta when y was flipped and wrapped to (-pi, pi]
+// by the reference's four steps, score, antipodal score, centre score).  Centres without a grasp get the reference's filler:
+// -1 everywhere except the axis, which its sign flip turns into +1.  ~60 small tensor launches (two of them 0.2 / 0.4 ms long on
+// 128 workgroups) of the host-paced stretch of the training iteration as one: a wave per centre, lanes stride over the grasps.
+// packed: (B, Gmax, 19) = 16 row-major frame entries | score | antipodal | centre score; gcount (B): grasps of the scene.
+__global__ __launch_bounds__(256) void label_match_kernel(const float* __restrict__ packed, const int32_t* __restrict__ gcount, int Gmax,
+                                                          const float* __restrict__ centre, int64_t centre_sb, int64_t centre_sn,
+                                                          int B, int Nc, float depth, double max_sq, float* __restrict__ out,
+                                                          int32_t* __restrict__ wide_row) {
+  const int lane = threadIdx.x & 63;
+  const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (w >= B * Nc) return;
+  const int b = w / Nc, c = w - b * Nc;
+  const float* a = centre + b * centre_sb + c * centre_sn;
+  const float a0 = a[0], a1 = a[1], a2 = a[2];
+  const float aa = (a0 * a0 + a1 * a1) + a2 * a2;
+  const float* rec = packed + (int64_t)b * Gmax * 19;
+  const int G = gcount[b];
+  double best = __builtin_huge_val();
+  int besti = 0x7fffffff;
+  for (int g = lane; g < G; g += 64) {
+    const float* f = rec + (int64_t)g * 19;
+    float cp[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float t = f[4 * k] * depth;              // approach_k * depth
+      cp[k] = (f[4 * k + 3] + t) - t;                // the reference shifts the contact point along the approach and back
+    }
+    const float dot = (a0 * cp[0] + a1 * cp[1]) + a2 * cp[2];
+    const float bb = (cp[0] * cp[0] + cp[1] * cp[1]) + cp[2] * cp[2];
+    float d = -2.f * dot;
+    d = d + bb;
+    d = d + aa;
+    const double dd = (double)d;
+    if (dd < best) { best = dd; besti = g; }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const double ob = __shfl_xor(best, off);
+    const int oi = __shfl_xor(besti, off);
+    if (ob < best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+  }
+  if (lane != 0) return;
+  float* o = out + (int64_t)w * 10;
+  const bool has = G > 0 && best <= max_sq;
+  float fx[3], fy[3], fz[3], fc[3], sc[3];
+  if (has) {
+    const float* f = rec + (int64_t)besti * 19;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { fx[k] = f[4 * k]; fy[k] = f[4 * k + 1]; fz[k] = f[4 * k + 2]; fc[k] = f[4 * k + 3]; sc[k] = f[16 + k]; }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) fx[k] = fy[k] = fz[k] = fc[k] = sc[k] = -1.f;
+  }
+  const float pi = 3.14159265358979323846f, two_pi = 6.28318530717958647692f;
+  const bool missing = fx[0] == -1.f && fx[1] == -1.f && fx[2] == -1.f;
+  float th = atan2f(fx[2], fz[2]);
+  const bool flip = fy[0] < 0.f;
+  if (flip) th = pi - th;
+  if (th >= two_pi) th = th - two_pi;
+  if (th <= -two_pi) th = th + two_pi;
+  if (th > pi) th = th - two_pi;
+  if (th <= -pi) th = th + two_pi;
+  if (missing) th = -1.f;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { o[k] = fc[k]; o[3 + k] = flip ? -fy[k] : fy[k]; o[7 + k] = sc[k]; }
+  o[6] = th;
+  wide_row[w] = sc[1] != -1.f ? 1 : 0;
+}
+
+extern "C" int regnet_label_match_f32(const float* packed, const int32_t* gcount, int64_t Gmax, const float* centre,
+                                      int64_t centre_sb, int64_t centre_sn, int64_t B, int64_t Nc, float depth, double max_sq,
+                                      float* out, int32_t* wide_row, void* stream) {
+  if (B < 0 || Nc < 0 || Gmax < 0) return REGNET_ERR_SHAPE;
+  if (B * Nc == 0) return REGNET_OK;
+  if (!packed || !gcount || !centre || !out || !wide_row) return REGNET_ERR_NULL;
+  hipLaunchKernelGGL(label_match_kernel, dim3((unsigned)((B * Nc + 3) / 4)), dim3(256), 0, as_stream(stream), packed, gcount,
+                     (int)Gmax, centre, centre_sb, centre_sn, (int)B, (int)Nc, depth, max_sq, out, wide_row);
+  REGNET_LAUNCH_CHECK();
+  return REGNET_OK;
+}

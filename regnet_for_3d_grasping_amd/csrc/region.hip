@@ -602,6 +602,38 @@ extern "C" int regnet_gather_max_arg_f32(const float* feat, int64_t num_rows, in
   return REGNET_OK;
 }
 
+// Backward of gather_max_arg_kernel: grad[arg[r][f]][f] += dy[r][f] (rows that gave a maximum; arg < 0: an empty group).  The
+// destination is addressed as row (scene b = row / scene_rows, point n = row % scene_rows) -> b * batch_stride + n * row_stride
+// + f * ch_stride, so the same kernel adds into a (rows, F) matrix (row_stride F, ch_stride 1) or straight into the
+// channel-first (B, F, N) gradient of the feature map (batch_stride F N, row_stride 1, ch_stride N) -- no (rows, F) gradient,
+// no transpose of it.  R x F float atomics (a few hundred thousand): groups of neighbouring centres share points.
+__global__ __launch_bounds__(256) void scatter_max_grad_kernel(const float* __restrict__ dy, const int64_t* __restrict__ arg,
+                                                              long long total, int F, long long scene_rows,
+                                                              long long batch_stride, long long row_stride,
+                                                              long long ch_stride, float* __restrict__ grad) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const long long row = arg[i];
+  if (row < 0) return;
+  const int f = (int)(i % F);
+  const long long b = row / scene_rows, n = row - b * scene_rows;
+  unsafeAtomicAdd(grad + b * batch_stride + n * row_stride + (long long)f * ch_stride, dy[i]);
+}
+
+extern "C" int regnet_scatter_max_grad_f32(const float* dy, const int64_t* arg, int64_t R, int64_t F, int64_t scene_rows,
+                                           int64_t batch_stride, int64_t row_stride, int64_t ch_stride, float* grad,
+                                           void* stream) {
+  if (R < 0 || F < 0 || scene_rows <= 0) return REGNET_ERR_SHAPE;
+  if (R == 0 || F == 0) return REGNET_OK;
+  if (!dy || !arg || !grad) return REGNET_ERR_NULL;
+  const long long total = (long long)R * F, blocks = (total + 255) / 256;
+  if (blocks >= (1ll << 31) || F >= (1ll << 31)) return REGNET_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(scatter_max_grad_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), dy, arg, total, (int)F,
+                     (long long)scene_rows, (long long)batch_stride, (long long)row_stride, (long long)ch_stride, grad);
+  REGNET_LAUNCH_CHECK();
+  return REGNET_OK;
+}
+
 // out[r] = -(x[r][0] + ... + x[r][K-1]): the gradient of the per-centre term V of a pre-multiplied first layer
 // (pn2_utils/modules.py: Y = U[nbr] - V, so dV = -sum over the K neighbours of dY).  One wave per 64 / K ... rows of K
 // contiguous floats; torch's own `neg` + 4-D `sum` took 0.78 ms for the level-2 block's 537 MB gradient (0.7 TB/s).

@@ -488,6 +488,15 @@ static int tg_launch(TgArgs a, long long batches, hipStream_t st) {
   return REGNET_OK;
 }
 
+// Workgroup slots the persistent kernel leaves EMPTY (of its two per CU): its workgroups fill the register file and 147 of the
+// 160 KB of LDS of a CU for the whole launch, so a small kernel of another stream can only start where a slot was never taken.
+static int tg_reserved_slots = 0;
+extern "C" int regnet_conv1x1_stream_reserve_slots(int slots) {
+  const int before = tg_reserved_slots;
+  if (slots >= 0) tg_reserved_slots = slots;
+  return before;
+}
+
 template <bool A_KMAJ, bool B_AFFINE = false>
 static int tg_launch_stream(TgArgs a, long long batches, int32_t* ticket, hipStream_t st) {
   a.tiles_m = (a.M + TG_BM - 1) / TG_BM;
@@ -506,7 +515,8 @@ static int tg_launch_stream(TgArgs a, long long batches, int32_t* ticket, hipStr
       cus = 256;
     slots = 2 * cus;
   }
-  const unsigned grid = (unsigned)(total < slots ? total : slots);
+  const long long open_slots = slots - tg_reserved_slots > slots / 2 ? slots - tg_reserved_slots : slots / 2;
+  const unsigned grid = (unsigned)(total < open_slots ? total : open_slots);
   hipLaunchKernelGGL((tgemm_stream_kernel<A_KMAJ, B_AFFINE>), dim3(grid), dim3(TG_THREADS), 0, st, a);
   REGNET_LAUNCH_CHECK();
   return REGNET_OK;

@@ -29,9 +29,10 @@ def get_grasp_allobj(pc, predict_score, params, data_paths, use_theta=True):
     (center_num, score_thre, group_num, r_time_group, group_num_more, r_time_group_more,
      width, height, depth) = params
     center_pc, center_pc_index = _select_score_center(pc, predict_score, center_num, score_thre)
-    if pc.is_cuda and (DEVICE_DRAWS or pc.shape[0] * pc.shape[1] > BATCHED_SEARCH_MAX_POINTS):
-        # (large batches are throughput-bound: two candidate searches back to back at the start of the stage take CUs from the
-        # next batch's first chain kernel -- same step time, but that launch read 4 % longer; they keep one search per group)
+    if pc.is_cuda and (DEVICE_DRAWS or (pc.shape[0] * pc.shape[1] > BATCHED_SEARCH_MAX_POINTS and len(data_paths) == 0)):
+        # (large inference batches are throughput-bound: two candidate searches back to back at the start of the stage take CUs
+        # from the next batch's first chain kernel -- same step time, but that launch read 4 % longer; they keep one search per
+        # group.  With labels -- a training iteration -- the stage is the critical path of the host: one read, whatever the size)
         pc_group_index, pc_group = _get_group_pc(pc, center_pc, center_pc_index, group_num, width, height, depth,
                                                  r_time_group)
         pc_group_more_index, pc_group_more = _get_group_pc(pc, center_pc, center_pc_index, group_num_more, width,
@@ -55,6 +56,7 @@ def get_grasp_allobj(pc, predict_score, params, data_paths, use_theta=True):
     return center_pc, center_pc_index, pc_group_index, pc_group, pc_group_more_index, pc_group_more, grasp_labels
 
 
+LABEL_KERNEL = True            # GPU, batched: matching and _transform_grasp as one kernel (csrc/losses.hip: label_match_kernel)
 BATCHED_LABELS = True          # GPU: match all scenes' centres to their grasp labels in one batched pass (_get_center_grasp)
 NO_GRASP_SQ_DISTANCE = 0.005   # a centre further than this (SQUARED distance) from every grasp has no label (:120)
 
@@ -109,6 +111,24 @@ def _get_center_grasp(center_pc_index, center_pc, data_paths, depth, use_theta=T
         for i, (frames, score, anti, cen) in enumerate(loaded):
             host[i, :Gs[i], :16] = frames.reshape(Gs[i], 16).numpy()
             host[i, :Gs[i], 16], host[i, :Gs[i], 17], host[i, :Gs[i], 18] = score.numpy(), anti.numpy(), cen.numpy()
+        if LABEL_KERNEL and use_theta:
+            # matching + the (centre, axis, angle, scores) form of the match in ONE launch (csrc/losses.hip: label_match_kernel):
+            # one host->device copy (records + counts), one launch, one read (does any row carry an antipodal score?)
+            from . import _lib
+            blob = np.empty((B * Gmax * 19 + B,), dtype=np.float32)
+            blob[:B * Gmax * 19] = host.reshape(-1)
+            blob[B * Gmax * 19:].view(np.int32)[:] = np.asarray(Gs, dtype=np.int32)
+            packed = torch.from_numpy(blob).to(dev)
+            out = torch.empty((B, Nc, 10), dtype=torch.float32, device=dev)
+            wide_row = torch.empty((B * Nc,), dtype=torch.int32, device=dev)
+            xyz = center_pc if center_pc.dtype == torch.float32 and center_pc.stride(2) == 1 else center_pc.float().contiguous()
+            with torch.cuda.device(dev):
+                _lib.check(_lib.lib.regnet_label_match_f32(
+                    packed.data_ptr(), packed.data_ptr() + 4 * B * Gmax * 19, Gmax, xyz.data_ptr(), xyz.stride(0), xyz.stride(1),
+                    B, Nc, float(np.float32(depth)), float(NO_GRASP_SQ_DISTANCE), out.data_ptr(), wide_row.data_ptr(),
+                    torch.cuda.current_stream(dev).cuda_stream), "label_match")
+            wide = bool(wide_row.cpu().numpy().any())
+            return out if wide else out[:, :, :8].contiguous()
         packed = torch.from_numpy(host).to(dev)
         valid = torch.from_numpy(np.arange(Gmax)[None, :] < np.asarray(Gs)[:, None]).to(dev)
         frames = packed[:, :, :16].view(B, Gmax, 4, 4)

@@ -28,6 +28,9 @@ from .pointnet2 import PointNet2Refine, PointNet2TwoStage
 def _pool_rows(all_feature, rows):
     """max over the G gathered rows: all_feature (B,N,F), rows (R,G) global row ids -> (R,F,1)."""
     F = all_feature.shape[2]
+    if all_feature.is_cuda and torch.is_grad_enabled() and all_feature.requires_grad and all_feature.dim() == 3:
+        # training: gather from a copy made WITHOUT autograd; the pool's own node hands the gradient to the map (channel-first)
+        return region_ops.gather_max_map_train(all_feature, _contiguous_rows(all_feature, detach=True), rows).unsqueeze(-1)
     flat = _contiguous_rows(all_feature)
     if flat.is_cuda and not torch.is_grad_enabled():
         return region_ops.gather_max(flat, rows).unsqueeze(-1)
@@ -41,23 +44,24 @@ _rows_cache = [None, None]
 
 
 def forget_rows():
-    """Drop the cached contiguous rows (and with them the autograd nodes they hang on).  ``RefineTrainer.step`` calls
-    this at the end of every iteration; in training the cache holds ``flat`` strongly, because its graph must survive
-    from the region head's pool to the refine head's."""
+    """Drop the cached contiguous rows.  ``RefineTrainer.step`` calls this at the end of every iteration (the copy is 210 MB at
+    B = 8; in training it is held strongly from the region head's pool to the refine head's)."""
     _rows_cache[0] = _rows_cache[1] = None
 
 
-def _contiguous_rows(all_feature):
+def _contiguous_rows(all_feature, detach=False):
     """``all_feature.contiguous().view(-1, F)``, made ONCE per feature map: ScoreNet hands the map out as a transposed view
     in training, the region head and the refine head both pool from it, and every ``.contiguous()`` is a 210 MB transpose
-    copy forward and another one backward (B = 8).  Keyed on the tensor object, weakly; the copy itself is held strongly
-    only while it requires grad (one training iteration: ``forget_rows``), never in eval mode."""
+    copy (B = 8).  Keyed on the tensor object, weakly.  ``detach``: the copy carries no graph (GPU training: the pools
+    route their gradient themselves, region_ops._GatherMaxMapFn) and is held strongly until ``forget_rows``; otherwise the
+    copy is held only while it requires grad, never in eval mode."""
     import weakref
     ref, flat = _rows_cache
-    if ref is not None and ref() is all_feature and flat is not None:
+    if ref is not None and ref() is all_feature and flat is not None and (not detach or not flat.requires_grad):
         return flat
-    flat = all_feature.contiguous().view(-1, all_feature.shape[2])
-    _rows_cache[0], _rows_cache[1] = weakref.ref(all_feature), (flat if flat.requires_grad else None)
+    src = all_feature.detach() if detach else all_feature
+    flat = src.contiguous().view(-1, all_feature.shape[2])
+    _rows_cache[0], _rows_cache[1] = weakref.ref(all_feature), (flat if (detach or flat.requires_grad) else None)
     return flat
 
 

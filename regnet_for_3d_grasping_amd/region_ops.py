@@ -90,19 +90,33 @@ def resample_groups(pc, cand, pos):
     return index, points
 
 
+def _gather_max_arg(feature_rows, rows):
+    R, G = rows.shape
+    F = feature_rows.shape[1]
+    with torch.cuda.device(feature_rows.device):
+        out = torch.empty((R, F), dtype=torch.float32, device=feature_rows.device)
+        arg = torch.empty((R, F), dtype=torch.int64, device=feature_rows.device)
+        _check(_L.regnet_gather_max_arg_f32(feature_rows.data_ptr(), feature_rows.shape[0], F, rows.data_ptr(), R, G,
+                                            out.data_ptr(), arg.data_ptr(), _stream(feature_rows)), "gather_max_arg")
+    return out, arg
+
+
+def _scatter_max_grad(dy, arg, grad, scene_rows, batch_stride, row_stride, ch_stride):
+    dy = dy.contiguous()
+    with torch.cuda.device(dy.device):
+        _check(_L.regnet_scatter_max_grad_f32(dy.data_ptr(), arg.data_ptr(), arg.shape[0], arg.shape[1], scene_rows,
+                                              batch_stride, row_stride, ch_stride, grad.data_ptr(), _stream(dy)),
+               "scatter_max_grad")
+
+
 class _GatherMaxFn(torch.autograd.Function):
     """gather_max with autograd (training): the backward scatters the R x F incoming values to the rows that gave the
-    maxima, instead of the reference's materialised (R, G, F) gather, its max and their zero-filled gradients."""
+    maxima (one launch of float atomics into a zeroed (n, F) gradient), instead of the reference's materialised (R, G, F)
+    gather, its max and their zero-filled gradients."""
 
     @staticmethod
     def forward(ctx, feature_rows, rows):
-        R, G = rows.shape
-        F = feature_rows.shape[1]
-        with torch.cuda.device(feature_rows.device):
-            out = torch.empty((R, F), dtype=torch.float32, device=feature_rows.device)
-            arg = torch.empty((R, F), dtype=torch.int64, device=feature_rows.device)
-            _check(_L.regnet_gather_max_arg_f32(feature_rows.data_ptr(), feature_rows.shape[0], F, rows.data_ptr(), R, G,
-                                                out.data_ptr(), arg.data_ptr(), _stream(feature_rows)), "gather_max_arg")
+        out, arg = _gather_max_arg(feature_rows, rows)
         ctx.save_for_backward(arg)
         ctx.src_shape = tuple(feature_rows.shape)
         return out
@@ -111,10 +125,48 @@ class _GatherMaxFn(torch.autograd.Function):
     def backward(ctx, dy):
         (arg,) = ctx.saved_tensors
         n, F = ctx.src_shape
-        grad = torch.zeros((n * F,), dtype=dy.dtype, device=dy.device)
-        flat = (arg * F + torch.arange(F, device=arg.device).view(1, F)).reshape(-1)
-        grad.index_put_((flat.clamp_(min=0),), torch.where(arg.reshape(-1) >= 0, dy.reshape(-1), dy.new_zeros(())), accumulate=True)
-        return grad.view(n, F), None
+        grad = torch.zeros((n, F), dtype=torch.float32, device=dy.device)
+        _scatter_max_grad(dy, arg, grad, max(n, 1), 0, F, 1)
+        return grad, None
+
+
+# A trainer that already holds a gradient of the channel-first feature map (the segmentation head's, EARLY_HEAD_BACKWARD) sets
+# it here for the duration of the region stage's backward: (tensor (B, F, N) contiguous float32, event after its last writer).
+# The pools then ADD their gradient into it and return none of their own -- no zero-filled 210 MB gradients, no sum of the two
+# pools', no transposed copy back to channel-first, no addition to the head's (0.7 ms of device time at 8 x 25 600).
+_grad_sink = [None]
+
+
+def set_feature_grad_sink(tensor, ready_event=None):
+    """``tensor`` None: back to returning gradients through autograd.  See ``_grad_sink``."""
+    _grad_sink[0] = None if tensor is None else (tensor, ready_event)
+
+
+class _GatherMaxMapFn(torch.autograd.Function):
+    """``gather_max`` from the feature map itself: ``feature_map`` (B, N, F) is any view of the network's (B, F, N) output,
+    ``rows_copy`` its (B * N, F) contiguous copy made without autograd (the pools gather from it), rows (R, G) global row
+    ids.  The backward writes the gradient in the map's own channel-first layout -- or into the trainer's sink."""
+
+    @staticmethod
+    def forward(ctx, feature_map, rows_copy, rows):
+        out, arg = _gather_max_arg(rows_copy, rows)
+        ctx.save_for_backward(arg)
+        ctx.map_shape = tuple(feature_map.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        (arg,) = ctx.saved_tensors
+        B, N, F = ctx.map_shape
+        sink = _grad_sink[0]
+        if sink is not None and tuple(sink[0].shape) == (B, F, N) and sink[0].is_contiguous() and sink[0].device == dy.device:
+            if sink[1] is not None:
+                torch.cuda.current_stream(dy.device).wait_event(sink[1])
+            _scatter_max_grad(dy, arg, sink[0], N, F * N, 1, N)
+            return None, None, None
+        grad = torch.zeros((B, F, N), dtype=torch.float32, device=dy.device)
+        _scatter_max_grad(dy, arg, grad, N, F * N, 1, N)
+        return grad.transpose(1, 2), None, None
 
 
 def gather_max_train(feature_rows, rows):
@@ -122,6 +174,14 @@ def gather_max_train(feature_rows, rows):
     _need_f32(feature_rows, "feature_rows")
     _need_i64(rows, "rows")
     return _GatherMaxFn.apply(feature_rows.contiguous(), rows.contiguous())
+
+
+def gather_max_map_train(feature_map, rows_copy, rows):
+    """``gather_max`` for the (B, N, F) feature map of a training iteration, given its contiguous rows (no graph attached):
+    -> (R, F); the gradient reaches ``feature_map`` directly (see _GatherMaxMapFn)."""
+    _need_f32(rows_copy, "rows_copy")
+    _need_i64(rows, "rows")
+    return _GatherMaxMapFn.apply(feature_map, rows_copy, rows.contiguous())
 
 
 def rowsum_neg(x, K):

@@ -64,6 +64,11 @@ def allreduce_gradients(parameters, reduce="sum"):
 # point feature is kept and joins the region losses' gradient at that tensor, so the trunk is still traversed once.
 # Same gradients as one ``total.backward()`` up to the order of one fp32 addition (tests/test_gpu_train.py).
 EARLY_HEAD_BACKWARD = True
+# Workgroup slots (of 2 per CU) the head's persistent contractions leave empty while they run beside the region stage: a
+# persistent workgroup holds its CU's register file for the whole launch, so without free slots the region stage's kernels
+# advance one launch per contraction (profiles/r04m: gather_max 0.38 instead of 0.06 ms, the heads' layers 0.1-0.36 instead of
+# 0.02-0.09).  64 slots = 64 CUs running one workgroup instead of two for 1.5 ms per iteration.
+HEAD_BACKWARD_FREE_SLOTS = 64
 
 
 def _distributed():
@@ -411,8 +416,18 @@ class RefineTrainer:
             if feat.is_cuda:
                 forward_done = torch.cuda.Event()
                 forward_done.record()
-            grads = torch.autograd.grad(total, [feat] + head, retain_graph=True, allow_unused=True)
-            parts["early"] = (feat, grads[0], head, grads[1:], total)
+            # the head's backward shares the GPU with the region stage's small host-paced kernels: its persistent
+            # contractions leave HEAD_BACKWARD_FREE_SLOTS workgroup slots empty for them (conv1x1_train.reserve_stream_slots)
+            from . import conv1x1_train
+            before = conv1x1_train.reserve_stream_slots(HEAD_BACKWARD_FREE_SLOTS) if feat.is_cuda else None
+            try:
+                grads = torch.autograd.grad(total, [feat] + head, retain_graph=True, allow_unused=True)
+            finally:
+                if before is not None:
+                    conv1x1_train.reserve_stream_slots(before)
+            # the region stage sees the feature map as a LEAF: its backward (``step``) ends there, the trunk is traversed once
+            all_feature = all_feature.detach().requires_grad_(True)
+            parts["early"] = (feat, grads[0], head, grads[1:], total, all_feature)
             total = total.detach()       # its gradient is already out; what is added below is the region stage's share
             if forward_done is not None:
                 # the region stage on its OWN stream, behind the forward only: its device->host reads would otherwise wait
@@ -426,6 +441,11 @@ class RefineTrainer:
         with region_stream:
             try:
                 with contextlib.redirect_stdout(io.StringIO()):
+                    if all_feature.is_cuda:
+                        # the feature map as contiguous rows (what both pools gather from: a 210 MB transpose at B = 8), enqueued
+                        # BEFORE the stage's first device->host read instead of between its host-paced launches
+                        from . import gripper_region_network
+                        gripper_region_network._contiguous_rows(all_feature, detach=all_feature.requires_grad)
                     g = get_grasp_allobj(pc, output_score, self.params, grasp_records)
                     res = self.region_net(g[3], g[5], g[2], g[4], g[0], g[1], pc, all_feature, self.gripper_params, g[6],
                                           grasp_records)
@@ -457,7 +477,7 @@ class RefineTrainer:
             if early is None:
                 total.backward()
             else:
-                feat, g_feat, head, g_head, _ = early
+                feat, g_feat, head, g_head, _, region_feature = early
                 for p, g in zip(head, g_head):
                     if g is not None:
                         if p.grad is None:
@@ -466,11 +486,26 @@ class RefineTrainer:
                             p.grad.add_(g)
                 if self.bucket is not None:
                     self.bucket.mark_touched([p for p, g in zip(head, g_head) if g is not None])
-                roots, seeds = [feat], [g_feat]
-                if total.requires_grad:          # the region stage contributed losses
-                    roots.append(total)
-                    seeds.append(None)
-                torch.autograd.backward(roots, seeds)
+                if total.requires_grad:
+                    # the region stage contributed losses.  Its backward first -- it ends at the leaf it was given for the feature
+                    # map, and on the GPU the two pools add their gradient straight into the head's
+                    # (region_ops.set_feature_grad_sink); whatever else reaches the leaf arrives in its .grad.  Then the trunk,
+                    # once, from the sum.
+                    from . import region_ops
+                    if g_feat is not None and g_feat.is_cuda and g_feat.is_contiguous():
+                        head_done = torch.cuda.Event()
+                        head_done.record()
+                        region_ops.set_feature_grad_sink(g_feat, head_done)
+                    try:
+                        total.backward()
+                    finally:
+                        region_ops.set_feature_grad_sink(None)
+                    if side is not None:
+                        torch.cuda.current_stream(pc.device).wait_stream(side)
+                    if region_feature.grad is not None:
+                        extra = region_feature.grad.transpose(1, 2)
+                        g_feat = extra if g_feat is None else g_feat + extra
+                torch.autograd.backward([feat], [g_feat])
         if self.bucket is not None:
             self.bucket.reduce_gradients()
         self.opt_score.step()

@@ -616,3 +616,61 @@ def test_fused_region_losses_match_the_tensor_code(seed):
     for x, y in zip(ra[6], rb[6]):
         close(x, y)
     close(gra, grb, 1e-6); close(gca, gcb, 1e-6)
+
+
+@pytest.mark.parametrize("antipodal", [True, False])
+def test_label_match_kernel_equals_the_tensor_path(antipodal, monkeypatch):
+    """get_regiondataset._get_center_grasp on the GPU: matching every centre to its nearest grasp and re-expressing the frame
+    (get_regiondataset.py:45-199) as ONE kernel (csrc/losses.hip: label_match_kernel) == the batched tensor expressions, bit
+    for bit: same fp32 distance expansion compared as float64, same filler rows, same 8- / 10-channel rule."""
+    from regnet_for_3d_grasping_amd import get_regiondataset as grd, synthetic
+    B, N, Nc = 3, 6144, 64
+    pc = synthetic.make_batch(8300, B, N).to(DEV)
+    records = [synthetic.make_grasp_labels(pc[b].cpu().numpy(), 70 + b, every=7 + 3 * b) for b in range(B)]
+    if not antipodal:
+        for rec in records:
+            rec["antipodal_score"] = np.full_like(rec["antipodal_score"], -1.0)
+    g = torch.Generator().manual_seed(5)
+    idx = torch.stack([torch.randperm(N, generator=g)[:Nc] for _ in range(B)]).to(DEV)
+    centre = torch.gather(pc, 1, idx.unsqueeze(-1).expand(B, Nc, 6)).clone()
+    centre[:, :5, :3] += 1.0                      # centres far from every grasp: the reference's filler rows
+    out = {}
+    for kernel in (True, False):
+        monkeypatch.setattr(grd, "LABEL_KERNEL", kernel)
+        out[kernel] = grd._get_center_grasp(idx, centre, records, 0.06)
+    assert out[True].shape == out[False].shape == (B, Nc, 10 if antipodal else 8)
+    assert torch.equal(out[True], out[False]), float((out[True] - out[False]).abs().max())
+    assert bool((out[False][:, :5, 3:6] == 1.0).all()) and bool((out[False][:, 5:, 3:6] != 1.0).any())
+
+
+def test_gather_max_from_the_feature_map_routes_its_gradient_channel_first():
+    """region_ops.gather_max_map_train: the pools of a training iteration gather from a graph-free contiguous copy of the
+    (B, N, F) view of ScoreNet's (B, F, N) map and hand their gradient to the map in its own layout -- or ADD it into a
+    gradient the trainer already holds (set_feature_grad_sink).  Against flat[rows].view(R, G, F).max(1)[0]
+    (gripper_region_network.py:382-390) through autograd."""
+    from regnet_for_3d_grasping_amd import region_ops
+    g = torch.Generator().manual_seed(17)
+    B, N, F_, R, G = 3, 700, 64, 50, 32
+    feat = torch.randn(B, F_, N, generator=g).to(DEV).requires_grad_(True)
+    rows = torch.randint(0, B * N, (R, G), generator=g)
+    rows[:, 1] = rows[:, 0]
+    rows = rows.to(DEV)
+    dy = torch.randn(R, F_, generator=g).to(DEV)
+    view = feat.transpose(1, 2)
+    y0 = view.contiguous().view(-1, F_)[rows.reshape(-1)].view(R, G, F_).max(dim=1)[0]
+    (g0,) = torch.autograd.grad(y0, [feat], dy)
+    copy = view.detach().contiguous().view(-1, F_)
+    y1 = region_ops.gather_max_map_train(view, copy, rows)
+    assert torch.equal(y0, y1)
+    (g1,) = torch.autograd.grad(y1, [feat], dy, retain_graph=True)
+    torch.testing.assert_close(g1, g0, rtol=0.0, atol=1e-6)
+    # the sink: an existing channel-first gradient receives the pool's; autograd itself gets nothing
+    held = torch.randn(B, F_, N, generator=g).to(DEV)
+    want = held + g0
+    region_ops.set_feature_grad_sink(held, None)
+    try:
+        (g2,) = torch.autograd.grad(y1, [feat], dy, allow_unused=True)
+    finally:
+        region_ops.set_feature_grad_sink(None)
+    assert g2 is None
+    torch.testing.assert_close(held, want, rtol=0.0, atol=1e-6)
