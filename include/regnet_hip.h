@@ -558,6 +558,11 @@ int regnet_conv1x1_fwd_stream_f32(const float* W, const float* X, float* Y, int6
                                   int32_t* ticket, void* stream);
 int regnet_conv1x1_dgrad_stream_f32(const float* W, const float* dY, float* dX, int64_t B, int64_t Co, int64_t Ci, int64_t L,
                                     int32_t* ticket, void* stream);
+/* regnet_conv1x1_fwd_smallci_f32: the same forward for 1 <= Ci <= 8 input channels (the level-1 block's first layer on its
+ * grouped rows, 6 -> 128): a store stream -- a thread holds four points of every input channel and writes a float4 per output
+ * channel.  L % 4 == 0, X and Y 16-byte aligned, any Co.                                                                */
+int regnet_conv1x1_fwd_smallci_f32(const float* W, const float* X, float* Y, int64_t B, int64_t Co, int64_t Ci, int64_t L,
+                                   void* stream);
 /* regnet_conv1x1_stream_reserve_slots: the persistent kernels above hold every CU's register file for a whole launch (two
  * workgroups per CU); `slots` of those 2 x CUs workgroup slots stay empty from now on (at most half of them; negative: query
  * only), so that small kernels of ANOTHER stream -- the region stage beside the segmentation head's backward -- find CUs to

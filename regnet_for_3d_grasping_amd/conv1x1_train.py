@@ -22,6 +22,9 @@ STREAM = True
 # evaluated as statistics only, the second convolution applies the normalisation + ReLU to its operand fragments (forward and
 # weight gradient) and runs the BatchNorm's backward on its input gradient (csrc/tgemm.hip B_AFFINE, bn_train.Pending)
 DEFER_BN = True
+# input channel counts without a native tile (259, 515, 3: [xyz | feature] rows) are zero-padded to the next multiple of 16
+# (at least 32) so that all three contractions stay on csrc/tgemm.hip (_Conv1x1Padded); 0: rocBLAS batched GEMMs for them
+PAD_CHANNELS = True
 DEFERRED = {"layers": 0}     # convolutions that consumed a pending BatchNorm since import (tests, bench)
 
 
@@ -160,6 +163,54 @@ def _chunks(L, tiles, B):
     return s
 
 
+def native_fwd_smallci(x, w):
+    """x (B, Ci <= 8, L) contiguous, w (Co, Ci) contiguous -> Y (B, Co, L): a store stream (csrc/tgemm.hip: conv_smallci_kernel)."""
+    from . import _lib
+    B, Ci, L = x.shape
+    Co = w.shape[0]
+    y = torch.empty((B, Co, L), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib.regnet_conv1x1_fwd_smallci_f32(w.data_ptr(), x.data_ptr(), y.data_ptr(), B, Co, Ci, L, _stream(x)),
+                   "conv1x1_fwd_smallci")
+    return y
+
+
+def _padded_channels(B, Co, Ci, L):
+    """Input channel count rounded up so that csrc/tgemm.hip takes the layer (259 -> 272, 515 -> 528, 3 -> 32: the first layers
+    of the blocks that see [xyz | feature] rows), or 0 when padding does not help / is not worth it."""
+    if not (NATIVE and PAD_CHANNELS) or Ci <= 8:     # (a handful of channels: native_fwd_smallci; their gradients are tiny GEMMs)
+        return 0
+    Cip = max(32, (Ci + 15) // 16 * 16)
+    if Cip == Ci or Cip > 2 * Ci + 32 or not _native_ok(B, Co, Cip, L, wgrad=True):
+        return 0
+    return Cip
+
+
+class _Conv1x1Padded(torch.autograd.Function):
+    """_Conv1x1 for an input channel count csrc/tgemm.hip has no tile for: zero channels are appended to x and zero columns to
+    w (exact: they add 0.0 to every sum), forward / input gradient / weight gradient then run on the native kernels instead of
+    rocBLAS batched GEMMs (8 launches per layer and scene in the backward)."""
+
+    @staticmethod
+    def forward(ctx, x, w, Cip):
+        B, Ci, L = x.shape
+        xp = torch.zeros((B, Cip, L), dtype=torch.float32, device=x.device)
+        xp[:, :Ci].copy_(x)
+        wp = torch.zeros((w.shape[0], Cip), dtype=torch.float32, device=x.device)
+        wp[:, :Ci].copy_(w)
+        ctx.save_for_backward(xp, wp)
+        ctx.Ci = Ci
+        return native_fwd(xp, wp)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xp, wp = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = native_dgrad(wp, dy)[:, :ctx.Ci] if ctx.needs_input_grad[0] else None
+        dw = native_wgrad(dy, xp)[:, :ctx.Ci] if ctx.needs_input_grad[1] else None
+        return dx, dw, None
+
+
 class _Conv1x1(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w):
@@ -169,6 +220,8 @@ class _Conv1x1(torch.autograd.Function):
         Co = w.shape[0]
         if _native_ok(B, Co, Ci, L):
             return native_fwd(x, w.contiguous())
+        if NATIVE and Ci <= 8 and L % 4 == 0 and x.data_ptr() % 16 == 0:
+            return native_fwd_smallci(x, w.contiguous())
         # bmm on the expanded weight, NOT torch.matmul: for (2-D, 3-D) operands matmul folds the batch by transposing the
         # activation -- a full copy each way
         return torch.bmm(w.unsqueeze(0).expand(x.shape[0], -1, -1), x)
@@ -247,6 +300,10 @@ def conv1x1_of_pending(conv, pending, shape):
 
 def gemm_conv(x, w):
     """x (B, Ci, L) contiguous, w (Co, Ci) -> (B, Co, L): the autograd GEMM convolution itself."""
+    B, Ci, L = x.shape
+    Cip = _padded_channels(B, w.shape[0], Ci, L) if x.is_cuda and not _native_ok(B, w.shape[0], Ci, L) else 0
+    if Cip:
+        return _Conv1x1Padded.apply(x, w, Cip)
     return _Conv1x1.apply(x, w)
 
 
@@ -254,5 +311,5 @@ def conv1x1(conv, x):
     """``conv(x)`` for a bias-free kernel-size-1 Conv1d / Conv2d; check ``supported`` first."""
     B, Ci = x.shape[0], x.shape[1]
     Co = conv.weight.shape[0]
-    y = _Conv1x1.apply(x.contiguous().view(B, Ci, -1), conv.weight.view(Co, Ci))
+    y = gemm_conv(x.contiguous().view(B, Ci, -1), conv.weight.view(Co, Ci))
     return y.view(B, Co, *x.shape[2:])

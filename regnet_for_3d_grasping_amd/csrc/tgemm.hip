@@ -522,6 +522,50 @@ static int tg_launch_stream(TgArgs a, long long batches, int32_t* ticket, hipStr
   return REGNET_OK;
 }
 
+// Forward of a convolution with a HANDFUL of input channels (the first layer of the level-1 block on its grouped rows: 6 -> 128
+// over 8 x 327 680 points, nn/modules/conv.py:60-76): 4 GFLOP against a 1.3 GB output -- a store stream, not a contraction.  A
+// thread keeps four consecutive points of every input channel in registers and writes one float4 per output channel (a wave: 1 KB
+// runs); the weights are wave-uniform scalar loads.  rocBLAS took 0.64 ms for it (2.1 TB/s).
+template <int CI>
+__global__ __launch_bounds__(256) void conv_smallci_kernel(const float* __restrict__ W, const float* __restrict__ X,
+                                                          float* __restrict__ Y, int Co, long long L) {
+  const long long l = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (l >= L) return;
+  const float* x = X + (long long)blockIdx.y * CI * L + l;
+  float* y = Y + (long long)blockIdx.y * Co * L + l;
+  float4 v[CI];
+#pragma unroll
+  for (int i = 0; i < CI; ++i) v[i] = *reinterpret_cast<const float4*>(x + (long long)i * L);
+  for (int o = 0; o < Co; ++o) {
+    const float* w = W + o * CI;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < CI; ++i) {
+      const float wi = w[i];
+      acc.x = fmaf(wi, v[i].x, acc.x); acc.y = fmaf(wi, v[i].y, acc.y);
+      acc.z = fmaf(wi, v[i].z, acc.z); acc.w = fmaf(wi, v[i].w, acc.w);
+    }
+    *reinterpret_cast<float4*>(y + (long long)o * L) = acc;
+  }
+}
+
+extern "C" int regnet_conv1x1_fwd_smallci_f32(const float* W, const float* X, float* Y, int64_t B, int64_t Co, int64_t Ci,
+                                              int64_t L, void* stream) {
+  if (B < 0 || Co < 1 || Ci < 1 || Ci > 8 || L < 4 || (L % 4) || B >= 65536 || Co >= (1ll << 31)) return REGNET_ERR_SHAPE;
+  if (B == 0) return REGNET_OK;
+  if (!W || !X || !Y) return REGNET_ERR_NULL;
+  if (!tg_aligned16(X) || !tg_aligned16(Y)) return REGNET_ERR_SHAPE;
+  const dim3 grid((unsigned)((L / 4 + 255) / 256), (unsigned)B);
+  hipStream_t st = as_stream(stream);
+  switch (Ci) {
+#define SMALLCI_CASE(n) case n: hipLaunchKernelGGL(conv_smallci_kernel<n>, grid, dim3(256), 0, st, W, X, Y, (int)Co, (long long)L); break;
+    SMALLCI_CASE(1) SMALLCI_CASE(2) SMALLCI_CASE(3) SMALLCI_CASE(4) SMALLCI_CASE(5) SMALLCI_CASE(6) SMALLCI_CASE(7) SMALLCI_CASE(8)
+#undef SMALLCI_CASE
+  }
+  REGNET_LAUNCH_CHECK();
+  return REGNET_OK;
+}
+
 // Shapes this build handles (everything else: the caller keeps its library path): channel counts multiples of 16,
 // points a multiple of 4, 16-byte aligned buffers.
 extern "C" int regnet_conv1x1_train_supported(int64_t Co, int64_t Ci, int64_t L) {

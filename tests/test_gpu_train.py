@@ -294,7 +294,10 @@ def test_training_first_layer_before_gather_matches_plain_path():
             outs.append((pooled, dense, fa.grad))
         finally:
             modules.TRAIN_PREMUL = True
-    def close_l2(a, b, tol=1e-3):   # gradients: robust to a max-pool / ReLU decision within one ulp falling the other way
+    def close_l2(a, b, tol=5e-3):
+        # gradients: typically 3e-6 apart; a few max-pool / ReLU decisions within one ulp falling the other way between the two
+        # (differently rounded) paths move them by up to 2.5e-3 through the train-mode BatchNorms (scripts/ablate/premul_grad_probe.py:
+        # 2 seeds of 6); a wrong formula is O(1)
         assert float((a - b).norm()) <= tol * float(b.norm()) + 1e-12
 
     close(outs[0][0], outs[1][0]), close(outs[0][1], outs[1][1]), close_l2(outs[0][2], outs[1][2])
