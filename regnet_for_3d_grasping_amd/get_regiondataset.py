@@ -21,7 +21,7 @@ from . import np_random, region_ops
 from .pn2_utils import function as _F
 
 
-def get_grasp_allobj(pc, predict_score, params, data_paths, use_theta=True):
+def get_grasp_allobj(pc, predict_score, params, data_paths, use_theta=True, defer_large_groups=False):
     """pc (B,N,6), predict_score (B,N), params = [center_num, score_thre, group_num, r_time_group,
     group_num_more, r_time_group_more, width, height, depth] ->
     (center_pc (B,Nc,6), center_pc_index (B,Nc), pc_group_index (B,Nc,G), pc_group (B,Nc,G,6),
@@ -29,6 +29,7 @@ def get_grasp_allobj(pc, predict_score, params, data_paths, use_theta=True):
     (center_num, score_thre, group_num, r_time_group, group_num_more, r_time_group_more,
      width, height, depth) = params
     center_pc, center_pc_index = _select_score_center(pc, predict_score, center_num, score_thre)
+    labels_pending = None
     if pc.is_cuda and (DEVICE_DRAWS or (pc.shape[0] * pc.shape[1] > BATCHED_SEARCH_MAX_POINTS and len(data_paths) == 0)):
         # (large inference batches are throughput-bound: two candidate searches back to back at the start of the stage take CUs
         # from the next batch's first chain kernel -- same step time, but that launch read 4 % longer; they keep one search per
@@ -43,19 +44,36 @@ def get_grasp_allobj(pc, predict_score, params, data_paths, use_theta=True):
         # host draws for the second (one synchronisation and ~0.3 ms of waiting less per batch than group by group)
         cand_s, count_s = region_ops.radius_candidates(pc, center_pc, group_radius(width, height, depth, r_time_group))
         cand_m, count_m = region_ops.radius_candidates(pc, center_pc, group_radius(width, height, depth, r_time_group_more))
+        if len(data_paths) > 0 and pc.is_cuda:
+            # the labels draw nothing from numpy's stream: their host preparation and launch go here, while the device is
+            # still searching (the read of the counts below would just wait for it)
+            labels_pending = _get_center_grasp(center_pc_index, center_pc, data_paths, depth, use_theta, defer_read=True)
         np_random.flush()
         counts = torch.stack((count_s, count_m)).cpu().numpy()
         pos = torch.from_numpy(np_random.choice_rows(counts[0], group_num, 0)[0]).to(pc.device)
         pc_group_index, pc_group = region_ops.resample_groups(pc, cand_s, pos)
-        pos = torch.from_numpy(np_random.choice_rows(counts[1], group_num_more, 0)[0]).to(pc.device)
-        pc_group_more_index, pc_group_more = region_ops.resample_groups(pc, cand_m, pos)
+
+        def large_groups():
+            pos = torch.from_numpy(np_random.choice_rows(counts[1], group_num_more, 0)[0]).to(pc.device)
+            return region_ops.resample_groups(pc, cand_m, pos)
+
+        if defer_large_groups and DEFER_LARGE_GROUPS and pc.is_cuda:
+            # (train_step) the large groups are first needed by the refine stage; their draws -- the next ones on numpy's stream
+            # whoever makes them -- are left to the caller, who makes them while the device runs the region head:
+            # ``pc_group_more_index`` is the callable, ``pc_group_more`` None (GripperRegionNetwork.forward resolves them)
+            pc_group_more_index, pc_group_more = large_groups, None
+        else:
+            pc_group_more_index, pc_group_more = large_groups()
     grasp_labels = None
-    if len(data_paths) > 0:
+    if labels_pending is not None:
+        grasp_labels = labels_pending() if callable(labels_pending) else labels_pending
+    elif len(data_paths) > 0:
         grasp_labels = _get_center_grasp(center_pc_index, center_pc, data_paths, depth, use_theta)
     np_random.flush_unless_deferred()   # numpy's generator gets the state the device draws left (pipeline: once per run)
     return center_pc, center_pc_index, pc_group_index, pc_group, pc_group_more_index, pc_group_more, grasp_labels
 
 
+DEFER_LARGE_GROUPS = True      # get_grasp_allobj(defer_large_groups=True) may leave the large groups' draws + resampling to its caller
 LABEL_KERNEL = True            # GPU, batched: matching and _transform_grasp as one kernel (csrc/losses.hip: label_match_kernel)
 BATCHED_LABELS = True          # GPU: match all scenes' centres to their grasp labels in one batched pass (_get_center_grasp)
 NO_GRASP_SQ_DISTANCE = 0.005   # a centre further than this (SQUARED distance) from every grasp has no label (:120)
@@ -88,7 +106,7 @@ def _compute_distance(points1, points2):
     return d.double()
 
 
-def _get_center_grasp(center_pc_index, center_pc, data_paths, depth, use_theta=True):
+def _get_center_grasp(center_pc_index, center_pc, data_paths, depth, use_theta=True, defer_read=False):
     """Match every centre to its nearest ground-truth grasp (get_regiondataset.py:45-134).
     Returns (B, Nc, 10) = centre(3) | closing axis(3) | angle | score | antipodal | centre-score with
     -1 rows for centres without a grasp; (B, Nc, 13) raw-frame layout when ``use_theta`` is False."""
@@ -127,8 +145,10 @@ def _get_center_grasp(center_pc_index, center_pc, data_paths, depth, use_theta=T
                     packed.data_ptr(), packed.data_ptr() + 4 * B * Gmax * 19, Gmax, xyz.data_ptr(), xyz.stride(0), xyz.stride(1),
                     B, Nc, float(np.float32(depth)), float(NO_GRASP_SQ_DISTANCE), out.data_ptr(), wide_row.data_ptr(),
                     torch.cuda.current_stream(dev).cuda_stream), "label_match")
-            wide = bool(wide_row.cpu().numpy().any())
-            return out if wide else out[:, :, :8].contiguous()
+            def finish():
+                return out if bool(wide_row.cpu().numpy().any()) else out[:, :, :8].contiguous()
+
+            return finish if defer_read else finish()     # (defer_read: the caller makes the one read when it suits it)
         packed = torch.from_numpy(host).to(dev)
         valid = torch.from_numpy(np.arange(Gmax)[None, :] < np.asarray(Gs)[:, None]).to(dev)
         frames = packed[:, :, :16].view(B, Gmax, 4, 4)

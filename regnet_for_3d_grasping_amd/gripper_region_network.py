@@ -283,7 +283,9 @@ class GripperRegionNetwork(nn.Module):
         """Shapes as the reference (gripper_region_network.py:361-375); returns its 16-tuple."""
         B, N_C, N_G, _ = pc_group.shape
         N = all_feature.shape[1]
-        pc_group_more_xyz = pc_group_more[:, :, :, :6].reshape(B * N_C, -1, 6)
+        large_groups = pc_group_more_index if callable(pc_group_more_index) else None   # get_regiondataset.DEFER_LARGE_GROUPS
+        if large_groups is None:
+            pc_group_more_xyz = pc_group_more[:, :, :, :6].reshape(B * N_C, -1, 6)
 
         rows = (pc_group_index.long().view(B, N_C * N_G) + _scene_offsets(B, 1, N, pc_group_index.device)).view(B * N_C, N_G)
         pooled = _pool_rows(all_feature, rows)                                    # (B*N_C, F, 1)
@@ -292,6 +294,11 @@ class GripperRegionNetwork(nn.Module):
         fast = (ground_grasp is None and pooled.is_cuda and not torch.is_grad_enabled() and center_pc.dtype == torch.float32
                 and hasattr(region_ops, "stage2_decode"))
         x_cls, x_reg, mp_center_feature = self.extrat_feature_region(pooled, None, pooled=True, raw_reg=fast)
+        if large_groups is not None:
+            # the large groups' draws (next on numpy's stream, before the loss's class-balancing draws) and their resampling,
+            # made by the host while the device is busy with the pool and the head just enqueued
+            pc_group_more_index, pc_group_more = large_groups()
+            pc_group_more_xyz = pc_group_more[:, :, :, :6].reshape(B * N_C, -1, 6)
         if fast:
             self.templates = self.templates.to(center_pc.device)
             tmpl = _float_templates(self.templates)

@@ -169,7 +169,14 @@ class PointNet2Seg(nn.Module):
 
         if fused.usable(self, sparse_feature):
             return sparse_feature, fused.head_forward(self, sparse_feature)
-        x = self.bn_score(self.conv_score(self.mlp(sparse_feature)))
+        x = self.conv_score(self.mlp(sparse_feature))
+        from . import bn_train
+        if bn_train.supported(self.bn_score, x):
+            # training on the GPU: the one-channel BatchNorm on this repo's passes (MIOpen's spatial kernels reduce the B x N
+            # values of a single channel in one workgroup: 0.05 ms forward, 0.29 ms backward at 8 x 25 600)
+            x = bn_train.bn_relu(self.bn_score, x, False)
+        else:
+            x = self.bn_score(x)
         score = self.sigmoid(x.transpose(2, 1).contiguous()).view(B, N)
         return sparse_feature, score
 

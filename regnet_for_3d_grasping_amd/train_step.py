@@ -446,7 +446,7 @@ class RefineTrainer:
                         # BEFORE the stage's first device->host read instead of between its host-paced launches
                         from . import gripper_region_network
                         gripper_region_network._contiguous_rows(all_feature, detach=all_feature.requires_grad)
-                    g = get_grasp_allobj(pc, output_score, self.params, grasp_records)
+                    g = get_grasp_allobj(pc, output_score, self.params, grasp_records, defer_large_groups=True)
                     res = self.region_net(g[3], g[5], g[2], g[4], g[0], g[1], pc, all_feature, self.gripper_params, g[6],
                                           grasp_records)
                 loss_tuple, loss_refine_tuple = res[3], res[13]
