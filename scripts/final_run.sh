@@ -4,6 +4,7 @@ OUT=gpurun_out/$TAG
 mkdir -p $OUT
 timeout 1500 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; tail -2 $OUT/pytest_gpu.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
+for i in 1 2 3; do timeout 300 python -m pytest tests/test_gpu_train.py -x -q --tb=short > $OUT/pytest_train_again_$i.log 2>&1; tail -1 $OUT/pytest_train_again_$i.log; done
 timeout 1200 bash scripts/collect_profiles.sh $TAG --steps 20 --warmup 5 > $OUT/collect.log 2>&1; tail -3 $OUT/collect.log
 timeout 300 python bench.py --steps 20 --warmup 5 --cpu-scenes 0 --train-steps 0 > $OUT/bench_20.json 2>/dev/null
 timeout 300 python bench.py --steps 200 --warmup 5 --cpu-scenes 0 --train-steps 0 > $OUT/bench_200.json 2>/dev/null
