@@ -563,6 +563,17 @@ int regnet_conv1x1_dgrad_stream_f32(const float* W, const float* dY, float* dX, 
  * channel.  L % 4 == 0, X and Y 16-byte aligned, any Co.                                                                */
 int regnet_conv1x1_fwd_smallci_f32(const float* W, const float* X, float* Y, int64_t B, int64_t Co, int64_t Ci, int64_t L,
                                    void* stream);
+/* ... and their weight gradient: dW = sum over part's first axis, part (regnet_conv1x1_wgrad_smallci_partials(B, Co, L), Co, Ci)
+ * written by the call (one partial matrix per scene and slice of the point axis; the caller's sum fixes the order).     */
+int64_t regnet_conv1x1_wgrad_smallci_partials(int64_t B, int64_t Co, int64_t L);
+int regnet_conv1x1_wgrad_smallci_f32(const float* dY, const float* X, float* part, int64_t B, int64_t Co, int64_t Ci, int64_t L,
+                                     void* stream);
+/* regnet_conv1x1_smallco_f32: the mirror case, 1 <= Co <= 4 output channels (the segmentation head's score convolution, 128 -> 1
+ * with bias): dir 0: out (B, Co, L) = W (Co, Ci) . in (B, Ci, L) + bias (Co, may be NULL); dir 1: out (B, Ci, L) = W^T . in
+ * (B, Co, L), the input gradient (bias ignored).  L % 4 == 0, in / out 16-byte aligned.  The weight gradient is
+ * regnet_conv1x1_wgrad_smallci_f32 with the operands' roles swapped.                                                   */
+int regnet_conv1x1_smallco_f32(int dir, const float* W, const float* bias, const float* in, float* out, int64_t B, int64_t Co,
+                               int64_t Ci, int64_t L, void* stream);
 /* regnet_conv1x1_stream_reserve_slots: the persistent kernels above hold every CU's register file for a whole launch (two
  * workgroups per CU); `slots` of those 2 x CUs workgroup slots stay empty from now on (at most half of them; negative: query
  * only), so that small kernels of ANOTHER stream -- the region stage beside the segmentation head's backward -- find CUs to

@@ -175,6 +175,83 @@ def native_fwd_smallci(x, w):
     return y
 
 
+def native_wgrad_smallci(dy, x):
+    """dy (B, Co, L), x (B, Ci <= 8, L), both contiguous -> dW (Co, Ci): partial matrices per scene and slice
+    (csrc/tgemm.hip: wgrad_smallci_kernel), summed in a fixed order."""
+    from . import _lib
+    L_ = _lib.lib
+    B, Co, L = dy.shape
+    Ci = x.shape[1]
+    n = int(L_.regnet_conv1x1_wgrad_smallci_partials(B, Co, L))
+    part = torch.empty((n, Co, Ci), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(L_.regnet_conv1x1_wgrad_smallci_f32(dy.data_ptr(), x.data_ptr(), part.data_ptr(), B, Co, Ci, L, _stream(x)),
+                   "conv1x1_wgrad_smallci")
+    return part.sum(0) if n > 1 else part.view(Co, Ci)
+
+
+class _ConvSmallCo(torch.autograd.Function):
+    """y = W . x + bias for 1 <= Co <= 4 output channels (csrc/tgemm.hip: conv_smallco_*): x (B, Ci, L) contiguous, w (Co, Ci),
+    bias (Co) or None."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        from . import _lib
+        B, Ci, L = x.shape
+        Co = w.shape[0]
+        w = w.contiguous()
+        y = torch.empty((B, Co, L), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib.regnet_conv1x1_smallco_f32(0, w.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                                           x.data_ptr(), y.data_ptr(), B, Co, Ci, L, _stream(x)), "conv1x1_smallco")
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import _lib
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        B, Ci, L = x.shape
+        Co = w.shape[0]
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            with torch.cuda.device(x.device):
+                _lib.check(_lib.lib.regnet_conv1x1_smallco_f32(1, w.data_ptr(), None, dy.data_ptr(), dx.data_ptr(), B, Co, Ci, L,
+                                                               _stream(x)), "conv1x1_smallco")
+        if ctx.needs_input_grad[1]:
+            dw = native_wgrad_smallci(x, dy).t().contiguous()       # (Ci, Co) partial sums with the roles swapped -> (Co, Ci)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dy.sum((0, 2))
+        return dx, dw, db
+
+
+def small_co_ok(conv, x):
+    """``conv`` is a kernel-size-1 Conv1d / Conv2d with at most 4 output channels (with or without bias) that the store-stream
+    kernels take for the CUDA float32 input ``x``."""
+    if not (ENABLED and NATIVE and x.is_cuda and x.dtype == torch.float32 and x.dim() in (3, 4) and conv.weight.shape[0] <= 4):
+        return False
+    one, zero = (1,) * (x.dim() - 2), (0,) * (x.dim() - 2)
+    if not (tuple(conv.kernel_size) == one and tuple(conv.stride) == one and tuple(conv.dilation) == one
+            and tuple(conv.padding) == zero and conv.groups == 1 and x.numel() > 0):
+        return False
+    L = x.numel() // (x.shape[0] * x.shape[1])
+    return L % 4 == 0 and conv.weight.shape[1] <= 4096
+
+
+def conv1x1_small_co(conv, x):
+    """``conv(x)`` for such a layer; check ``small_co_ok`` first."""
+    B, Ci = x.shape[0], x.shape[1]
+    Co = conv.weight.shape[0]
+    xc = x.contiguous().view(B, Ci, -1)
+    if xc.data_ptr() % 16:
+        xc = xc.clone()
+    y = _ConvSmallCo.apply(xc, conv.weight.view(Co, Ci), conv.bias)
+    return y.view(B, Co, *x.shape[2:])
+
+
 def _padded_channels(B, Co, Ci, L):
     """Input channel count rounded up so that csrc/tgemm.hip takes the layer (259 -> 272, 515 -> 528, 3 -> 32: the first layers
     of the blocks that see [xyz | feature] rows), or 0 when padding does not help / is not worth it."""
@@ -243,6 +320,8 @@ class _Conv1x1(torch.autograd.Function):
         else:
             dx = torch.bmm(w.t().unsqueeze(0).expand(B, -1, -1), dy) if ctx.needs_input_grad[0] else None
         dw = None
+        if ctx.needs_input_grad[1] and NATIVE and Ci <= 8 and L % 4 == 0 and x.data_ptr() % 16 == 0 and dy.data_ptr() % 16 == 0:
+            return dx, native_wgrad_smallci(dy, x)
         if ctx.needs_input_grad[1]:
             S = _chunks(L, ((Co + 127) // 128) * ((Ci + 127) // 128), B)
             Ls = L // S

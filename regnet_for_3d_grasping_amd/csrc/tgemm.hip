@@ -566,6 +566,159 @@ extern "C" int regnet_conv1x1_fwd_smallci_f32(const float* W, const float* X, fl
   return REGNET_OK;
 }
 
+// Weight gradient of the same layers: dW[o][i] = sum_{b,l} dY[b][o][l] X[b][i][l] with CI <= 8 -- a reduction over the 1.3 GB
+// gradient, not a contraction.  A wave owns four output channels and one slice of one scene's points: per step a lane loads a
+// float4 of each of its four dY rows and of every X row and updates 4 x CI sums; the sums are reduced over the wave and written as
+// one partial matrix per (scene, slice) -- added by the caller in a fixed order (deterministic, like the split weight gradient above).
+template <int CI>
+__global__ __launch_bounds__(256) void wgrad_smallci_kernel(const float* __restrict__ dY, const float* __restrict__ X,
+                                                           float* __restrict__ part, int Co, long long L, long long slice_len) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int o0 = (blockIdx.y * 4 + wave) * 4;
+  if (o0 >= Co) return;
+  const long long b = blockIdx.z, l0 = (long long)blockIdx.x * slice_len;
+  const long long l1 = l0 + slice_len < L ? l0 + slice_len : L;
+  const float* x = X + b * CI * L;
+  const float* dy = dY + (b * Co + o0) * L;
+  const int no = Co - o0 < 4 ? Co - o0 : 4;
+  float acc[4][CI];
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int i = 0; i < CI; ++i) acc[k][i] = 0.f;
+  for (long long l = l0 + 4 * lane; l < l1; l += 256) {
+    float4 xv[CI], dv[4];
+#pragma unroll
+    for (int i = 0; i < CI; ++i) xv[i] = *reinterpret_cast<const float4*>(x + (long long)i * L + l);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dv[k] = k < no ? *reinterpret_cast<const float4*>(dy + (long long)k * L + l) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int i = 0; i < CI; ++i)
+        acc[k][i] += (dv[k].x * xv[i].x + dv[k].y * xv[i].y) + (dv[k].z * xv[i].z + dv[k].w * xv[i].w);
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int i = 0; i < CI; ++i) {
+      float v = acc[k][i];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+      acc[k][i] = v;
+    }
+  if (lane == 0) {
+    float* out = part + ((b * gridDim.x + blockIdx.x) * Co + o0) * CI;
+    for (int k = 0; k < no; ++k)
+#pragma unroll
+      for (int i = 0; i < CI; ++i) out[k * CI + i] = acc[k][i];
+  }
+}
+
+static long long smallci_slices(long long B, long long Co, long long L) {
+  const long long groups = B * ((Co + 15) / 16);
+  long long s = (1024 + groups - 1) / groups;                 // ~1024 workgroups
+  const long long most = (L + 4095) / 4096;                   // at least 4096 points per slice
+  if (s > most) s = most;
+  return s < 1 ? 1 : s;
+}
+
+extern "C" int64_t regnet_conv1x1_wgrad_smallci_partials(int64_t B, int64_t Co, int64_t L) {
+  return B <= 0 || Co <= 0 || L <= 0 ? 0 : B * smallci_slices(B, Co, L);
+}
+
+// part: (regnet_conv1x1_wgrad_smallci_partials(B, Co, L), Co, Ci) floats; dW = their sum over the first axis.
+extern "C" int regnet_conv1x1_wgrad_smallci_f32(const float* dY, const float* X, float* part, int64_t B, int64_t Co, int64_t Ci,
+                                                int64_t L, void* stream) {
+  if (B < 0 || Co < 1 || Ci < 1 || Ci > 8 || L < 4 || (L % 4) || B >= 65536 || Co >= (1ll << 20)) return REGNET_ERR_SHAPE;
+  if (B == 0) return REGNET_OK;
+  if (!dY || !X || !part) return REGNET_ERR_NULL;
+  if (!tg_aligned16(dY) || !tg_aligned16(X)) return REGNET_ERR_SHAPE;
+  const long long S = smallci_slices(B, Co, L);
+  long long slice_len = (L + S - 1) / S;
+  slice_len = (slice_len + 255) / 256 * 256;                 // whole wave steps
+  const dim3 grid((unsigned)S, (unsigned)((Co + 15) / 16), (unsigned)B);
+  hipStream_t st = as_stream(stream);
+  switch (Ci) {
+#define SMALLCI_CASE(n) case n: hipLaunchKernelGGL(wgrad_smallci_kernel<n>, grid, dim3(256), 0, st, dY, X, part, (int)Co, (long long)L, slice_len); break;
+    SMALLCI_CASE(1) SMALLCI_CASE(2) SMALLCI_CASE(3) SMALLCI_CASE(4) SMALLCI_CASE(5) SMALLCI_CASE(6) SMALLCI_CASE(7) SMALLCI_CASE(8)
+#undef SMALLCI_CASE
+  }
+  REGNET_LAUNCH_CHECK();
+  return REGNET_OK;
+}
+
+// The mirror case: a HANDFUL of output channels (the score convolution of the segmentation head, 128 -> 1 with bias over 8 x 25 600
+// points, pointnet2.py:51, :118): forward a reduction over the channels per point, input gradient an outer product -- both streams.
+// (The weight gradient is wgrad_smallci_kernel with the operands' roles swapped.)  MIOpen ran them as an implicit GEMM with
+// transposes: 0.18 ms forward.
+template <int CO>
+__global__ __launch_bounds__(256) void conv_smallco_fwd_kernel(const float* __restrict__ W, const float* __restrict__ bias,
+                                                              const float* __restrict__ X, float* __restrict__ Y, int Ci, long long L) {
+  const long long l = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (l >= L) return;
+  const float* x = X + (long long)blockIdx.y * Ci * L + l;
+  float4 acc[CO];
+#pragma unroll
+  for (int o = 0; o < CO; ++o) { const float b = bias ? bias[o] : 0.f; acc[o] = make_float4(b, b, b, b); }
+#pragma unroll 4
+  for (int i = 0; i < Ci; ++i) {
+    const float4 v = *reinterpret_cast<const float4*>(x + (long long)i * L);
+#pragma unroll
+    for (int o = 0; o < CO; ++o) {
+      const float w = W[o * Ci + i];
+      acc[o].x = fmaf(w, v.x, acc[o].x); acc[o].y = fmaf(w, v.y, acc[o].y);
+      acc[o].z = fmaf(w, v.z, acc[o].z); acc[o].w = fmaf(w, v.w, acc[o].w);
+    }
+  }
+  float* y = Y + (long long)blockIdx.y * CO * L + l;
+#pragma unroll
+  for (int o = 0; o < CO; ++o) *reinterpret_cast<float4*>(y + (long long)o * L) = acc[o];
+}
+
+template <int CO>
+__global__ __launch_bounds__(256) void conv_smallco_dgrad_kernel(const float* __restrict__ W, const float* __restrict__ dY,
+                                                                float* __restrict__ dX, int Ci, long long L) {
+  const long long l = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (l >= L) return;
+  const float* dy = dY + (long long)blockIdx.y * CO * L + l;
+  float4 d[CO];
+#pragma unroll
+  for (int o = 0; o < CO; ++o) d[o] = *reinterpret_cast<const float4*>(dy + (long long)o * L);
+  float* dx = dX + (long long)blockIdx.y * Ci * L + l;
+  for (int i = 0; i < Ci; ++i) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int o = 0; o < CO; ++o) {
+      const float w = W[o * Ci + i];
+      acc.x = fmaf(w, d[o].x, acc.x); acc.y = fmaf(w, d[o].y, acc.y);
+      acc.z = fmaf(w, d[o].z, acc.z); acc.w = fmaf(w, d[o].w, acc.w);
+    }
+    *reinterpret_cast<float4*>(dx + (long long)i * L) = acc;
+  }
+}
+
+// dir 0: Y (B, Co, L) = W (Co, Ci) . X (B, Ci, L) + bias (Co, may be NULL);  dir 1: dX (B, Ci, L) = W^T . dY (B, Co, L).  1 <= Co <= 4.
+extern "C" int regnet_conv1x1_smallco_f32(int dir, const float* W, const float* bias, const float* in, float* out, int64_t B,
+                                          int64_t Co, int64_t Ci, int64_t L, void* stream) {
+  if (B < 0 || Co < 1 || Co > 4 || Ci < 1 || Ci >= (1ll << 20) || L < 4 || (L % 4) || B >= 65536 || (dir != 0 && dir != 1)) return REGNET_ERR_SHAPE;
+  if (B == 0) return REGNET_OK;
+  if (!W || !in || !out) return REGNET_ERR_NULL;
+  if (!tg_aligned16(in) || !tg_aligned16(out)) return REGNET_ERR_SHAPE;
+  const dim3 grid((unsigned)((L / 4 + 255) / 256), (unsigned)B);
+  hipStream_t st = as_stream(stream);
+  switch (Co) {
+#define SMALLCO_CASE(n) case n: \
+      if (dir == 0) hipLaunchKernelGGL(conv_smallco_fwd_kernel<n>, grid, dim3(256), 0, st, W, bias, in, out, (int)Ci, (long long)L); \
+      else hipLaunchKernelGGL(conv_smallco_dgrad_kernel<n>, grid, dim3(256), 0, st, W, in, out, (int)Ci, (long long)L); \
+      break;
+    SMALLCO_CASE(1) SMALLCO_CASE(2) SMALLCO_CASE(3) SMALLCO_CASE(4)
+#undef SMALLCO_CASE
+  }
+  REGNET_LAUNCH_CHECK();
+  return REGNET_OK;
+}
+
 // Shapes this build handles (everything else: the caller keeps its library path): channel counts multiples of 16,
 // points a multiple of 4, 16-byte aligned buffers.
 extern "C" int regnet_conv1x1_train_supported(int64_t Co, int64_t Ci, int64_t L) {

@@ -169,8 +169,12 @@ class PointNet2Seg(nn.Module):
 
         if fused.usable(self, sparse_feature):
             return sparse_feature, fused.head_forward(self, sparse_feature)
-        x = self.conv_score(self.mlp(sparse_feature))
-        from . import bn_train
+        from . import bn_train, conv1x1_train
+        x = self.mlp(sparse_feature)
+        if self.training and conv1x1_train.small_co_ok(self.conv_score, x):
+            x = conv1x1_train.conv1x1_small_co(self.conv_score, x)     # 128 -> k_score with bias: store-stream kernels, not MIOpen
+        else:
+            x = self.conv_score(x)
         if bn_train.supported(self.bn_score, x):
             # training on the GPU: the one-channel BatchNorm on this repo's passes (MIOpen's spatial kernels reduce the B x N
             # values of a single channel in one workgroup: 0.05 ms forward, 0.29 ms backward at 8 x 25 600)

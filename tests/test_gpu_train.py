@@ -212,6 +212,7 @@ def test_prefetched_geometry_plan_gives_the_same_training_forward():
 
 
 @pytest.mark.parametrize("shape,co", [((2, 6, 40, 64), 32), ((3, 259, 4096), 64), ((1, 128, 2048, 64), 128), ((2, 5, 77), 3),
+                                      ((2, 3, 1024), 128), ((3, 6, 4100), 20), ((2, 6, 300, 64), 128), ((1, 8, 70000), 18),
                                       ((2, 256, 65, 64), 128), ((3, 64, 2064), 48), ((1, 512, 1024), 1024),
                                       ((2, 1024, 192), 512), ((4, 128, 8192), 256)])
 def test_gemm_conv1x1_matches_torch_convolution(shape, co):
@@ -677,3 +678,28 @@ def test_gather_max_from_the_feature_map_routes_its_gradient_channel_first():
         region_ops.set_feature_grad_sink(None)
     assert g2 is None
     torch.testing.assert_close(held, want, rtol=0.0, atol=1e-6)
+
+
+@pytest.mark.parametrize("B,Ci,L,Co,bias", [(2, 128, 25600, 1, True), (3, 64, 1028, 3, True), (1, 20, 512, 4, False)])
+def test_small_output_channel_convolution_matches_torch(B, Ci, L, Co, bias):
+    """conv1x1_train.conv1x1_small_co (the score convolution of the segmentation head, 128 -> 1 with bias, pointnet2.py:51, :118,
+    on store-stream kernels instead of MIOpen's implicit GEMM) against nn.Conv1d in float64: output and the three gradients."""
+    import torch.nn as nn
+    from regnet_for_3d_grasping_amd import conv1x1_train
+    torch.manual_seed(B + Ci + Co)
+    conv = nn.Conv1d(Ci, Co, 1, bias=bias).to(DEV)
+    x = torch.randn(B, Ci, L, device=DEV, requires_grad=True)
+    up = torch.randn(B, Co, L, device=DEV)
+    assert conv1x1_train.small_co_ok(conv, x)
+    y = conv1x1_train.conv1x1_small_co(conv, x)
+    y.backward(up)
+    got = [y, x.grad, conv.weight.grad] + ([conv.bias.grad] if bias else [])
+    c64 = nn.Conv1d(Ci, Co, 1, bias=bias).to(DEV).double()
+    c64.load_state_dict({k: v.double() for k, v in conv.state_dict().items()})
+    x64 = x.detach().double().requires_grad_(True)
+    y64 = c64(x64)
+    y64.backward(up.double())
+    want = [y64, x64.grad, c64.weight.grad] + ([c64.bias.grad] if bias else [])
+    for a, b in zip(got, want):
+        assert a.shape == b.shape
+        assert float((a.double() - b).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max()))
