@@ -229,8 +229,9 @@ def test_gemm_conv1x1_matches_torch_convolution(shape, co):
     up = torch.randn_like(ya)
     ya.backward(up)
     ga, conv.weight.grad = conv.weight.grad.clone(), None
-    yb = conv(xb)
-    yb.backward(up)
+    with torch.backends.cudnn.flags(enabled=False):     # torch's own convolution kernels: MIOpen's backward aborted once in a full-suite run
+        yb = conv(xb)
+        yb.backward(up)
     assert ya.is_contiguous() and ya.shape == yb.shape
 
     def close(a, b):
