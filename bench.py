@@ -694,11 +694,22 @@ def main():
             with torch.no_grad():
                 counts = [score_net.plan(b)["sa"][0].get("count") for b in pcs]
             if all(c is not None for c in counts):
+                from regnet_for_3d_grasping_amd import fused
                 shares = [float((c <= 32).float().mean()) for c in counts]     # per distinct batch
                 small = sum(shares) / len(shares)
                 roofline["small_ball_share"] = {"mean": round(small, 4), "min": round(min(shares), 4),
                                                 "max": round(max(shares), 4), "batches": len(shares)}
-                roofline["executed_share_of_algorithmic_flops"] = round(1.0 - 0.5 * small * 49152.0 / 49920.0, 4)
+                # neighbourhoods with 33..48 members that the kernel pairs (slots 8 g + w and 8 g + w + 4 of the processing
+                # order, csrc/sa_chain.hip) run three point tiles per pair instead of four: 3/4 of layers 2-3 each
+                pshares = []
+                for c in counts:
+                    cls = ((c.reshape(-1) > 32).to(torch.int8) + (c.reshape(-1) > 48).to(torch.int8))[fused.chain3_order(c)]
+                    full = cls[:cls.numel() // 8 * 8].view(-1, 2, 4)          # [workgroup][w < 4 | w >= 4][w & 3]
+                    pshares.append(float(2 * ((full[:, 0] == 1) & (full[:, 1] == 1)).sum()) / cls.numel())
+                paired = sum(pshares) / len(pshares)
+                roofline["paired_ball_share"] = round(paired, 4)
+                roofline["executed_share_of_algorithmic_flops"] = round(
+                    1.0 - (0.5 * small + 0.25 * paired) * 49152.0 / 49920.0, 4)
                 roofline["frac_executed"] = round(roofline["frac"] * roofline["executed_share_of_algorithmic_flops"], 4)
         if roofline:
             src = traffic_source()

@@ -222,9 +222,12 @@ int regnet_sa_layer12_f32(const float* feat, int64_t fb, int64_t fn, int64_t fc,
  * BN affine + ReLU, layer 3 its affine and ReLU if relu3.  The products are formed transposed (channels x points)
  * so each layer's MFMA accumulator is the next layer's B operand: no activation is written to LDS or HBM.
  * `count` (B*M int64, optional): the ball query's member counts -- slots >= count of a neighbourhood repeat slot 0
- * (regnet_ball_query_f32), so a neighbourhood with <= 32 members needs only its first 32 slots and half the MFMAs.
+ * (regnet_ball_query_f32), so a neighbourhood with <= 32 members needs only its first 32 slots and half the MFMAs,
+ * and two neighbourhoods with 33..48 members that sit 4 apart in a workgroup's 8 (slots 8 g + w and 8 g + w + 4 of
+ * the processing order) share their third 32-row tile: three tiles of MFMAs for the pair instead of four.
  * `order` (B*M int64, optional): a permutation of the neighbourhoods giving the order in which workgroups (8
- * neighbourhoods each) take them; sorting small neighbourhoods together lets whole workgroups finish early.
+ * neighbourhoods each) take them; sorting by member-count class (<= 32, 33..48, more) makes whole workgroups of
+ * one kind.  Outputs do not depend on `count` / `order` (bit-identical with and without).
  * Supported: group == 64, C1 == C2 == 128; anything else returns REGNET_ERR_UNSUPPORTED (use the layer-wise
  * entry points).  Same values as regnet_sa_layer12_f32 + regnet_mlp_layer_f32(pool) up to fp32 summation order. */
 int regnet_sa_chain3_f32(const float* feat, int64_t fb, int64_t fn, int64_t fc, int64_t Cf, const float* xyz,

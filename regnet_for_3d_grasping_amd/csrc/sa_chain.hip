@@ -55,10 +55,21 @@ struct ChainArgs {
 // at most 32 members fills only the first tile: its slots 32..63 are copies of slot 0 (the ball query pads with the
 // first hit), which cannot change a maximum, so the second tile's MFMAs are skipped altogether.  Both instantiations
 // execute the same barriers (one per W3 tile), so waves of one workgroup may take different ones.
+//
+// Paired neighbourhoods (role 1 = host, role 2 = guest).  Two neighbourhoods with 33..48 members each need THREE point
+// tiles between them, not four: waves w and w + 4 of a workgroup -- the two waves of one SIMD -- form a pair when both of
+// theirs are of that kind.  The host (w < 4) runs NPT = 2 with its second tile holding its own slots 32..47 in rows 0..15
+// and the GUEST's slots 32..47 in rows 16..31; the guest runs NPT = 1 on its slots 0..31.  Rows are accumulator registers
+// in the layer-3 product (rows 0..15 = registers 0..7), so the host pools the two halves of that tile separately at no
+// cost, leaves the guest's partial maximum in LDS (sPart, double-buffered by W3 tile) and the guest -- the lighter wave --
+// folds it into its own after the tile's barrier.  Every point's activations are the same MFMA chain as before and a
+// maximum does not care about grouping: bit-identical outputs, 3/4 of the matrix work for such a pair, and the SIMD's two
+// waves still add up to the same load on every SIMD of the workgroup (3 tiles each).
 template <int NPT>
 __device__ __forceinline__ void chain_group(const ChainArgs& p, const float* __restrict__ sW2, float (*sW3)[32 * CH_LD],
                                             const float* __restrict__ sW1, const float* __restrict__ sS2,
-                                            const float* __restrict__ sT2, const float (&x)[2][8], long long gs, bool valid,
+                                            const float* __restrict__ sT2, float (*sPart)[4][32], const int role,
+                                            const float (&x)[2][8], long long gs, bool valid,
                                             float4 w3a, float4 w3b, int tid, int lane, int fr, int fh, int t_row0,
                                             int t_c4) {
   // ---- layer 2 (layer 1 on the fly): acc2[dt][pt] = W2[32 dt .., :] . h1[:, 32 pt ..] ------------------------------
@@ -153,23 +164,40 @@ __device__ __forceinline__ void chain_group(const ChainArgs& p, const float* __r
       for (int pt = 0; pt < NPT; ++pt) acc3[pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(acc2[dt][pt][4 * q + 3], w.w, acc3[pt], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
-    // lane l holds channel et*32 + (l & 31) of 16 points per point tile (+ the other 16 in lane l ^ 32)
+    // lane l holds channel et*32 + (l & 31) of 16 points per point tile (+ the other 16 in lane l ^ 32); registers 0..7
+    // are rows 0..15 of a tile, registers 8..15 rows 16..31
+    float hold;
     {
       const float sc = p.scale3[et * 32 + fr], sh = p.shift3[et * 32 + fr];
-      float m = -__builtin_inff();
+      float m = -__builtin_inff(), m2 = -__builtin_inff();
 #pragma unroll
-      for (int pt = 0; pt < NPT; ++pt)
+      for (int r = 0; r < 16; ++r) m = fmaxf(m, acc3[0][r] * sc + sh);
+      if (NPT == 2) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) m = fmaxf(m, acc3[pt][r] * sc + sh);
+        for (int r = 0; r < 8; ++r) m = fmaxf(m, acc3[NPT - 1][r] * sc + sh);
+#pragma unroll
+        for (int r = 8; r < 16; ++r) m2 = fmaxf(m2, acc3[NPT - 1][r] * sc + sh);
+        if (role == 1) {   // rows 16..31 of the second tile are the guest's
+          m2 = fmaxf(m2, __shfl_xor(m2, 32, 64));
+          if (fh == 0) sPart[buf][tid >> 6][fr] = m2;
+        } else {
+          m = fmaxf(m, m2);
+        }
+      }
       if (p.relu3) m = fmaxf(m, 0.f);
       m = fmaxf(m, __shfl_xor(m, 32, 64));
-      if (fh == 0 && valid) orow[et * 32 + fr] = m;
+      hold = m;
+      if (role != 2 && fh == 0 && valid) orow[et * 32 + fr] = m;
     }
     if (et + 1 < tiles) {
       *reinterpret_cast<float4*>(&sW3[buf ^ 1][t_row0 * CH_LD + t_c4 * 4]) = w3a;
       *reinterpret_cast<float4*>(&sW3[buf ^ 1][(t_row0 + 16) * CH_LD + t_c4 * 4]) = w3b;
     }
     __syncthreads();
+    if (NPT == 1 && role == 2) {   // the host's next write to sPart[buf] is two barriers away
+      const float m = fmaxf(hold, sPart[buf][(tid >> 6) - 4][fr]);
+      if (fh == 0 && valid) orow[et * 32 + fr] = m;
+    }
   }
 }
 
@@ -188,6 +216,7 @@ __global__ __launch_bounds__(CH_THREADS, 2) void sa_chain_kernel(const ChainArgs
   __shared__ __attribute__((aligned(16))) float sW3[2][32 * CH_LD];
   __shared__ __attribute__((aligned(16))) float sW1[CH_C * 12];   // [c][w0..w7 | scale | shift | 0 0]
   __shared__ __attribute__((aligned(16))) float sS2[CH_C], sT2[CH_C];
+  __shared__ float sPart[2][4][32];   // [W3 tile parity][host wave][channel]: a paired guest's partial maxima
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 31, fh = lane >> 5;
 
@@ -217,7 +246,19 @@ __global__ __launch_bounds__(CH_THREADS, 2) void sa_chain_kernel(const ChainArgs
   const long long slot = (long long)blockIdx.x * CH_WAVES + wave;
   const bool valid = slot < p.groups;
   const long long gs = valid ? (p.order ? p.order[slot] : slot) : 0;
-  const int npt = (p.count && p.count[gs] <= 32) ? 1 : 2;   // wave-uniform
+  // pairing (see chain_group): waves w and w + 4 when both neighbourhoods have 33..48 members; all of it wave-uniform
+  int role = 0;
+  long long gm = gs;
+  const long long c_me = p.count ? p.count[gs] : 64;
+  if (p.count && valid) {
+    const long long pslot = wave < 4 ? slot + 4 : slot - 4;
+    if (pslot < p.groups) {
+      const long long gp = p.order ? p.order[pslot] : pslot;
+      const long long c_p = p.count[gp];
+      if (c_me > 32 && c_me <= 48 && c_p > 32 && c_p <= 48) { role = wave < 4 ? 1 : 2; gm = gp; }
+    }
+  }
+  const int npt = (c_me <= 32 || role == 2) ? 1 : 2;
   const long long b = gs / p.groups_per_scene;
   const float* xb = p.xyz + b * p.xb;
   const long long cj = p.ctr[gs];
@@ -225,12 +266,22 @@ __global__ __launch_bounds__(CH_THREADS, 2) void sa_chain_kernel(const ChainArgs
   float x[2][8];
 #pragma unroll
   for (int pt = 0; pt < 2; ++pt) {
-    const long long j = p.nbr[gs * 64 + pt * 32 + fr];
-    const float rx = xb[j * p.xn] - cx, ry = xb[p.xc + j * p.xn] - cy, rz = xb[2 * p.xc + j * p.xn] - cz;
+    // a host's second tile: rows 0..15 its own slots 32..47, rows 16..31 the guest's slots 32..47 (the guest's scene and centre)
+    const bool theirs = pt == 1 && role == 1 && fr >= 16;
+    const long long g = theirs ? gm : gs;
+    const long long bg = theirs ? gm / p.groups_per_scene : b;
+    const float* xg = p.xyz + bg * p.xb;
+    float ox = cx, oy = cy, oz = cz;
+    if (theirs) {
+      const long long cm = p.ctr[gm];
+      ox = xg[cm * p.xn]; oy = xg[p.xc + cm * p.xn]; oz = xg[2 * p.xc + cm * p.xn];
+    }
+    const long long j = p.nbr[g * 64 + pt * 32 + (theirs ? fr - 16 : fr)];
+    const float rx = xg[j * p.xn] - ox, ry = xg[p.xc + j * p.xn] - oy, rz = xg[2 * p.xc + j * p.xn] - oz;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       float v = 0.f;
-      if (c < p.Cf) v = p.feat[b * p.fb + j * p.fn + (long long)c * p.fc];
+      if (c < p.Cf) v = p.feat[bg * p.fb + j * p.fn + (long long)c * p.fc];
       else if (c == p.Cf) v = rx;
       else if (c == p.Cf + 1) v = ry;
       else if (c == p.Cf + 2) v = rz;
@@ -239,8 +290,8 @@ __global__ __launch_bounds__(CH_THREADS, 2) void sa_chain_kernel(const ChainArgs
   }
   __syncthreads();
 
-  if (npt == 2) chain_group<2>(p, sW2, sW3, sW1, sS2, sT2, x, gs, valid, w3a, w3b, tid, lane, fr, fh, t_row0, t_c4);
-  else chain_group<1>(p, sW2, sW3, sW1, sS2, sT2, x, gs, valid, w3a, w3b, tid, lane, fr, fh, t_row0, t_c4);
+  if (npt == 2) chain_group<2>(p, sW2, sW3, sW1, sS2, sT2, sPart, role, x, gs, valid, w3a, w3b, tid, lane, fr, fh, t_row0, t_c4);
+  else chain_group<1>(p, sW2, sW3, sW1, sS2, sT2, sPart, role, x, gs, valid, w3a, w3b, tid, lane, fr, fh, t_row0, t_c4);
   CH_TRACE_END();
 }
 

@@ -263,6 +263,12 @@ def sa_premul_layer(U, V, nbr, layer, B, Nsrc, M, group, pool_group=0):
 
 
 @_on_tensor_device
+def chain3_order(count):
+    """Processing order of sa_chain3's neighbourhoods by cost class (<= 32 members, 33..48, more), stable within a class."""
+    c = count.reshape(-1)
+    return torch.argsort((c > 32).to(torch.uint8) + (c > 48).to(torch.uint8), stable=True)
+
+
 def sa_chain3(feature, xyz, nbr, ctr, l1, l2, l3, B, M, group, count=None, order=None):
     """Whole narrow-input SA block (gather, three layers, max over the neighbours) in one kernel; -> (B*M, C3).
     ``count`` (B,M) int64: members per neighbourhood (half the work for those with <= 32); ``order`` (B*M,) int64:
@@ -432,10 +438,11 @@ def sa_group(module, xyz, ctr, first_tie=None):
     if (CHAIN3 and module.grouper.num_neighbours == 64 and len(module.mlp) == 3
             and module.mlp[0].conv.in_channels <= 8):
         # for the register-chained block (narrow gathered input, sa_features): neighbourhoods with <= 32 members first
-        # (they cost half), so that whole workgroups are of one kind; computed here, in the geometry stage, off the
-        # matrix cores' critical path
+        # (one point tile instead of two), then those with 33..48 (waves w and w + 4 of a workgroup share a third tile:
+        # three tiles per pair, csrc/sa_chain.hip), then the full ones, so that whole workgroups are of one kind;
+        # computed here, in the geometry stage, off the matrix cores' critical path
         geo["count"] = count
-        geo["order"] = torch.argsort((count.view(-1) > 32).to(torch.uint8), stable=True)
+        geo["order"] = chain3_order(count)
     elif (PREMUL and not module.training and not torch.is_grad_enabled() and module.use_xyz
           and module.mlp[0].conv.in_channels > 8 and len(module.mlp) >= 2):
         # wide gathered input (levels 2+, see sa_features): everything of the pre-multiplied first layer that depends on the

@@ -267,7 +267,7 @@ def test_fp_premultiplied_first_layer_equals_interpolate_then_multiply(Cd, monke
     torch.testing.assert_close(up2, up0, rtol=1e-4, atol=1e-4)
 
 
-@pytest.mark.parametrize("M,C3,Cf", [(37, 256, 3), (8, 64, 0), (3, 160, 5)])
+@pytest.mark.parametrize("M,C3,Cf", [(37, 256, 3), (8, 64, 0), (3, 160, 5), (100, 256, 3)])
 def test_sa_chain3_whole_block_in_registers(M, C3, Cf):
     """Register-chained level-1 SA block == gather + three (conv, BN, ReLU) layers + max over the 64 neighbours."""
     from regnet_for_3d_grasping_amd import fused
@@ -285,13 +285,19 @@ def test_sa_chain3_whole_block_in_registers(M, C3, Cf):
     first = fused._pack(conv1, bn1, True, order)
     # ball-query style padding: a neighbourhood with `count` members repeats slot 0 behind them
     count = torch.from_numpy(rng.integers(1, G + 1, (B, M))).to(DEV)
+    if M == 100:   # mostly 33..48 members: whole workgroups of paired neighbourhoods (three point tiles per pair), across scenes
+        count = torch.from_numpy(rng.choice([33, 40, 47, 48, 48, 41, 36, 20, 49, 64], (B, M))).to(DEV)
     count[0, 0], count[-1, -1] = 32, 33
     slot = torch.arange(G, device=DEV).view(1, 1, G)
     nbr = torch.where(slot < count.unsqueeze(-1), nbr, nbr[:, :, :1].expand(B, M, G)).contiguous()
-    order = torch.argsort((count.view(-1) > 32).to(torch.uint8), stable=True)
+    order = fused.chain3_order(count)
     got = fused.sa_chain3(feat, xyz, nbr, ctr, first, layer2, layer3, B, M, G, count, order)
     plain = fused.sa_chain3(feat, xyz, nbr, ctr, first, layer2, layer3, B, M, G)
-    assert torch.equal(got, plain)     # skipping the all-padding point tile and reordering change nothing
+    assert torch.equal(got, plain)     # skipping all-padding point tiles, sharing a tile between two neighbourhoods and reordering change nothing
+    # pairs also form without an order (slots w and w + 4 of a workgroup as they come) and under the two-class order
+    assert torch.equal(fused.sa_chain3(feat, xyz, nbr, ctr, first, layer2, layer3, B, M, G, count), plain)
+    two_class = torch.argsort((count.view(-1) > 32).to(torch.uint8), stable=True)
+    assert torch.equal(fused.sa_chain3(feat, xyz, nbr, ctr, first, layer2, layer3, B, M, G, count, two_class), plain)
     idx = nbr.view(B, 1, M * G)
     gx = torch.gather(xyz, 2, idx.expand(B, 3, -1)).view(B, 3, M, G)
     gx = gx - torch.gather(xyz, 2, ctr[:, None, :].expand(B, 3, M)).unsqueeze(-1)
