@@ -262,13 +262,14 @@ def sa_premul_layer(U, V, nbr, layer, B, Nsrc, M, group, pool_group=0):
     return out
 
 
-@_on_tensor_device
 def chain3_order(count):
-    """Processing order of sa_chain3's neighbourhoods by cost class (<= 32 members, 33..48, more), stable within a class."""
+    """Processing order of sa_chain3's neighbourhoods by cost class (<= 32 members, 33..48, more), stable within a class.
+    (The expensive class first instead: 994-1 005 against 995-1 000 scenes/s over three alternations -- no difference.)"""
     c = count.reshape(-1)
     return torch.argsort((c > 32).to(torch.uint8) + (c > 48).to(torch.uint8), stable=True)
 
 
+@_on_tensor_device
 def sa_chain3(feature, xyz, nbr, ctr, l1, l2, l3, B, M, group, count=None, order=None):
     """Whole narrow-input SA block (gather, three layers, max over the neighbours) in one kernel; -> (B*M, C3).
     ``count`` (B,M) int64: members per neighbourhood (half the work for those with <= 32); ``order`` (B*M,) int64:
