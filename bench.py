@@ -585,10 +585,23 @@ def main():
     timer.critical_streams = {m.cuda_stream for m in pipe.s_mlps}
     timer.enabled = True
     pipe.graph_replays = 0
+    # CPython's cyclic collector inside the timed region (reported as config.host_gc): a generation-2 pass over a process
+    # that holds a few hundred thousand torch objects stalls the launching thread for milliseconds
+    import gc
+    gc_log = {"n": [0, 0, 0], "ms": 0.0, "t": 0.0}
+
+    def gc_watch(phase, info):
+        if phase == "start":
+            gc_log["t"] = time.perf_counter()
+        else:
+            gc_log["n"][info["generation"]] += 1
+            gc_log["ms"] += (time.perf_counter() - gc_log["t"]) * 1e3
+    gc.callbacks.append(gc_watch)
     t0 = time.perf_counter()
     out = run_steps(args.steps, refine_stats)
     fence()
     dt = time.perf_counter() - t0
+    gc.callbacks.remove(gc_watch)
     timer.enabled = False
     main_summary = timer.summary() if rank == 0 else None
     dt = sharding.max_over_ranks(dt, dev)
@@ -739,6 +752,8 @@ def main():
                        "sampling_lookahead_batches": first_launch_batches,
                        # distinct batches the steps cycle through (seeds 1000 + (k*W + rank)*B ...)
                        "distinct_batches": distinct,
+                       # automatic garbage collections of the host interpreter inside the timed region (all threads)
+                       "host_gc": {"collections_by_generation": gc_log["n"], "ms": round(gc_log["ms"], 2)},
                        "region_head": region_calibration or "seeded only (refine stage skipped by the reference's own guard)",
                        # per timed step: grasps decoded by stage 2, closing boxes with > 5 points (= rows of the refine
                        # network), class-1 grasps the refine stage kept
