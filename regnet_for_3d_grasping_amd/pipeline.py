@@ -65,6 +65,9 @@ def sampling_workgroups_per_scene(num_points):
 # the run's average launch duration (what `roofline` is computed from) reads 3 % longer.  Off by default: per-kernel durations
 # stay a property of the kernel; a latency-minded caller switches it on.
 LEVEL_EVENTS = False
+# ... but for the FIRST batch of a run only: nothing else is on the chip while its geometry is computed, so its level-1 block
+# may start as soon as level 1's ball query is there (levels 2-3 and the 3-NN searches then run beside it)
+FIRST_BATCH_LEVEL_EVENTS = True
 GRAPH_MAX_POINTS = 4 * 25600   # graphs="auto": batches of at most this many points replay hipGraphs (launch-bound shapes)
 
 
@@ -213,7 +216,7 @@ class ForwardPipeline:
             _ = s.cuda_stream
 
     # -- stages -------------------------------------------------------------------------------
-    def _sample_group(self, pcs):
+    def _sample_group(self, pcs, first=False):
         """Level-1 sampling of several consecutive batches in ONE launch -> one item per batch.
 
         A sampling workgroup owns a whole CU for ~4-5 ms (10 ms when this was measured).  The hardware deals the workgroups of every launch to the XCDs and
@@ -229,7 +232,8 @@ class ForwardPipeline:
             # all three sampling levels: the level-2 / level-3 launches hold a CU per scene too (1.3 + 0.5 ms)
             big = pcs[0] if len(pcs) == 1 else torch.cat(pcs, 0)
             level1_done = None
-            if self.level_events and "_sample" not in self.__dict__:
+            first = first and FIRST_BATCH_LEVEL_EVENTS and not self.level_events
+            if (self.level_events or first) and "_sample" not in self.__dict__:
                 marks = {}
 
                 def after_level(i):
@@ -249,7 +253,7 @@ class ForwardPipeline:
         items, at = [], 0
         for pc in pcs:
             items.append({"pc": pc, "ctr": [c[at:at + pc.shape[0]] for c in ctr], "fps_done": done,
-                          "fps1_done": level1_done})
+                          "fps1_done": level1_done if (not first or not items) else None})   # first: the run's first batch only
             at += pc.shape[0]
         return items
 
@@ -323,7 +327,7 @@ class ForwardPipeline:
         if graphs is not None:
             return self._geometry_replay(item, graphs)
         with torch.cuda.stream(self.s_geo), torch.no_grad():
-            if self.level_events and item.get("fps1_done") is not None and "_plan" not in self.__dict__:
+            if item.get("fps1_done") is not None and "_plan" not in self.__dict__:
                 # level by level: level 1's ball query needs level 1's sampling only, and every level's geometry carries its own
                 # completion event (PointNet2Seg.forward waits per level) -- the first batch of a run starts its level-1 block
                 # ~2.5 ms earlier (levels 2-3 sampling, their ball queries and the three 3-NN searches run beside it)
@@ -506,7 +510,7 @@ class ForwardPipeline:
                     if pcs:
                         if first_launch:
                             self.first_launch_batches = len(pcs)
-                        sampled.extend(self._sample_group(pcs))
+                        sampled.extend(self._sample_group(pcs, first=first_launch))
                         first_launch = False
                 if not sampled and not geo_q:
                     break

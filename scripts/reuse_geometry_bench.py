@@ -25,9 +25,9 @@ class ReusePipeline(pipeline.ForwardPipeline):
             self._ctr = [c[:self._b0].clone() for c in super()._sample(big)]
         return [c.repeat(big.shape[0] // self._b0, 1) for c in self._ctr]
 
-    def _sample_group(self, pcs):
+    def _sample_group(self, pcs, first=False):
         self._b0 = pcs[0].shape[0]
-        return super()._sample_group(pcs)
+        return super()._sample_group(pcs, first)
 
     def _plan(self, pc, ctr):
         if mode != "plan":
