@@ -538,7 +538,9 @@ def test_gather_max_train_matches_the_materialised_gather():
         y1 = region_ops.gather_max_train(flat, rows)
         (g1,) = torch.autograd.grad(y1, [flat], dy)
         assert torch.equal(y0, y1)
-        torch.testing.assert_close(g1, g0, rtol=0.0, atol=1e-6)
+        # both sides add a row's gradients up with atomics, in an order that varies from run to run: a few ulps of the sum
+        # (one element in 128 000 was 1.4e-6 off in one run of ~300)
+        torch.testing.assert_close(g1, g0, rtol=2e-6, atol=5e-6)
 
 
 @pytest.mark.parametrize("seed", [3, 4, 5])
@@ -667,7 +669,7 @@ def test_gather_max_from_the_feature_map_routes_its_gradient_channel_first():
     y1 = region_ops.gather_max_map_train(view, copy, rows)
     assert torch.equal(y0, y1)
     (g1,) = torch.autograd.grad(y1, [feat], dy, retain_graph=True)
-    torch.testing.assert_close(g1, g0, rtol=0.0, atol=1e-6)
+    torch.testing.assert_close(g1, g0, rtol=2e-6, atol=5e-6)    # atomics on both sides: the order of a row's additions varies
     # the sink: an existing channel-first gradient receives the pool's; autograd itself gets nothing
     held = torch.randn(B, F_, N, generator=g).to(DEV)
     want = held + g0
@@ -677,7 +679,7 @@ def test_gather_max_from_the_feature_map_routes_its_gradient_channel_first():
     finally:
         region_ops.set_feature_grad_sink(None)
     assert g2 is None
-    torch.testing.assert_close(held, want, rtol=0.0, atol=1e-6)
+    torch.testing.assert_close(held, want, rtol=2e-6, atol=5e-6)
 
 
 @pytest.mark.parametrize("B,Ci,L,Co,bias", [(2, 128, 25600, 1, True), (3, 64, 1028, 3, True), (1, 20, 512, 4, False)])
