@@ -71,6 +71,10 @@ def parse():
                     help="forward bench only: training iterations (configs[3] shapes, batch --train-batch) timed AFTER the timed "
                          "region for the line's \"train\" object (5 warm-up iterations first); 0 = skip")
     ap.add_argument("--train-batch", type=int, default=8)
+    ap.add_argument("--train-distinct-batches", type=int, default=4,
+                    help="training measurement: distinct batches the iterations cycle through (labels and scenes resident)")
+    ap.add_argument("--train-timeline-steps", type=int, default=3,
+                    help="training measurement: extra iterations under torch.profiler AFTER the timed ones for gpu_idle_ms_per_step (0 = skip)")
     ap.add_argument("--no-lookahead-steps", type=int, default=20,
                     help="steps of the extra pass AFTER the timed region with one sampling launch per batch and no enlarged "
                          "first launch (value_no_lookahead); 0 = skip")
@@ -226,6 +230,19 @@ def pmc_traffic(kernel):
         return None
 
 
+def rocprof_launch(kernel):
+    """(average launch duration in ms, source file) of ``kernel``'s family in the committed rocprofv3 --kernel-trace --stats
+    summary of this same command (profiles/rocprof_launch_ms.json, written by scripts/rocprof_summary.py --json from the trace
+    whose text form is the file named in its "source"); (None, None) when there is no such entry."""
+    path = os.path.join(REPO, "profiles", "rocprof_launch_ms.json")
+    try:
+        with open(path) as f:
+            doc = json.load(f)
+        return doc["families"][kernel]["avg_launch_ms"], doc.get("source")
+    except (OSError, ValueError, KeyError):
+        return None, None
+
+
 def traffic_source():
     """Is profiles/pmc_traffic.json still about THIS library?  Every kernel name the PMC passes recorded (``kernel_names`` per
     family, scripts/collect_pmc.py) must be a kernel of the library that is loaded now (``nm -C`` of the .so: the kernel
@@ -318,6 +335,83 @@ def cpu_baseline(args, n_scenes, gpu_models=None):
             "parity": parity}
 
 
+class HostBlockedTime:
+    """Context manager: seconds the calling thread spends BLOCKED waiting for the device inside the package's synchronising
+    reads (Tensor.cpu / .item / .tolist of GPU tensors, Event.synchronize, Stream.synchronize, torch.cuda.synchronize)."""
+
+    def __init__(self):
+        self.seconds, self.calls, self._saved = 0.0, 0, []
+
+    def _wrap(self, owner, name, needs_cuda_self):
+        orig = getattr(owner, name)
+        outer = self
+
+        def timed(*a, **k):
+            if needs_cuda_self and not (a and getattr(a[0], "is_cuda", False)):
+                return orig(*a, **k)
+            t = time.perf_counter()
+            try:
+                return orig(*a, **k)
+            finally:
+                outer.seconds += time.perf_counter() - t
+                outer.calls += 1
+        self._saved.append((owner, name, orig))
+        setattr(owner, name, timed)
+
+    def __enter__(self):
+        for name in ("cpu", "item", "tolist"):
+            self._wrap(torch.Tensor, name, True)
+        self._wrap(torch.cuda.Event, "synchronize", False)
+        self._wrap(torch.cuda.Stream, "synchronize", False)
+        self._wrap(torch.cuda, "synchronize", False)
+        return self
+
+    def __exit__(self, *exc):
+        for owner, name, orig in reversed(self._saved):
+            setattr(owner, name, orig)
+        self._saved = []
+
+
+def gpu_timeline(step_fn, n):
+    """Run ``step_fn(k)`` for k in range(n) under torch.profiler (device activities only) and reduce the kernels' start / end
+    stamps of ALL streams to the union of busy intervals: -> {steps, span_ms_per_step, busy_ms_per_step, idle_ms_per_step,
+    kernels_per_step, gaps_over_20us_per_step}, or {"error": ...} when the profiler is not usable on this box."""
+    try:
+        from torch.profiler import ProfilerActivity, profile
+        torch.cuda.synchronize()
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            t0 = time.perf_counter()
+            for k in range(n):
+                step_fn(k)
+            torch.cuda.synchronize()
+            wall = time.perf_counter() - t0
+        spans = []
+        for ev in prof.events():
+            if getattr(ev, "device_type", None) is not None and "cuda" in str(ev.device_type).lower():
+                tr = ev.time_range
+                if tr.end > tr.start:
+                    spans.append((tr.start, tr.end))
+        if not spans:
+            return {"error": "no device activity recorded"}
+        spans.sort()
+        busy, gaps, (cur_s, cur_e) = 0.0, 0, spans[0]
+        for s0, e0 in spans[1:]:
+            if s0 > cur_e:
+                busy += cur_e - cur_s
+                gaps += (s0 - cur_e) > 20.0
+                cur_s, cur_e = s0, e0
+            else:
+                cur_e = max(cur_e, e0)
+        busy += cur_e - cur_s
+        span = max(e for _, e in spans) - spans[0][0]
+        return {"steps": n, "wall_ms_per_step_under_profiler": round(wall / n * 1e3, 3),
+                "span_ms_per_step": round(span / n / 1e3, 3), "busy_ms_per_step": round(busy / n / 1e3, 3),
+                "idle_ms_per_step": round((span - busy) / n / 1e3, 3), "kernels_per_step": round(len(spans) / n, 1),
+                "gaps_over_20us_per_step": round(gaps / n, 1)}
+    except Exception as exc:      # a side measurement: never takes the line down
+        return {"error": repr(exc)[:200]}
+
+
 def _cpu_model():
     try:
         with open("/proc/cpuinfo") as f:
@@ -342,9 +436,16 @@ def measure_train(args, rank, world, dev, steps, warmup, batch):
     from regnet_for_3d_grasping_amd.score_network import ScoreNetwork
     from regnet_for_3d_grasping_amd.train_step import RefineTrainer
     B, N = batch, args.points
-    pc_cpu = synthetic.make_batch(1000 + rank * B, B, N)
-    records = [synthetic.make_grasp_labels(pc_cpu[b].numpy(), 50 + rank * B + b) for b in range(B)]
-    target = torch.from_numpy(np.random.default_rng(2 + rank).uniform(0, 1, (B, N)).astype(np.float32)).to(dev)
+    # the iterations cycle through `distinct` batches of this rank's shard (scene i of a run uses seed 1000 + i;
+    # iteration k feeds global batch k % distinct), all resident in HBM, labels parsed, before the timed region
+    distinct = max(1, args.train_distinct_batches)
+    batches = []
+    for k in range(distinct):
+        seeds = sharding.scene_seeds(rank, world, B, step=k)
+        pc_k = torch.from_numpy(np.stack([synthetic.make_scene(s_, N) for s_ in seeds], 0))
+        records_k = [synthetic.make_grasp_labels(pc_k[b].numpy(), 50 + s_) for b, s_ in enumerate(seeds)]
+        target_k = torch.from_numpy(np.random.default_rng([2, seeds[0]]).uniform(0, 1, (B, N)).astype(np.float32)).to(dev)
+        batches.append((pc_k.to(dev), target_k, records_k))
     score_net = ScoreNetwork(training=True)
     score_net.load_state_dict(synthetic.seeded_state_dict(score_net, 7))
     region_net = GripperRegionNetwork(training=True, group_num=pipeline.GROUP_NUM, gripper_num=pipeline.GRIPPER_NUM,
@@ -356,7 +457,6 @@ def measure_train(args, rank, world, dev, steps, warmup, batch):
     gc_was_on = gc.isenabled()
     trainer = RefineTrainer(score_net.to(dev), region_net.to(dev), pipeline.PARAMS, pipeline.GRIPPER_PARAMS,
                             gc_interval=args.gc_interval)
-    pc = pc_cpu.to(dev)
     np.random.seed(rank)
     # HIP events around the native 1x1-convolution kernels (forward / input gradient / weight gradient: the MFMA work of
     # the iteration) on the stream they are launched on, inside the timed region
@@ -373,29 +473,40 @@ def measure_train(args, rank, world, dev, steps, warmup, batch):
 
     # steady state of a training loop: the geometry (FPS / ball query / 3-NN: xyz only) of the NEXT batch is enqueued
     # on a side stream before each iteration, as a data loader with one batch of look-ahead would
-    ahead = trainer.prefetch(pc)
+    it = 0
+    ahead = trainer.prefetch(batches[0][0])
     for _ in range(warmup):
-        nxt = trainer.prefetch(pc)
+        nxt = trainer.prefetch(batches[(it + 1) % distinct][0])
+        pc, target, records = batches[it % distinct]
         trainer.step(pc, target, records, plan=ahead)
-        ahead = nxt
+        ahead, it = nxt, it + 1
     fence()
     timer.enabled = True
-    t0 = time.perf_counter()
+    blocked = HostBlockedTime()
     region_steps = refine_steps = 0
     allreduce_ms = []
-    for _ in range(steps):
-        nxt = trainer.prefetch(pc)
-        loss, parts = trainer.step(pc, target, records, plan=ahead)
-        ahead = nxt
-        region_steps += "region_error" not in parts
-        refine_steps += parts.get("refine") is not None
-        if trainer.bucket is not None and trainer.bucket.last_ms is not None:
-            allreduce_ms.append(trainer.bucket.last_ms)
-    fence()
-    dt = sharding.max_over_ranks(time.perf_counter() - t0, dev)
+    with blocked:
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            nxt = trainer.prefetch(batches[(it + 1) % distinct][0])
+            pc, target, records = batches[it % distinct]
+            loss, parts = trainer.step(pc, target, records, plan=ahead)
+            ahead, it = nxt, it + 1
+            region_steps += "region_error" not in parts
+            refine_steps += parts.get("refine") is not None
+            if trainer.bucket is not None and trainer.bucket.last_ms is not None:
+                allreduce_ms.append(trainer.bucket.last_ms)
+        t_enqueued = time.perf_counter() - t0
+        fence()
+        dt_local = time.perf_counter() - t0
+    dt = sharding.max_over_ranks(dt_local, dev)
     timer.enabled = False
     for name, fn in originals.items():
         setattr(conv1x1_train, name, fn)
+    # where the GPU has nothing to run: a few MORE iterations under torch's profiler (kernel start / end stamps of every
+    # stream -> union of busy intervals), outside the timed region
+    gpu_idle = gpu_timeline(lambda k: trainer.step(*batches[(it + k) % distinct]), args.train_timeline_steps) \
+        if args.train_timeline_steps > 0 else None
     # what the trainer's own collection (every TRAIN_GC_INTERVAL iterations) costs: one collection timed here, amortised below
     t1 = time.perf_counter()
     gc.collect()
@@ -410,6 +521,15 @@ def measure_train(args, rank, world, dev, steps, warmup, batch):
             "value": round(B * steps * world / dt, 3), "unit": "scenes/s", "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic", "roofline": roofline,
+            # the launching thread: wall time of the timed iterations minus the time it was BLOCKED in a device->host read or
+            # a synchronisation (waiting for the GPU); host_ms_per_step ~ ms_per_step means the iteration is paced by the host
+            "host_ms_per_step": round((dt_local - blocked.seconds) / steps * 1e3, 3),
+            "host_blocked_ms_per_step": round(blocked.seconds / steps * 1e3, 3),
+            "host_blocking_reads_per_step": round(blocked.calls / steps, 1),
+            "host_enqueue_done_ms_per_step": round(t_enqueued / steps * 1e3, 3),
+            # union of all kernels' busy intervals over `gpu_timeline.steps` extra iterations (torch.profiler, after the timed region)
+            "gpu_idle_ms_per_step": None if not gpu_idle else gpu_idle.get("idle_ms_per_step"),
+            "gpu_timeline": gpu_idle,
             # event-timed duration of the iteration's single flat gradient all-reduce (RCCL, side stream); null at 1 GPU
             "allreduce_ms": round(sum(allreduce_ms) / len(allreduce_ms), 4) if allreduce_ms else None,
             # CPython's automatic cyclic collector is off during training (RefineTrainer(gc_interval=N) collects every N
@@ -419,15 +539,19 @@ def measure_train(args, rank, world, dev, steps, warmup, batch):
             "config": {"workload": "%s: training iteration (forward with labels, stage-2 + refine losses, backward, "
                                    "two Adam steps), %d-pt synthetic scenes, batch=%d per GPU" % (
                                        "configs[4]" if N == 51200 else "configs[3]", N, B),
-                       "points": N, "batch_per_gpu": B, "global_batch": B * world,
+                       "points": N, "batch_per_gpu": B, "global_batch": B * world, "distinct_batches": distinct,
+                       "bucket_bytes": None if trainer.bucket is None else int(trainer.bucket.flat.numel()) * 4,
                        "parallelism": "dp%d: ONE flat fp32 gradient all-reduce per iteration (%d elements, both networks) over RCCL" % (world, grads),
                        "steps_with_region_losses": region_steps, "steps_with_refine_losses": refine_steps,
                        "last_loss": float(loss)}}
 
 
-def run_train(args, rank, world, dev):
+def run_train(args, rank, world, dev, collective=None):
     res = measure_train(args, rank, world, dev, args.steps, args.warmup, args.batch)
     if rank == 0:
+        if collective is not None:
+            res["config"]["collective"] = dict(collective, bucket_bytes=res["config"].pop("bucket_bytes", None),
+                                               allreduce_ms=res["allreduce_ms"])
         print(json.dumps(res))
 
 
@@ -486,6 +610,31 @@ def roofline_of(agg, steps, batch, critical=None):
     return fam, roofline
 
 
+def sa_chain_executed_share(score_net, pcs):
+    """Share of sa_chain_kernel's algorithmic flops (all 64 slots of every level-1 neighbourhood) that the kernel executes
+    on these batches: neighbourhoods with <= 32 members run one 32-row point tile instead of two; two neighbourhoods with
+    33..48 members that the kernel pairs (slots 8 g + w and 8 g + w + 4 of the processing order, csrc/sa_chain.hip) run three
+    tiles instead of four.  Layers 2-3 are 49152 / 49920 of the block's flops.  None when the plan carries no counts."""
+    from regnet_for_3d_grasping_amd import fused
+    with torch.no_grad():
+        counts = [score_net.plan(b)["sa"][0].get("count") for b in pcs]
+    if not counts or any(c is None for c in counts):
+        return None
+    shares = [float((c <= 32).float().mean()) for c in counts]     # per distinct batch
+    small = sum(shares) / len(shares)
+    pshares = []
+    for c in counts:
+        cls = ((c.reshape(-1) > 32).to(torch.int8) + (c.reshape(-1) > 48).to(torch.int8))[fused.chain3_order(c)]
+        full = cls[:cls.numel() // 8 * 8].view(-1, 2, 4)          # [workgroup][w < 4 | w >= 4][w & 3]
+        pshares.append(float(2 * ((full[:, 0] == 1) & (full[:, 1] == 1)).sum()) / cls.numel())
+    paired = sum(pshares) / len(pshares)
+    mean_count = sum(float(c.float().mean()) for c in counts) / len(counts)
+    return {"small_ball_share": {"mean": round(small, 4), "min": round(min(shares), 4), "max": round(max(shares), 4),
+                                 "batches": len(shares)},
+            "paired_ball_share": round(paired, 4), "mean_ball_count": round(mean_count, 2),
+            "executed_share_of_algorithmic_flops": round(1.0 - (0.5 * small + 0.25 * paired) * 49152.0 / 49920.0, 4)}
+
+
 def main():
     args = parse()
     from regnet_for_3d_grasping_amd import sharding
@@ -505,6 +654,17 @@ def main():
         # (sharding.pin_rank: a contiguous share of the GPU's NUMA node, affinity mask + OpenMP / torch pools)
         pinned = sharding.pin_rank(local_rank, world, None if one_device else local_rank)
         sharding.init("gloo" if one_device else "nccl", dev)   # RCCL; forward: only the barrier + max-over-ranks of the contract
+        import torch.distributed as dist
+        if not one_device and str(dist.get_backend()) != "nccl":
+            raise SystemExit("bench.py --gpus %d: the process group's backend is %r, not nccl (= RCCL on ROCm)" % (world, dist.get_backend()))
+    # what the process group really is (backend, world size, RCCL version, a startup all-reduce proving `world` distinct
+    # ranks / devices, the gradient-bucket-sized all-reduce's duration and bus bandwidth): config.collective of both lines
+    collective = sharding.describe_collective(dev) if world > 1 else None
+    if collective is not None:
+        collective["pinned_cores"] = len(pinned)
+        if collective["distinct_ranks_by_allreduce"] != world or (not one_device and collective["distinct_devices"] != world):
+            raise SystemExit("bench.py --gpus %d: the group holds %d distinct ranks on %d distinct devices" % (
+                world, collective["distinct_ranks_by_allreduce"], collective["distinct_devices"]))
     import importlib
     for item in args.set:
         target, value = item.split("=")
@@ -518,7 +678,7 @@ def main():
             raise SystemExit("--global-batch %d is not a multiple of the %d ranks" % (args.global_batch, world))
         args.batch = args.train_batch = args.global_batch // world
     if args.train:
-        run_train(args, rank, world, dev)
+        run_train(args, rank, world, dev, collective)
         if world > 1:
             torch.distributed.destroy_process_group()
         return
@@ -700,30 +860,39 @@ def main():
             roofline["accounting_note"] = ("the %d timed steps replayed hipGraphs (%d feature stages); launch durations are from %d "
                                            "extra steps outside the timed region with the same launches issued one by one"
                                            % (args.steps, graph_replays, graph_accounting_steps))
-        if roofline and roofline["kernel"] == "sa_chain_kernel":
-            # the level-1 chain skips the second point tile of neighbourhoods with <= 32 members (their slots 32..63 repeat
-            # slot 0): "achieved" counts the ALGORITHMIC flops (all 64 slots, what the reference multiplies); say how much of
-            # it the matrix pipe really executes on these scenes (layers 2-3 are 49152 / 49920 of the block's flops)
-            with torch.no_grad():
-                counts = [score_net.plan(b)["sa"][0].get("count") for b in pcs]
-            if all(c is not None for c in counts):
-                from regnet_for_3d_grasping_amd import fused
-                shares = [float((c <= 32).float().mean()) for c in counts]     # per distinct batch
-                small = sum(shares) / len(shares)
-                roofline["small_ball_share"] = {"mean": round(small, 4), "min": round(min(shares), 4),
-                                                "max": round(max(shares), 4), "batches": len(shares)}
-                # neighbourhoods with 33..48 members that the kernel pairs (slots 8 g + w and 8 g + w + 4 of the processing
-                # order, csrc/sa_chain.hip) run three point tiles per pair instead of four: 3/4 of layers 2-3 each
-                pshares = []
-                for c in counts:
-                    cls = ((c.reshape(-1) > 32).to(torch.int8) + (c.reshape(-1) > 48).to(torch.int8))[fused.chain3_order(c)]
-                    full = cls[:cls.numel() // 8 * 8].view(-1, 2, 4)          # [workgroup][w < 4 | w >= 4][w & 3]
-                    pshares.append(float(2 * ((full[:, 0] == 1) & (full[:, 1] == 1)).sum()) / cls.numel())
-                paired = sum(pshares) / len(pshares)
-                roofline["paired_ball_share"] = round(paired, 4)
-                roofline["executed_share_of_algorithmic_flops"] = round(
-                    1.0 - (0.5 * small + 0.25 * paired) * 49152.0 / 49920.0, 4)
-                roofline["frac_executed"] = round(roofline["frac"] * roofline["executed_share_of_algorithmic_flops"], 4)
+        # sa_chain_kernel skips the padded point tiles of small neighbourhoods (exact: a duplicate cannot move a maximum), so
+        # the ALGORITHMIC flops of its launches (all 64 slots, what the reference multiplies) overstate what the matrix pipe
+        # executes; every fraction quoted as a utilisation below is computed from the EXECUTED flops
+        chain_exec = sa_chain_executed_share(score_net, pcs)
+        launched_gflop = sum(f["units"] for f in fam.values() if f["bound"] == "mfma") / 1e9 / max(
+            (graph_accounting_steps or args.steps) * args.batch, 1)
+        chain_alg_gflop = (fam["sa_chain_kernel"]["units"] / 1e9 / max((graph_accounting_steps or args.steps) * args.batch, 1)
+                           if "sa_chain_kernel" in fam else 0.0)
+        share = chain_exec["executed_share_of_algorithmic_flops"] if chain_exec else 1.0
+        executed_gflop = launched_gflop - chain_alg_gflop * (1.0 - share)
+        if roofline and roofline["bound"] == "mfma":
+            k_share = share if roofline["kernel"] == "sa_chain_kernel" else 1.0
+            if roofline["kernel"] == "sa_chain_kernel" and chain_exec:
+                roofline.update(chain_exec)
+            roofline["frac_algorithmic"] = roofline["frac"]
+            roofline["achieved_algorithmic"] = roofline["achieved"]
+            roofline["frac"] = round(roofline["frac_algorithmic"] * k_share, 6)          # executed flops / event duration / peak
+            roofline["achieved"] = round(roofline["achieved_algorithmic"] * k_share, 4)
+            roofline["frac_executed"] = roofline["frac"]
+            roofline["executed_flop_per_launch"] = round(roofline["algorithmic_units_per_launch"] * k_share)
+            rp_ms, rp_src = rocprof_launch(roofline["kernel"])
+            roofline["rocprof_avg_launch_ms"] = rp_ms
+            roofline["rocprof_source"] = rp_src
+            if rp_ms:
+                # the same fraction from the committed trace's duration instead of this run's events (the trace is of
+                # another run of this command on another box: durations differ by a few per cent)
+                roofline["frac_rocprof"] = round(roofline["executed_flop_per_launch"] / (rp_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 6)
+            # whole step: executed flops of ALL matrix kernels of a batch / ms_per_step / peak
+            roofline["step_frac_executed"] = round(executed_gflop * args.batch / (dt / args.steps * 1e3) / 1e3
+                                                   / MFMA_F32_PEAK_TFLOPS, 6)
+            roofline["frac_note"] = ("frac / achieved / frac_rocprof count EXECUTED flops (sa_chain_kernel skips padded point tiles: "
+                                     "executed_share_of_algorithmic_flops); frac_algorithmic / achieved_algorithmic count SURVEY "
+                                     "8(d)'s algorithmic flops and may exceed what a matrix pipe can do")
         if roofline:
             src = traffic_source()
             roofline["traffic_source"] = src
@@ -770,10 +939,17 @@ def main():
                                             "mlp_layer K384 N1024 (conv_formal)":
                                             sum(c for (n, m), (_, c) in agg.items() if n == "mlp_layer" and " K384 N1024" in m)}},
                        "switches": args.set or None,
+                       # multi-rank runs: what the process group really is (sharding.describe_collective); the forward path
+                       # itself has no data-path collective -- the probe all-reduce is the training bucket's size
+                       "collective": collective,
                        "hip_graphs": bool(graph_replays),
                        "scorenet_gflop_per_scene": SCORENET_GFLOP_PER_SCENE.get(args.points),
-                       "executed_gflop_per_scene": round(sum(f["units"] for f in fam.values() if f["bound"] == "mfma")
-                                                         / 1e9 / max(args.steps * args.batch, 1), 2)},
+                       # flops of the launched matrix kernels per scene: "launched" after the algebraic restructuring (layer 1
+                       # of levels 2-3 and of the propagation blocks evaluated per source point), "executed" also without the
+                       # padded point tiles sa_chain_kernel skips
+                       "launched_gflop_per_scene": round(launched_gflop, 2),
+                       "executed_gflop_per_scene": round(executed_gflop, 2),
+                       "level1_balls": chain_exec},
             "roofline": roofline,
             "roofline_exclusive": None,
             "latency_ms_single_scene": latency_ms,
@@ -800,6 +976,11 @@ def main():
                             "steps": train_line["steps"], "warmup": train_line["warmup"],
                             "batch_per_gpu": args.train_batch, "roofline": train_line["roofline"],
                             "allreduce_ms": train_line["allreduce_ms"], "workload": train_line["config"]["workload"],
+                            "host_ms_per_step": train_line["host_ms_per_step"],
+                            "host_blocked_ms_per_step": train_line["host_blocked_ms_per_step"],
+                            "gpu_idle_ms_per_step": train_line["gpu_idle_ms_per_step"], "gpu_timeline": train_line["gpu_timeline"],
+                            "distinct_batches": train_line["config"]["distinct_batches"],
+                            "bucket_bytes": train_line["config"]["bucket_bytes"],
                             "parallelism": train_line["config"]["parallelism"],
                             "note": "measured after the timed region; `python bench.py --train` times it alone"}
         if world == 1 and args.cpu_scenes > 0:

@@ -16,6 +16,7 @@ The training losses (``ground_grasp`` given; :92-184, :233-309) are plain torch 
 targets); they draw their class-balancing samples from numpy's global RNG like the reference.
 """
 import math
+import threading
 
 import numpy as np
 import torch
@@ -40,13 +41,20 @@ def _pool_rows(all_feature, rows):
     return flat[rows.reshape(-1)].view(rows.shape[0], rows.shape[1], F).max(dim=1)[0].unsqueeze(-1)
 
 
-_rows_cache = [None, None]
+class _RowsCache(threading.local):
+    """Per THREAD (a training call and an inference call on two threads must not see each other's copy)."""
+    ref = None
+    flat = None
+
+
+_rows_cache = _RowsCache()
 
 
 def forget_rows():
-    """Drop the cached contiguous rows.  ``RefineTrainer.step`` calls this at the end of every iteration (the copy is 210 MB at
-    B = 8; in training it is held strongly from the region head's pool to the refine head's)."""
-    _rows_cache[0] = _rows_cache[1] = None
+    """Drop the cached contiguous rows (the copy is 210 MB at B = 8; in training it is held strongly from the region head's
+    pool to the refine head's).  ``GripperRegionNetwork.forward`` calls this when it returns, so the copy never outlives the
+    forward that used it, whoever drives the network; ``RefineTrainer.step`` calls it again at the end of the iteration."""
+    _rows_cache.ref = _rows_cache.flat = None
 
 
 def _contiguous_rows(all_feature, detach=False):
@@ -56,12 +64,12 @@ def _contiguous_rows(all_feature, detach=False):
     route their gradient themselves, region_ops._GatherMaxMapFn) and is held strongly until ``forget_rows``; otherwise the
     copy is held only while it requires grad, never in eval mode."""
     import weakref
-    ref, flat = _rows_cache
+    ref, flat = _rows_cache.ref, _rows_cache.flat
     if ref is not None and ref() is all_feature and flat is not None and (not detach or not flat.requires_grad):
         return flat
     src = all_feature.detach() if detach else all_feature
     flat = src.contiguous().view(-1, all_feature.shape[2])
-    _rows_cache[0], _rows_cache[1] = weakref.ref(all_feature), (flat if (detach or flat.requires_grad) else None)
+    _rows_cache.ref, _rows_cache.flat = weakref.ref(all_feature), (flat if (detach or flat.requires_grad) else None)
     return flat
 
 
@@ -171,7 +179,7 @@ class GripperRegionNetwork(nn.Module):
         2.5 cm, its axis within 60 deg (1 - cos < 0.5) and its angle within 1.047 rad of the label;
         CE on a class-balanced subset (numpy RNG) + four smooth-L1 terms on the positives."""
         dev = next_grasp.device
-        if next_gt is not None and region_losses.usable(next_grasp, next_x_cls, next_x_reg, next_gt):
+        if next_gt is not None and region_losses.usable_refine(next_grasp, next_x_cls, next_x_reg, next_gt):
             return region_losses.refine_loss(next_grasp, next_x_cls, next_x_reg, next_gt, self.radius, self.grasp_score_thre)
         if (next_gt is None and next_grasp.is_cuda and not torch.is_grad_enabled() and next_grasp.dtype == torch.float32
                 and hasattr(region_ops, "refine_decode")):
@@ -281,6 +289,15 @@ class GripperRegionNetwork(nn.Module):
     def forward(self, pc_group, pc_group_more, pc_group_index, pc_group_more_index, center_pc, center_pc_index, pc,
                 all_feature, gripper_params, ground_grasp=None, data_path=None):
         """Shapes as the reference (gripper_region_network.py:361-375); returns its 16-tuple."""
+        try:
+            return self._forward(pc_group, pc_group_more, pc_group_index, pc_group_more_index, center_pc, center_pc_index, pc,
+                                 all_feature, gripper_params, ground_grasp, data_path)
+        finally:
+            forget_rows()     # the contiguous copy of the feature map both pools gathered from (their autograd nodes keep
+                              # indices, not the copy)
+
+    def _forward(self, pc_group, pc_group_more, pc_group_index, pc_group_more_index, center_pc, center_pc_index, pc,
+                 all_feature, gripper_params, ground_grasp=None, data_path=None):
         B, N_C, N_G, _ = pc_group.shape
         N = all_feature.shape[1]
         large_groups = pc_group_more_index if callable(pc_group_more_index) else None   # get_regiondataset.DEFER_LARGE_GROUPS
@@ -307,7 +324,7 @@ class GripperRegionNetwork(nn.Module):
             true_mask, keep2 = _all_centres(B, N_C, center_pc.device)
             loss_tuple, correct_tuple, next_gt = (None, None), (None, None, None, None), None
         elif (ground_grasp is not None and center_pc.dtype == torch.float32
-              and region_losses.usable(x_reg, x_cls, center_pc, ground_grasp)):
+              and region_losses.usable_stage2(x_reg, x_cls, center_pc, ground_grasp)):
             # training on the GPU: the whole label branch of compute_loss (decode, anchor matching, four smooth-L1 terms, the
             # class-balanced cross entropy, monitoring) in two launches + one read, gradients included (csrc/losses.hip)
             self.templates = self.templates.to(center_pc.device)

@@ -50,6 +50,13 @@ def supported(layers, x):
         if not (bn.affine and bn.track_running_stats and bn.momentum is not None and conv.weight.is_cuda
                 and tuple(conv.kernel_size) == (1,) and conv.groups == 1):
             return False
+        # the kernels read the parameters and buffers as dense float32 rows (regnet_head_layer_train_fwd_f32 answers anything
+        # else with ERR_SHAPE, which the trainer would record as a region error every step): anything else -> torch's layers
+        tensors = (conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var)
+        if not all(t is None or (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()) for t in tensors):
+            return False
+        if conv.weight.data_ptr() % 16:
+            return False
     return True
 
 
@@ -168,6 +175,8 @@ class _HeadTree(torch.autograd.Function):
 
 def _run(layers, x):
     x2 = x.reshape(x.shape[0], x.shape[1]).contiguous()
+    if x2.data_ptr() % 16:      # an offset view that is already contiguous comes back unchanged: the kernels want 16-byte rows
+        x2 = x2.clone()
     tree = tuple((parent, relu) for _, _, parent, relu in layers)
     buffers = tuple((bn.running_mean, bn.running_var, bn.num_batches_tracked, float(bn.momentum), float(bn.eps))
                     for _, bn, _, _ in layers)

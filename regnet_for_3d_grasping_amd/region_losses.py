@@ -27,6 +27,20 @@ def usable(*tensors):
     return FUSED and all(t.is_cuda and t.dtype == torch.float32 for t in tensors)
 
 
+def usable_stage2(x_reg, x_cls, centres, ground):
+    """The fused stage-2 loss is instantiated for the reference's configuration only (csrc/losses.hip:
+    regnet_stage2_loss_rows_f32): 10 regression channels per anchor, label rows of at least 10 columns, at most 64 anchors.
+    Anything else (``reg_channel`` is a constructor parameter) takes the tensor path, as the reference does."""
+    return (usable(x_reg, x_cls, centres, ground) and x_reg.dim() == 3 and x_reg.shape[-1] == 10 and x_reg.shape[1] <= 64
+            and ground.shape[-1] >= 10)
+
+
+def usable_refine(next_grasp, next_x_cls, next_x_reg, next_gt):
+    """Same for the refine loss (regnet_refine_loss_rows_f32: C == 10, label rows of >= 10 columns)."""
+    return (usable(next_grasp, next_x_cls, next_x_reg, next_gt) and next_x_reg.dim() == 2 and next_x_reg.shape[-1] == 10
+            and next_grasp.shape[-1] >= 10 and next_gt.shape[-1] >= 10)
+
+
 class _Stage2Loss(torch.autograd.Function):
     """loss = 10 l_centre + 5 l_axis + l_theta + l_score + CE(class-balanced anchors); gradients to x_reg and x_cls."""
 
@@ -37,6 +51,11 @@ class _Stage2Loss(torch.autograd.Function):
         l_theta, l_score, 4 monitoring terms of the arg-max decode, #(g8 == pick), #(g8 != pick), CE, 0]."""
         n, A, C = x_reg.shape
         m = int(rows.numel())
+        if m == 0:
+            # no labelled centre in the batch: the tensor path fails in ``np.concatenate([])`` (ValueError) and the reference's
+            # bare ``except`` (train.py:430) falls back to the ScoreNet loss alone -- same exception type here, raised before
+            # anything is launched or drawn from numpy's stream
+            raise ValueError("stage-2 loss: no labelled centre in the batch")
         dev = x_reg.device
         x_reg, x_cls, labels = x_reg.contiguous(), x_cls.contiguous(), labels.contiguous()
         centres = centres if centres.stride(1) == 1 else centres.contiguous()

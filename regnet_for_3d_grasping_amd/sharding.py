@@ -50,6 +50,62 @@ def gather_counts(count, device="cpu"):
     return int(t.item())
 
 
+def describe_collective(device, probe_elements=7066927 + 128, probe_iters=5):
+    """What the process group REALLY is, for the bench line of a multi-rank run (``config.collective``): backend and world
+    size as the group reports them, the RCCL version, a startup all-reduce that proves ``world`` distinct ranks on distinct
+    devices, and the duration / bus bandwidth of an all-reduce the size of the training iteration's gradient bucket
+    (``probe_elements`` fp32: both networks' 7 066 927 parameters + the presence flags, utils.py:129-133 replaced by ONE
+    flat all-reduce).  Collective: every rank must call it.  Returns None without an initialised group of > 1 ranks."""
+    import time
+
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return None
+    world, rank = dist.get_world_size(), dist.get_rank()
+    backend = str(dist.get_backend())
+    on_gpu = torch.device(device).type == "cuda"
+    # one-hot rank vector: the sum over ranks is all ones iff the group holds `world` DISTINCT ranks
+    onehot = torch.zeros(world, dtype=torch.int64, device=device)
+    onehot[rank] = 1
+    dist.all_reduce(onehot, op=dist.ReduceOp.SUM)
+    distinct_ranks = int((onehot == 1).sum().item())
+    # (device index, PCI bus id) of every rank's GPU
+    ident = torch.zeros(2, dtype=torch.int64, device=device)
+    if on_gpu:
+        idx = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+        props = torch.cuda.get_device_properties(idx)
+        ident[0], ident[1] = idx, (getattr(props, "pci_domain_id", 0) << 16) | (getattr(props, "pci_bus_id", 0) << 8) | getattr(props, "pci_device_id", 0)
+    gathered = [torch.zeros_like(ident) for _ in range(world)]
+    dist.all_gather(gathered, ident)
+    devices = sorted({(int(g[0]), int(g[1])) for g in gathered})
+    version = None
+    if backend == "nccl":
+        try:
+            version = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except (RuntimeError, AttributeError, TypeError):
+            version = None
+    buf = torch.ones(probe_elements, dtype=torch.float32, device=device)
+
+    def fence():
+        if on_gpu:
+            torch.cuda.synchronize()
+    dist.all_reduce(buf)            # warm-up: communicator set-up, first-use allocations
+    fence()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(probe_iters):
+        dist.all_reduce(buf)
+    fence()
+    ms = max_over_ranks((time.perf_counter() - t0) / probe_iters * 1e3, device)
+    nbytes = probe_elements * 4
+    return {"backend": backend, "world_size": world, "rccl_version": version,
+            "distinct_ranks_by_allreduce": distinct_ranks, "distinct_devices": len(devices),
+            "devices": ["cuda:%d pci %06x" % d for d in devices],
+            "probe_bytes": nbytes, "probe_allreduce_ms": round(ms, 4),
+            # ring convention: every byte crosses 2 (W - 1) / W links' worth of the slowest link
+            "bus_GBps": round(2.0 * (world - 1) / world * nbytes / (ms * 1e-3) / 1e9, 3) if ms > 0 else None}
+
+
 # ---- host side of one-process-per-GPU: which cores a rank's Python, OpenMP and torch intra-op threads run on ------------
 def _parse_cpulist(text):
     """'0-15,128-143' -> [0, ..., 15, 128, ..., 143] (the kernel's cpulist format)."""

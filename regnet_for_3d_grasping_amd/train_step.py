@@ -271,6 +271,7 @@ class ScoreTrainer:
         self.scheduler = torch.optim.lr_scheduler.StepLR(self.optimizer, step_size=5, gamma=0.5)
         self.geometry = GeometryPrefetcher(score_net)
         self.bucket = None           # created by the first step that finds a process group (_ensure_bucket)
+        self._iterations = 0
         self._ensure_bucket()
 
     def prefetch(self, pc):
@@ -281,6 +282,9 @@ class ScoreTrainer:
         """The gradient all-reduce is decided per STEP, not at construction: a process group initialised after the
         trainer was built must not leave the ranks training apart without an error."""
         if self.bucket is None and _distributed():
+            if getattr(self, "_iterations", 0) > 0:    # (optimizer moments / step counts of the local steps would stay per rank)
+                raise RuntimeError("a process group appeared after %d local training steps: build the ScoreTrainer after "
+                                   "torch.distributed is initialised" % self._iterations)
             broadcast_module_state(self.net)
             self.bucket = GradientBucket([self.net], self.reduce)
 
@@ -298,6 +302,7 @@ class ScoreTrainer:
         if self.bucket is not None:
             self.bucket.reduce_gradients()
         self.optimizer.step()
+        self._iterations += 1
         return loss_total.detach()
 
     def end_epoch(self):
@@ -377,6 +382,11 @@ class RefineTrainer:
         """The gradient all-reduce is decided per STEP, not once at construction: a process group initialised after the
         trainer was built must not leave the ranks training apart without an error."""
         if self.bucket is None and _distributed():
+            if self._iterations > 0:
+                # rank 0's parameters could be broadcast, but not the Adam moments, step counts and StepLR state the local
+                # steps already built: the ranks would apply different optimizer states to the same all-reduced gradient
+                raise RuntimeError("a process group appeared after %d local training steps: build the RefineTrainer (or "
+                                   "restore a checkpoint into it) after torch.distributed is initialised" % self._iterations)
             broadcast_module_state(self.score_net, self.region_net)
             self.bucket = GradientBucket([self.score_net, self.region_net], self.reduce)
 
@@ -455,7 +465,7 @@ class RefineTrainer:
                 if len(loss_refine_tuple) > 2:
                     total = total + loss_refine_tuple[0].sum()
                     parts["refine"] = loss_refine_tuple[0]
-            except (RuntimeError, IndexError, ValueError) as exc:   # the reference uses a bare except (train.py:430)
+            except (RuntimeError, IndexError, ValueError, ArithmeticError) as exc:   # the reference uses a bare except (train.py:430)
                 parts["region_error"] = repr(exc)
         return total, parts
 

@@ -43,13 +43,32 @@ def fill(model):
     return model
 
 
+def fill_circulant(model):
+    """Epoch-8 fixtures: numpy-seeded O(1) weights (tests/golden_util.circulant_state) -- a well-conditioned network, so
+    that the HIP path's scores can be held to 1e-4 on reference-pickled weights without a sensitivity allowance."""
+    sys.path.insert(0, _ref_shims.REPO_ROOT)
+    from tests.golden_util import circulant_state
+    state = model.state_dict()
+    for key, value in state.items():
+        value.copy_(circulant_state(key.replace("module.", ""), tuple(value.shape), value.dtype))
+    return model
+
+
 def main():
     sn, grn, _ = _ref_shims.import_reference()
     torch.manual_seed(0)
-    score = fill(torch.nn.DataParallel(sn.ScoreNetwork(training=True, k_obj=2)))
-    region = fill(grn.GripperRegionNetwork(training=True, group_num=256, gripper_num=64, grasp_score_threshold=0.5,
-                                           radius=0.06, reg_channel=10))
-    for model, name in ((score, "ckpt_score_7.model.gz"), (region, "ckpt_region_7.model.gz")):
+
+    def fresh():
+        return (torch.nn.DataParallel(sn.ScoreNetwork(training=True, k_obj=2)),
+                grn.GripperRegionNetwork(training=True, group_num=256, gripper_num=64, grasp_score_threshold=0.5,
+                                         radius=0.06, reg_channel=10))
+    score, region = (fill(m) for m in fresh())
+    score8, region8 = (fill_circulant(m) for m in fresh())
+    for model, name in ((score, "ckpt_score_7.model.gz"), (region, "ckpt_region_7.model.gz"),
+                        (score8, "ckpt_score_8.model.gz"), (region8, "ckpt_region_8.model.gz")):
+        if os.path.exists(os.path.join(HERE, name)) and "--force" not in sys.argv:
+            print(name, "exists (kept; --force rewrites it)")
+            continue
         cls = model.module.__class__ if hasattr(model, "module") else model.__class__
         assert cls.__module__.startswith("multi_model."), cls.__module__
         buf = io.BytesIO()

@@ -116,6 +116,40 @@ def loss_inputs(seed, n=96, A=4):
     return stage2, refine
 
 
+def circulant_state(key, shape, dtype, seed=8):
+    """numpy-seeded, O(1), WELL-CONDITIONED fill of one state_dict entry that still compresses (the reference-pickled
+    checkpoint fixtures ckpt_*_8.model.gz: 28 MB of fp32 as a few hundred KB).  A weight matrix (O, I, ...) is block
+    circulant: row o is ``g_b`` rotated by ``o mod I`` with ``g_b ~ N(0, 2 / I)`` drawn per block ``b = o // I`` from
+    ``default_rng([seed, crc32(key), b])`` -- every output channel is a lag of the circular correlation of a random vector
+    with the input, so the rows are as decorrelated as independent draws (unlike ckpt_*_7's 13-periodic ramp, whose rows
+    are shifted copies of ONE ramp), while consecutive rows are byte-shifted copies of each other, which LZ77 finds.
+    BatchNorm vectors and biases follow synthetic.seeded_state_dict's distributions.  ``key`` without the DataParallel
+    ``module.`` prefix."""
+    import zlib
+    crc = zlib.crc32(key.encode())
+    leaf = key.rsplit(".", 1)[-1]
+    rng = np.random.default_rng([seed, crc])
+    if leaf == "num_batches_tracked":
+        return torch.zeros(shape, dtype=dtype)
+    if leaf == "running_mean":
+        val = rng.normal(0.0, 0.1, shape)
+    elif leaf == "running_var":
+        val = rng.uniform(0.5, 1.5, shape)
+    elif len(shape) >= 2:
+        O, I = shape[0], int(np.prod(shape[1:]))
+        rows = np.empty((O, I), np.float32)
+        for b in range((O + I - 1) // I):
+            g = (np.random.default_rng([seed, crc, b]).normal(0.0, 1.0, I) * np.sqrt(2.0 / I)).astype(np.float32)
+            idx = (np.arange(I)[None, :] + np.arange(min(I, O - b * I))[:, None]) % I
+            rows[b * I:b * I + idx.shape[0]] = g[idx]
+        val = rows.reshape(shape)
+    elif ".bn" in key or "bn_" in key or key.startswith("bn"):
+        val = rng.uniform(0.8, 1.2, shape) if leaf == "weight" else rng.normal(0.0, 0.1, shape)
+    else:
+        val = rng.normal(0.0, 0.05, shape)
+    return torch.from_numpy(np.asarray(val, dtype=np.float32)).to(dtype)
+
+
 def meta_train():
     with open(os.path.join(GOLDEN, "s4_meta.json")) as f:
         return json.load(f)

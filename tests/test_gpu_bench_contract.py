@@ -33,6 +33,12 @@ def test_bench_line_has_the_contract_fields():
     assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and r["kernel"]
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-5 and 0 < r["frac"] < 1
     assert r["traffic"] is None or r["traffic"] > 0
+    # utilisation figures count EXECUTED flops; the algorithmic count is kept beside them
+    assert r["frac"] == r["frac_executed"] <= r["frac_algorithmic"] and 0 < r["step_frac_executed"] < 1
+    assert r["executed_flop_per_launch"] <= r["algorithmic_units_per_launch"]
+    if r["rocprof_avg_launch_ms"] is not None:
+        assert r["rocprof_source"].startswith("profiles/") and 0 < r["frac_rocprof"] < 1
+    assert d["config"]["executed_gflop_per_scene"] <= d["config"]["launched_gflop_per_scene"] <= d["config"]["scorenet_gflop_per_scene"]
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
     p = d["parity"]
@@ -56,6 +62,10 @@ def test_bench_line_carries_the_round3_fields():
     t = d["train"]
     assert t["scenes_per_s"] > 0 and t["ms_per_step"] > 0 and t["roofline"]["kernel"] == "tgemm_kernel"
     assert t["allreduce_ms"] is None                                # one rank: no collective
+    assert 0 < t["host_ms_per_step"] <= t["ms_per_step"] * 1.05 and t["host_blocked_ms_per_step"] >= 0
+    assert t["distinct_batches"] == 4 and t["bucket_bytes"] is None
+    g = t["gpu_timeline"]
+    assert g is not None and ("error" in g or (g["busy_ms_per_step"] > 0 and g["idle_ms_per_step"] >= 0))
 
 
 def test_bench_small_batch_replays_graphs_and_says_so():
@@ -85,3 +95,10 @@ def test_bench_two_ranks_over_gloo_on_one_device():
     t = d["train"]
     assert "error" not in t, t
     assert t["allreduce_ms"] is not None and t["allreduce_ms"] >= 0 and t["parallelism"].startswith("dp2: ONE flat")
+    # the line describes the process group it ran on: backend / world size as the group reports them, the
+    # rank-id all-reduce proving two distinct ranks, the bucket-sized probe all-reduce
+    c = d["config"]["collective"]
+    assert c["backend"] == "gloo" and c["world_size"] == 2 and c["distinct_ranks_by_allreduce"] == 2
+    assert c["probe_bytes"] == (7066927 + 128) * 4 and c["probe_allreduce_ms"] > 0 and c["bus_GBps"] > 0
+    assert c["rccl_version"] is None                                # gloo here; under RCCL the version tuple is reported
+    assert t["bucket_bytes"] == c["probe_bytes"] - 4 * 128 + 4 * t["bucket_params"] if "bucket_params" in t else t["bucket_bytes"] > 28e6

@@ -731,3 +731,113 @@ def test_few_input_channel_convolution_matches_float64(shape, co):
     x2 = x.detach().clone().requires_grad_(True)
     conv1x1_train.conv1x1(conv, x2).backward(up)
     assert torch.equal(conv.weight.grad, first)
+
+
+def test_batch_without_a_labelled_centre_falls_back_to_the_score_loss():
+    """a batch in which no centre found a ground-truth grasp (every label row -1) must not crash the fused
+    stage-2 loss (it divided by the number of labelled centres on the host): the reference's bare ``except``
+    (train.py:430) trains ScoreNet alone on such a batch, and so does RefineTrainer.step."""
+    from regnet_for_3d_grasping_amd import pipeline, region_losses, synthetic
+    from regnet_for_3d_grasping_amd.gripper_region_network import GripperRegionNetwork
+    from regnet_for_3d_grasping_amd.score_network import ScoreNetwork
+    from regnet_for_3d_grasping_amd.train_step import RefineTrainer
+    from . import golden_util as gu
+    stage2, _ = gu.loss_inputs(3)
+    ground = torch.full_like(stage2["ground"], -1.0).to(DEV)
+    net = GripperRegionNetwork(training=True, group_num=256, gripper_num=64, grasp_score_threshold=0.5, radius=0.06,
+                               reg_channel=10).to(DEV)
+    tmpl = net.templates.float().reshape(-1, 4).to(DEV).contiguous()
+    state = np.random.get_state()[1].copy()
+    with pytest.raises(ValueError):
+        region_losses.stage2_loss(stage2["first_grasp"].to(DEV), stage2["first_cls"].to(DEV), stage2["centres"].to(DEV), tmpl,
+                                  ground, net.radius)
+    assert np.array_equal(np.random.get_state()[1], state)        # nothing drawn from numpy's stream
+    # ... and through the trainer: grasps 10 m away from the scene match no centre
+    B, N = 2, 6144
+    pc = synthetic.make_batch(8700, B, N)
+    records = [synthetic.make_grasp_labels(pc[b].numpy(), 30 + b) for b in range(B)]
+    for rec in records:
+        rec["frame"][:, :3, 3] += 10.0
+    target = torch.from_numpy(np.random.default_rng(8).uniform(0, 1, (B, N)).astype(np.float32))
+    s = ScoreNetwork(training=True)
+    s.load_state_dict(synthetic.seeded_state_dict(s, 3))
+    r = GripperRegionNetwork(training=True, group_num=256, gripper_num=64, grasp_score_threshold=0.5, radius=0.06,
+                             reg_channel=10)
+    r.load_state_dict(synthetic.seeded_state_dict(r, 4))
+    t = RefineTrainer(s.to(DEV), r.to(DEV), pipeline.PARAMS, pipeline.GRIPPER_PARAMS)
+    before = [p.detach().clone() for p in t.region_net.parameters()]
+    np.random.seed(21)
+    loss, parts = t.step(pc.to(DEV), target.to(DEV), records)
+    assert "region_error" in parts and "labelled centre" in parts["region_error"], parts.get("region_error")
+    assert torch.isfinite(loss) and abs(float(loss) - float(parts["score"])) < 1e-6      # the ScoreNet loss alone
+    assert all(torch.isfinite(p).all() for p in t.score_net.parameters())
+    assert all(torch.equal(a, b) for a, b in zip(before, t.region_net.parameters()))      # the region network did not move
+
+
+def test_other_regression_widths_take_the_tensor_path():
+    """``reg_channel`` is a constructor parameter; the fused loss kernels are instantiated for the reference's 10
+    channels (and <= 64 anchors) only.  Any other configuration must take the tensor code (as the reference does), not fail
+    inside the kernel's argument check -- which the trainer would record as a region error on every step."""
+    from regnet_for_3d_grasping_amd import region_losses
+    x_reg = torch.zeros((8, 4, 12), device=DEV)
+    x_cls = torch.zeros((8, 4), device=DEV)
+    centres = torch.zeros((8, 6), device=DEV)
+    ground = torch.zeros((1, 8, 12), device=DEV)
+    assert not region_losses.usable_stage2(x_reg, x_cls, centres, ground)
+    assert region_losses.usable_stage2(x_reg[:, :, :10].contiguous(), x_cls, centres, ground)
+    assert not region_losses.usable_stage2(x_reg[:, :, :10].contiguous(), x_cls, centres, ground[:, :, :8])
+    assert not region_losses.usable_stage2(torch.zeros((8, 65, 10), device=DEV), torch.zeros((8, 65), device=DEV), centres, ground)
+    grasp, gt = torch.zeros((8, 10), device=DEV), torch.zeros((8, 10), device=DEV)
+    assert region_losses.usable_refine(grasp, torch.zeros((8, 2), device=DEV), torch.zeros((8, 10), device=DEV), gt)
+    assert not region_losses.usable_refine(grasp, torch.zeros((8, 2), device=DEV), torch.zeros((8, 12), device=DEV), gt)
+    assert not region_losses.usable_refine(grasp, torch.zeros((8, 2), device=DEV), torch.zeros((8, 10), device=DEV), gt[:, :8])
+
+
+def test_config3_training_iteration_8x25600():
+    """BASELINE.json configs[3]'s per-GPU shard VERBATIM (global batch 16 over 2 GPUs = 8 scenes of 25 600 points per
+    rank): the forward losses of the full ``--mode train`` iteration (train.py:347-384) against the oracle-backed CPU
+    mirror at the real shard size -- score loss 1e-5 absolute, stage-2 / refine / total 1e-3 relative -- with the region
+    head's affine set so that the refine loss runs on real rows; then an optimizer step."""
+    from oracle.install import oracle_backend
+    from regnet_for_3d_grasping_amd import pipeline, pn2_ext, synthetic
+    from regnet_for_3d_grasping_amd.gripper_region_network import GripperRegionNetwork
+    from regnet_for_3d_grasping_amd.score_network import ScoreNetwork
+    from regnet_for_3d_grasping_amd.train_step import RefineTrainer
+    B, N = 8, 25600
+    pc = synthetic.make_batch(8800, B, N)
+    records = [synthetic.make_grasp_labels(pc[b].numpy(), 110 + b) for b in range(B)]
+    target = torch.from_numpy(np.random.default_rng(9).uniform(0, 1, (B, N)).astype(np.float32))
+
+    def build(dev):
+        s = ScoreNetwork(training=True)
+        s.load_state_dict(synthetic.seeded_state_dict(s, 3))
+        r = GripperRegionNetwork(training=True, group_num=256, gripper_num=64, grasp_score_threshold=0.5,
+                                 radius=0.06, reg_channel=10)
+        r.load_state_dict(synthetic.seeded_state_dict(r, 4))
+        synthetic.set_region_head_affine(r)
+        s.extrat_featurePN2.mlp.dropout_prob = 0.0
+        t = RefineTrainer(s.to(dev), r.to(dev), pipeline.PARAMS, pipeline.GRIPPER_PARAMS)
+        t.score_net.train(); t.region_net.train()
+        return t
+
+    cpu, gpu = build("cpu"), build(DEV)
+    with oracle_backend(), torch.no_grad():
+        np.random.seed(16)
+        total_ref, parts_ref = cpu.forward_losses(pc, target, records)
+    np.random.seed(16)
+    with torch.no_grad():
+        total, parts = gpu.forward_losses(pc.to(DEV), target.to(DEV), records)
+    assert "region_error" not in parts and "region_error" not in parts_ref
+    assert abs(float(parts["score"]) - float(parts_ref["score"])) < 1e-5
+    assert abs(float(parts["stage2"]) - float(parts_ref["stage2"])) <= 1e-3 * abs(float(parts_ref["stage2"]))
+    assert parts["refine"] is not None and parts_ref["refine"] is not None and float(parts_ref["refine"]) > 0
+    assert abs(float(parts["refine"]) - float(parts_ref["refine"])) <= 1e-3 * abs(float(parts_ref["refine"]))
+    assert abs(float(total) - float(total_ref)) <= 1e-3 * abs(float(total_ref)), (float(total), float(total_ref))
+    print("configs[3] shard 8 x 25 600: total loss %.6f (CPU mirror %.6f), stage-2 %.6f, refine %.6f" % (
+        float(total), float(total_ref), float(parts["stage2"]), float(parts["refine"])))
+    np.random.seed(17)
+    l1, p1 = gpu.step(pc.to(DEV), target.to(DEV), records)
+    assert torch.isfinite(l1) and "region_error" not in p1
+    for net in (gpu.score_net, gpu.region_net):
+        assert all(torch.isfinite(p).all() for p in net.parameters())
+    pn2_ext.raise_if_fps_failed()
