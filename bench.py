@@ -78,6 +78,9 @@ def parse():
     ap.add_argument("--no-lookahead-steps", type=int, default=20,
                     help="steps of the extra pass AFTER the timed region with one sampling launch per batch and no enlarged "
                          "first launch (value_no_lookahead); 0 = skip")
+    ap.add_argument("--real-density-steps", type=int, default=20,
+                    help="steps of the extra pass AFTER the timed region over density-matched scenes (synthetic.make_scene(density="
+                         "'real'): level-1 neighbourhood sizes like the reference's own clouds) for value_real_density; 0 = skip")
     ap.add_argument("--lookahead", type=int, default=3, help="batches whose region stage may be pending (pipeline depth)")
     ap.add_argument("--geometry-ahead", type=int, default=1, help="batches whose ball-query / 3-NN geometry is queued ahead of the feature stage")
     ap.add_argument("--graphs", choices=("auto", "on", "off"), default="auto",
@@ -803,6 +806,40 @@ def main():
         torch.cuda.synchronize()
         no_lookahead = args.batch * args.no_lookahead_steps / (time.perf_counter() - t1)
 
+    real_density = None
+    if world == 1 and args.real_density_steps > 0:
+        # SURVEY 8(d) "real-density variant": the SAME pipeline configuration and weights over scenes whose level-1
+        # neighbourhood sizes match the reference's own clouds (mean 49.5 members, 23 % <= 32, 49 % full: the uniform scenes
+        # above have 30 % <= 32 and 19 % full) -- sa_chain_kernel skips less on them.  After the timed region.
+        pcs_r = []
+        for k in range(distinct):
+            seeds = sharding.scene_seeds(rank, world, args.batch, step=k)
+            pcs_r.append(torch.from_numpy(np.stack([synthetic.make_scene(s_, args.points, density="real") for s_ in seeds], 0)).to(dev))
+        pipe_r = pipeline.ForwardPipeline(score_net, region_net, with_region=not args.score_only, fps_streams=args.fps_streams,
+                                          mlp_streams=args.mlp_streams, fps_group=args.fps_group,
+                                          first_launch_groups=args.first_launch_groups, geometry_ahead=args.geometry_ahead,
+                                          graphs={"auto": "auto", "on": True, "off": False}[args.graphs])
+        was_enabled, timer.enabled = timer.enabled, False
+        for _ in pipe_r.run((pcs_r[k % distinct] for k in range(max(2, args.warmup))), max_pending_regions=args.lookahead):
+            pass
+        torch.cuda.synchronize()
+        stats_r = []
+        t1 = time.perf_counter()
+        for last in pipe_r.run((pcs_r[k % distinct] for k in range(args.real_density_steps)), max_pending_regions=args.lookahead):
+            if "next_grasp" in last:
+                stats_r.append(last.get("valid_crops"))
+        torch.cuda.synchronize()
+        dt_r = time.perf_counter() - t1
+        timer.enabled = was_enabled
+        real_density = {"value": round(args.batch * args.real_density_steps / dt_r, 3), "unit": "scenes/s",
+                        "ms_per_step": round(dt_r / args.real_density_steps * 1e3, 3), "steps": args.real_density_steps,
+                        "valid_crops_per_step": (None if not stats_r or any(v is None for v in stats_r)
+                                                 else round(sum(stats_r) / len(stats_r), 1)),
+                        "scenes": "synthetic.make_scene(seed, %d, density='real'), seeds as the headline's; histogram target "
+                                  "tests/golden/real_density_hist.json (scripts/real_density_hist.py)" % args.points,
+                        "level1_balls": sa_chain_executed_share(score_net, pcs_r)}
+        del pcs_r, pipe_r
+
     exclusive = None
     if args.mlp_streams > 1 and world == 1 and args.exclusive_steps > 0:
         # per-kernel accounting without feature stages overlapping each other: a short extra pass (outside the timed
@@ -953,6 +990,9 @@ def main():
             "roofline": roofline,
             "roofline_exclusive": None,
             "latency_ms_single_scene": latency_ms,
+            # the same pipeline on density-matched scenes (level-1 neighbourhoods like the reference's clouds), after the timed region
+            "value_real_density": None if real_density is None else real_density["value"],
+            "real_density": real_density,
             "value_no_lookahead": None if no_lookahead is None else round(no_lookahead, 3),
             "value_no_lookahead_note": None if no_lookahead is None else (
                 "%d steps after the timed region, --fps-group 1 --first-launch-groups 1 (one sampling launch per batch, "

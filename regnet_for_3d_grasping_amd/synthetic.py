@@ -9,13 +9,31 @@ import numpy as np
 import torch
 
 
-def make_scene(seed, num_points=25600):
+# density="real": relative areal point densities of four bands of the table (and of the boxes standing in them) and the
+# share of the table's length each band takes -- fitted with scripts/real_density_fit.py so that the level-1 neighbourhood
+# sizes (r = 0.02, K = 64, 5 120 FPS centroids) reproduce the reference clouds' histogram (tests/golden/real_density_hist.json,
+# derived by scripts/real_density_hist.py from test_file/*_predict/*.p in the authoring container): mean 49.5 members,
+# 23 % of the neighbourhoods with <= 32, 43 % with <= 48, 49 % full
+REAL_DENSITY_BANDS = ((0.245, 18.5), (0.26, 31.0), (0.08, 44.0), (0.415, 71.0))
+REAL_DENSITY_TABLE = (0.34, 0.30)      # half extents of the table of the density="real" scenes (m)
+
+
+def make_scene(seed, num_points=25600, density="uniform"):
     """One table-top scene as float32 ``(num_points, 6)`` = xyz + rgb, order-shuffled.
 
     60 % of the points lie on a table plane (z = 0.75 m with 1 mm noise); 40 % on the visible
     faces (top, +x side, +y side) of eight boxes standing on it.  Point order is a random
     permutation -- ball-query early exit depends on it.
+
+    ``density="uniform"`` (every fixture and the bench headline): table points uniform over the table.
+    ``density="real"``: the same geometry on a smaller table whose areal point density varies in bands along x the way a
+    depth camera's does with range (``REAL_DENSITY_BANDS``), matched to the reference clouds' level-1 neighbourhood-size
+    histogram -- what decides how much work ``sa_chain_kernel`` skips (SURVEY.md 8d "real-density variant").
     """
+    if density == "real":
+        return _make_scene_real(seed, num_points)
+    if density != "uniform":
+        raise ValueError("density must be 'uniform' or 'real'")
     rng = np.random.default_rng(seed)
     n_table = int(round(num_points * 0.6))
     n_obj = num_points - n_table
@@ -44,9 +62,47 @@ def make_scene(seed, num_points=25600):
     return scene[rng.permutation(num_points)]
 
 
-def make_batch(first_seed, batch, num_points=25600, device="cpu"):
+def _make_scene_real(seed, num_points):
+    rng = np.random.default_rng([seed, 4])
+    hx_t, hy_t = REAL_DENSITY_TABLE
+    share = np.array([b[0] for b in REAL_DENSITY_BANDS])
+    dens = np.array([b[1] for b in REAL_DENSITY_BANDS])
+    edges = -hx_t + 2.0 * hx_t * np.concatenate([[0.0], np.cumsum(share)])          # band i = [edges[i], edges[i + 1]) in x
+    n_boxes = 8
+    centre = rng.uniform([-hx_t + 0.06, -hy_t + 0.06], [hx_t - 0.06, hy_t - 0.06], (n_boxes, 2))
+    half = rng.uniform(0.02, 0.06, (n_boxes, 3))
+    box_band = np.clip(np.searchsorted(edges, centre[:, 0], side="right") - 1, 0, len(dens) - 1)
+    # expected points of every surface piece = area x relative density, scaled to num_points
+    table_area = share * (2.0 * hx_t) * (2.0 * hy_t)
+    face_area = np.stack([4.0 * half[:, 0] * half[:, 1], 4.0 * half[:, 1] * half[:, 2], 4.0 * half[:, 0] * half[:, 2]], 1)
+    weight = np.concatenate([table_area * dens, (face_area * dens[box_band][:, None]).reshape(-1)])
+    piece = rng.choice(len(weight), num_points, p=weight / weight.sum())
+    u = rng.uniform(-1.0, 1.0, num_points)
+    v = rng.uniform(-1.0, 1.0, num_points)
+    xyz = np.empty((num_points, 3), np.float64)
+    nb = len(dens)
+    on_table = piece < nb
+    band = np.where(on_table, piece, 0)
+    xyz[:, 0] = np.where(on_table, edges[band] + (u + 1.0) * 0.5 * (edges[band + 1] - edges[band]), 0.0)
+    xyz[:, 1] = np.where(on_table, v * hy_t, 0.0)
+    xyz[:, 2] = np.where(on_table, 0.75 + rng.normal(0.0, 0.001, num_points), 0.0)
+    k = np.where(on_table, 0, piece - nb)
+    box, face = k // 3, k % 3                                                          # 0 top, 1 +x side, 2 +y side
+    hx, hy, hz = half[box, 0], half[box, 1], half[box, 2]
+    top, sx, sy = face == 0, face == 1, face == 2
+    ox = centre[box, 0] + np.where(sx, hx, u * hx)
+    oy = centre[box, 1] + np.where(sy, hy, np.where(sx, u * hy, v * hy))
+    oz = 0.75 + np.where(top, 2.0 * hz, (v + 1.0) * hz)
+    obj = ~on_table
+    xyz[obj, 0], xyz[obj, 1], xyz[obj, 2] = ox[obj], oy[obj], oz[obj]
+    rgb = rng.uniform(0.0, 1.0, (num_points, 3))
+    scene = np.concatenate([xyz, rgb], 1).astype(np.float32)
+    return scene[rng.permutation(num_points)]
+
+
+def make_batch(first_seed, batch, num_points=25600, device="cpu", density="uniform"):
     """``(batch, num_points, 6)`` float32; scene ``i`` uses seed ``first_seed + i``."""
-    arr = np.stack([make_scene(first_seed + i, num_points) for i in range(batch)], 0)
+    arr = np.stack([make_scene(first_seed + i, num_points, density) for i in range(batch)], 0)
     return torch.from_numpy(arr).to(device)
 
 

@@ -1,7 +1,7 @@
 # what bench.py's own HIP-event brackets cost the step: --time-every 8 (default) vs sparser, alternating
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 for steps in 20 200; do
-COMMON="--steps $steps --warmup 5 --cpu-scenes 0 --latency-runs 0 --train-steps 0 --no-lookahead-steps 0"
+COMMON="--steps $steps --warmup 5 --cpu-scenes 0 --latency-runs 0 --train-steps 0 --no-lookahead-steps 0 --real-density-steps 0"
 for rep in 1 2; do
   for te in 8 32 100000; do
     timeout 300 python bench.py $COMMON --time-every $te 2>/dev/null | python -c "

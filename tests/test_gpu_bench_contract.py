@@ -101,4 +101,4 @@ def test_bench_two_ranks_over_gloo_on_one_device():
     assert c["backend"] == "gloo" and c["world_size"] == 2 and c["distinct_ranks_by_allreduce"] == 2
     assert c["probe_bytes"] == (7066927 + 128) * 4 and c["probe_allreduce_ms"] > 0 and c["bus_GBps"] > 0
     assert c["rccl_version"] is None                                # gloo here; under RCCL the version tuple is reported
-    assert t["bucket_bytes"] == c["probe_bytes"] - 4 * 128 + 4 * t["bucket_params"] if "bucket_params" in t else t["bucket_bytes"] > 28e6
+    assert 28e6 < t["bucket_bytes"] < 29e6          # both networks' 7 066 927 gradients + one presence flag per parameter, fp32
