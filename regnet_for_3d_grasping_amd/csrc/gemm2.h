@@ -263,16 +263,18 @@ __device__ __forceinline__ void g2_tile(const G2Args& p, float* smem, long long 
 #endif
 // slabs where the second accumulator set fits the register budget of the tile's occupancy: wave tiles of 32 accumulator
 // registers (64 x 32: the 64 x 128 x 4-wave tile, 74 -> 104 of 128 VGPRs at 4 waves per SIMD; 32 x 64: the 128 x 128 x 8-wave
-// tile).  Wave tiles of 64 x 64 (128 x 128 x 4 waves: 118 -> 168 + 51 spilled at 3 waves per SIMD; 256 x 128 x 8 waves: 116 of
-// 128) keep one chain.
-template <int TBM, int TBN, int WM, int WN> struct G2Slab {
-  static constexpr int kt = ((TBM / WM / 32) * (TBN / WN / 32) <= 2) ? G2_SLAB_KT : 0;
+// tile), and wave tiles of 64 (64 x 64) when the launch asks for at most TWO waves per SIMD -- 256 registers per wave: the
+// 128 x 128 x 4-wave tile at two workgroups per CU, 180 VGPRs, no spill (round 5).  At 3-4 waves per SIMD the 64 x 64 wave
+// tiles (128 x 128 x 4 waves at 3 workgroups per CU: 118 -> 168 + 51 spilled; 256 x 128 x 8 waves: 116 of 128) keep one chain.
+template <int TBM, int TBN, int WM, int WN, int WG_PER_CU> struct G2Slab {
+  static constexpr int acc_tiles = (TBM / WM / 32) * (TBN / WN / 32);
+  static constexpr int kt = (acc_tiles <= 2 || (acc_tiles <= 4 && WG_PER_CU * WM * WN <= 8)) ? G2_SLAB_KT : 0;
 };
 
 template <int TBM, int TBN, int WM, int WN, int STAGES, int WG_PER_CU, bool POOL>
 __global__ __launch_bounds__(WM * WN * 64, WG_PER_CU * WM * WN / 4)
 void gemm2_kernel(const G2Args p) {
-  constexpr int SLAB = G2Slab<TBM, TBN, WM, WN>::kt;
+  constexpr int SLAB = G2Slab<TBM, TBN, WM, WN, WG_PER_CU>::kt;
   constexpr int TM = TBM / WM / 32;
   __shared__ __attribute__((aligned(1024))) float smem[STAGES * (TBM + TBN) * G2_BK];
   const int bid = blockIdx.x;

@@ -515,9 +515,17 @@ static int launch_gemm2(const G2Args& g, bool pool, hipStream_t st) {
   if (force_tile == 1) return launch_gemm2_tile<128, 128, 2, 2, 3, 3>(g, pool, st);
   if (force_tile == 2) return launch_gemm2_tile<64, 128, 1, 4, 3, 4>(g, pool, st);
   if (force_tile == 3 && !pool) return launch_gemm2_tile<128, 128, 4, 2, 3, 2>(g, pool, st);   // 8 waves of 32 x 64: slabs fit
+  if (force_tile == 8 && !pool) return launch_gemm2_tile<128, 128, 2, 2, 3, 2>(g, pool, st);   // 4 waves of 64 x 64 at 2 workgroups per CU: slabs fit
   const long long nt = (g.N + 127) / 128;
   const long long t256 = ((g.P + 255) / 256) * nt, t128 = ((g.P + 127) / 128) * nt;
   if (g.N > 128 && t256 >= 4 * G2_CUS) return launch_gemm2_tile<256, 128, 4, 2, 3, 2>(g, pool, st);
+  // two or more slabs of K and at least one 128 x 128 tile per CU: four waves of 64 x 64 at two workgroups per CU -- at two waves
+  // per SIMD a wave has 256 registers, which hold the slab sums next to the 64 accumulator registers (180 VGPRs, no spill),
+  // and a 64 x 64 wave tile reads half the LDS bytes per MFMA of the 64 x 32 one.  Same order of additions as the 64 x 128
+  // tile: bit-identical.  Stand-alone on the step's shapes 4-7 % faster (profiles/r05_plain_layer_tiles.txt).
+  static const bool t8 = !(getenv("REGNET_G2_T8") && getenv("REGNET_G2_T8")[0] == '0');                 // A/B measurements only
+  if (t8 && !pool && G2_SLAB_KT > 0 && g.Kpad >= 2 * G2_SLAB_KT * G2_BK && t128 >= G2_CUS)
+    return launch_gemm2_tile<128, 128, 2, 2, 3, 2>(g, pool, st);
   // (only the 64 x 128 tile has the registers for slab accumulation -- gemm2.h: G2Slab -- so a layer with two or more
   // slabs of K takes it even where the 128 x 128 tile would be ~6 % faster: P = 40 960, N = 512, K = 256 / 512 of the
   // ScoreNet forward, +18 us per step for 0.55e-5 of parity margin, profiles/r04_error_budget.txt)
