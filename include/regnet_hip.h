@@ -167,6 +167,12 @@ int regnet_box_crop_f32(const float* group_points, int64_t gb, int64_t gn, const
  * feat (num_rows,F) row-major, rows (R,G) int64 -> out (R,F).                                    */
 int regnet_gather_max_f32(const float* feat, int64_t num_rows, int64_t F, const int64_t* rows,
                           int64_t R, int64_t G, float* out, void* stream);
+/* regnet_gather_max_scene_f32: the same with the reference's `index + b * N` (gripper_region_network.py:388, :334) formed in
+ * the address: output row r pools the index list rows[rid], rid = row_ids ? row_ids[r] : r (int64 device, R entries), whose
+ * entries are LOCAL point ids of scene rid / per_scene; global feature row = entry + (rid / per_scene) * scene_stride.
+ * Negative entries are skipped.  Needs F % 4 == 0 and a 16-byte aligned feat (REGNET_ERR_UNSUPPORTED otherwise).          */
+int regnet_gather_max_scene_f32(const float* feat, int64_t num_rows, int64_t F, const int64_t* rows, const int64_t* row_ids,
+                                int64_t R, int64_t G, int64_t per_scene, int64_t scene_stride, float* out, void* stream);
 
 /* ---- per-point shared-MLP contraction on fp32 MFMA (channels-last activations) ---------------
  * Replaces the cuDNN/cuBLAS 1x1-conv + BatchNorm + ReLU chains the reference runs for
@@ -245,6 +251,26 @@ int regnet_sa_chain3_f32(const float* feat, int64_t fb, int64_t fn, int64_t fc, 
 int regnet_pack_rows_f32(const float* feat, int64_t fb, int64_t fc, int64_t fn, int64_t Cf, const float* xyz,
                          int64_t xb, int64_t xc, int64_t xn, int64_t B, int64_t N, int64_t W, float* out,
                          void* stream);
+/* regnet_pack_rows_centred_f32: the same with the xyz columns written as xyz - mu[b] (mu (B,3) contiguous device floats, or
+ * NULL = regnet_pack_rows_f32): the scene-mean centring of the pre-multiplied first layer (fused.PREMUL_CENTRE) inside the
+ * pack instead of as a tensor subtraction in front of it -- one fp32 subtraction per value either way, same bits.          */
+int regnet_pack_rows_centred_f32(const float* feat, int64_t fb, int64_t fc, int64_t fn, int64_t Cf, const float* xyz,
+                                 int64_t xb, int64_t xc, int64_t xn, const float* mu, int64_t B, int64_t N, int64_t W,
+                                 float* out, void* stream);
+
+/* ---- gather_points (multi_model/utils/pn2_utils/function.py:11-26; callers modules.py:41, :238) ---------------------
+ * out[b][c][m] = points[b][c][index[b][m]]: points element (b,c,n) at points[b*pb + c*pc + n*pn], index (b,m) at
+ * index[b*ib + m*im] (int64), out element (b,c,m) at out[b*ob + c*oc + m*om].  An index outside [0, N) writes 0 and ORs 1
+ * into *status (device int32, may be NULL) -- torch.gather raises for it; the Python wrapper checks lazily.                  */
+int regnet_gather_points_f32(const float* points, int64_t pb, int64_t pc, int64_t pn, int64_t B, int64_t C, int64_t N,
+                             const int64_t* index, int64_t ib, int64_t im, int64_t M, float* out, int64_t ob, int64_t oc,
+                             int64_t om, int32_t* status, void* stream);
+
+/* regnet_class_order_i64: order (n) int64 = the stable sort permutation of the level-1 neighbourhoods by cost class
+ * (count > 32) + (count > 48) -- what torch.argsort(class, stable=True) returns (fused.chain3_order; the processing order
+ * of regnet_sa_chain3_f32) -- as a three-bin counting sort in one launch.  count (n) int64 device (regnet_ball_query_f32's
+ * second output), n <= 2^24.                                                                                                 */
+int regnet_class_order_i64(const int64_t* count, int64_t n, int64_t* order, void* stream);
 
 /* regnet_grasp_collision_counts_f32 / regnet_grasp_antipodal_stats_f32: the per-grasp point scans of the reference's grasp
  * evaluation, dataset_utils/eval_score/eval.py:4-24 -> eval_utils/evaluation_data_generator.py (EvalDataTest /

@@ -41,6 +41,7 @@ SIGNATURES = {
     "regnet_select_positive_f32": (_int, [_vp, _i64, _i64, _vp, _i64, _i64, _i64, _f32, _vp, _vp, _vp, _vp]),
     "regnet_box_crop_f32": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _f32, _i64, _i64, _vp, _vp, _vp]),
     "regnet_gather_max_f32": (_int, [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _vp]),
+    "regnet_gather_max_scene_f32": (_int, [_vp, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
     "regnet_gripper_frame_f32": (_int, [_vp, _i64, _i64, _vp, _vp, _vp]),
     "regnet_stage2_loss_rows_f32": (_int, [_vp, _vp, _i64, _i64, _vp, _i64, _vp, _vp, _i64, _f32, _vp, _vp, _i64, _vp, _vp, _vp,
                                            _vp, _vp, _vp, _vp]),
@@ -82,6 +83,9 @@ SIGNATURES = {
                                             _vp, _vp, _vp]),
     "regnet_bn_train_stats_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "regnet_pack_rows_f32": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp]),
+    "regnet_pack_rows_centred_f32": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _vp]),
+    "regnet_gather_points_f32": (_int, [_vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _vp]),
+    "regnet_class_order_i64": (_int, [_vp, _i64, _vp, _vp]),
     "regnet_sa_premul_layer_f32": (_int, [_vp, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _vp, _vp,
                                           _vp, _i64, _i64, _int, _int, _vp]),
     "regnet_sa_layer12_f32": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _i64,

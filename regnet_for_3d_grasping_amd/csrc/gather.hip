@@ -254,8 +254,8 @@ extern "C" int regnet_gather_knn_bwd_f32(const float* grad_out, int64_t sb, int6
 // one launch instead of a zero fill and two strided copies.  feat element (b,c,n) at feat[b*fb + c*fc + n*fn].
 __global__ __launch_bounds__(256) void pack_rows_kernel(const float* __restrict__ feat, long long fb, long long fc,
                                                         long long fn, int Cf, const float* __restrict__ xyz, long long xb,
-                                                        long long xc, long long xn, long long N, int W,
-                                                        float* __restrict__ out, long long total) {
+                                                        long long xc, long long xn, const float* __restrict__ mu, long long N,
+                                                        int W, float* __restrict__ out, long long total) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;   // one output element per thread, channel fastest
   if (i >= total) return;
   const long long row = i / W;
@@ -263,13 +263,16 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const float* __restrict_
   const long long b = row / N, n = row - b * N;
   float v = 0.f;
   if (c < Cf) v = feat[b * fb + (long long)c * fc + n * fn];
-  else if (c < Cf + 3) v = xyz[b * xb + (long long)(c - Cf) * xc + n * xn];
+  else if (c < Cf + 3) {
+    v = xyz[b * xb + (long long)(c - Cf) * xc + n * xn];
+    if (mu) v = v - mu[3 * b + (c - Cf)];          // one fp32 subtraction: what `xyz - mu` computed as a tensor first
+  }
   out[i] = v;
 }
 
-extern "C" int regnet_pack_rows_f32(const float* feat, int64_t fb, int64_t fc, int64_t fn, int64_t Cf, const float* xyz,
-                                    int64_t xb, int64_t xc, int64_t xn, int64_t B, int64_t N, int64_t W, float* out,
-                                    void* stream) {
+extern "C" int regnet_pack_rows_centred_f32(const float* feat, int64_t fb, int64_t fc, int64_t fn, int64_t Cf, const float* xyz,
+                                            int64_t xb, int64_t xc, int64_t xn, const float* mu, int64_t B, int64_t N,
+                                            int64_t W, float* out, void* stream) {
   if (B < 0 || N < 0 || Cf < 0 || W < Cf + 3) return REGNET_ERR_SHAPE;
   const long long total = B * N * W;
   if (total == 0) return REGNET_OK;
@@ -277,8 +280,103 @@ extern "C" int regnet_pack_rows_f32(const float* feat, int64_t fb, int64_t fc, i
   const long long blocks = (total + 255) / 256;
   if (blocks >= (1ll << 31)) return REGNET_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), feat, (long long)fb,
-                     (long long)fc, (long long)fn, (int)Cf, xyz, (long long)xb, (long long)xc, (long long)xn,
+                     (long long)fc, (long long)fn, (int)Cf, xyz, (long long)xb, (long long)xc, (long long)xn, mu,
                      (long long)N, (int)W, out, total);
+  REGNET_LAUNCH_CHECK();
+  return REGNET_OK;
+}
+
+extern "C" int regnet_pack_rows_f32(const float* feat, int64_t fb, int64_t fc, int64_t fn, int64_t Cf, const float* xyz,
+                                    int64_t xb, int64_t xc, int64_t xn, int64_t B, int64_t N, int64_t W, float* out,
+                                    void* stream) {
+  return regnet_pack_rows_centred_f32(feat, fb, fc, fn, Cf, xyz, xb, xc, xn, nullptr, B, N, W, out, stream);
+}
+
+// ---- gather_points (pn2_utils/function.py:11-26): out[b][c][m] = points[b][c][index[b][m]], any strides on both sides.
+// One thread per output element, m fastest (the centroid gather of every set-abstraction level: (B,3,N) -> (B,3,M); with the
+// strides swapped also rows of a (B,N,C) cloud: the grasp centres, get_regiondataset.py:288).  An index outside [0, N) flags
+// the launch (status word) and writes 0 -- torch.gather raises for it.
+__global__ __launch_bounds__(256) void gather_points_kernel(const float* __restrict__ pts, long long pb, long long pc,
+                                                            long long pn, long long N, const long long* __restrict__ idx,
+                                                            long long ib, long long im, int C, long long M,
+                                                            float* __restrict__ out, long long ob, long long oc, long long om,
+                                                            long long total, int* __restrict__ status) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const long long m = i % M;
+  const long long t = i / M;
+  const int c = (int)(t % C);
+  const long long b = t / C;
+  const long long n = idx[b * ib + m * im];
+  float v = 0.f;
+  if (n >= 0 && n < N) v = pts[b * pb + (long long)c * pc + n * pn];
+  else if (status) atomicOr(status, 1);
+  out[b * ob + (long long)c * oc + m * om] = v;
+}
+
+extern "C" int regnet_gather_points_f32(const float* points, int64_t pb, int64_t pc, int64_t pn, int64_t B, int64_t C, int64_t N,
+                                        const int64_t* index, int64_t ib, int64_t im, int64_t M, float* out, int64_t ob,
+                                        int64_t oc, int64_t om, int32_t* status, void* stream) {
+  if (B < 0 || C < 0 || N < 0 || M < 0) return REGNET_ERR_SHAPE;
+  const long long total = B * C * M;
+  if (total == 0) return REGNET_OK;
+  if (!points || !index || !out) return REGNET_ERR_NULL;
+  const long long blocks = (total + 255) / 256;
+  if (blocks >= (1ll << 31) || C >= (1ll << 31)) return REGNET_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(gather_points_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), points, (long long)pb,
+                     (long long)pc, (long long)pn, (long long)N, (const long long*)index, (long long)ib, (long long)im, (int)C,
+                     (long long)M, out, (long long)ob, (long long)oc, (long long)om, total, status);
+  REGNET_LAUNCH_CHECK();
+  return REGNET_OK;
+}
+
+// ---- processing order of the level-1 neighbourhoods by cost class (fused.chain3_order): class = (count > 32) + (count > 48),
+// order = the STABLE sort permutation by class (what torch.argsort(stable=True) of the class ids returns): a three-bin
+// counting sort by one workgroup -- per-thread counts over contiguous chunks, an exclusive scan over (class, thread), one
+// scatter.  n <= 2^24 elements (8 x 5 120 in a step).
+#define CO_THREADS 1024
+__global__ __launch_bounds__(CO_THREADS) void class_order_kernel(const long long* __restrict__ count, long long n,
+                                                                 long long* __restrict__ order) {
+  __shared__ int cnt[3][CO_THREADS];
+  __shared__ int base[3];
+  const int t = threadIdx.x;
+  const long long per = (n + CO_THREADS - 1) / CO_THREADS;
+  const long long lo = (long long)t * per, hi = lo + per < n ? lo + per : n;
+  int c0 = 0, c1 = 0, c2 = 0;
+  for (long long i = lo; i < hi; ++i) {
+    const long long c = count[i];
+    const int k = (c > 32) + (c > 48);
+    c0 += k == 0; c1 += k == 1; c2 += k == 2;
+  }
+  cnt[0][t] = c0; cnt[1][t] = c1; cnt[2][t] = c2;
+  __syncthreads();
+  // exclusive scan of each class over the threads (Hillis-Steele on three rows at once)
+  for (int off = 1; off < CO_THREADS; off <<= 1) {
+    int a0 = 0, a1 = 0, a2 = 0;
+    if (t >= off) { a0 = cnt[0][t - off]; a1 = cnt[1][t - off]; a2 = cnt[2][t - off]; }
+    __syncthreads();
+    cnt[0][t] += a0; cnt[1][t] += a1; cnt[2][t] += a2;
+    __syncthreads();
+  }
+  if (t == 0) {
+    base[0] = 0; base[1] = cnt[0][CO_THREADS - 1]; base[2] = cnt[0][CO_THREADS - 1] + cnt[1][CO_THREADS - 1];
+  }
+  __syncthreads();
+  int p0 = base[0] + cnt[0][t] - c0, p1 = base[1] + cnt[1][t] - c1, p2 = base[2] + cnt[2][t] - c2;   // inclusive -> exclusive
+  for (long long i = lo; i < hi; ++i) {
+    const long long c = count[i];
+    const int k = (c > 32) + (c > 48);
+    if (k == 0) order[p0++] = i; else if (k == 1) order[p1++] = i; else order[p2++] = i;
+  }
+}
+
+extern "C" int regnet_class_order_i64(const int64_t* count, int64_t n, int64_t* order, void* stream) {
+  if (n < 0) return REGNET_ERR_SHAPE;
+  if (n == 0) return REGNET_OK;
+  if (n > (1ll << 24)) return REGNET_ERR_UNSUPPORTED;
+  if (!count || !order) return REGNET_ERR_NULL;
+  hipLaunchKernelGGL(class_order_kernel, dim3(1), dim3(CO_THREADS), 0, as_stream(stream), (const long long*)count, (long long)n,
+                     (long long*)order);
   REGNET_LAUNCH_CHECK();
   return REGNET_OK;
 }

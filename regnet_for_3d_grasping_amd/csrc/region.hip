@@ -538,7 +538,7 @@ extern "C" int regnet_grasp_antipodal_stats_f32(const float* points, int64_t pn,
 
 // out[r, ch] = max_g feat[rows[r, g], ch]: the grouped-feature gather fused with MaxPool1d(G).
 // feat is (num_rows, F) row-major (= all_feature.view(B*N, F)); one workgroup per output row,
-// threads across channels so every gathered row is one coalesced F*4-byte read.
+// threads across channels so every gathered row is one coalesced F*4-byte read.  (F not a multiple of 4 or unaligned rows.)
 __global__ __launch_bounds__(256) void gather_max_kernel(const float* __restrict__ feat, int64_t num_rows, int F,
                                                         const int64_t* __restrict__ rows, int G,
                                                         float* __restrict__ out) {
@@ -554,16 +554,85 @@ __global__ __launch_bounds__(256) void gather_max_kernel(const float* __restrict
   }
 }
 
-extern "C" int regnet_gather_max_f32(const float* feat, int64_t num_rows, int64_t F, const int64_t* rows, int64_t R,
-                                     int64_t G, float* out, void* stream) {
-  if (num_rows < 0 || F < 0 || R < 0 || G <= 0) return REGNET_ERR_SHAPE;
+// The same for 16-byte rows (F % 4 == 0, aligned feat), round 5: a lane reads a float4, a wave one 1 KB row piece, the four
+// waves of a workgroup take every fourth group member with FOUR rows in flight each (16 independent 1 KB reads per workgroup,
+// 8 workgroups per CU), and the waves' partial maxima meet in 4 KB of LDS.  A maximum does not depend on the order: same bits.
+// Optional addressing by scene: row id rid = row_ids ? row_ids[r] : r selects the index list rows[rid]; its entries are LOCAL
+// to scene rid / per_scene and scene_stride rows apart (per_scene == 0: global row ids as above) -- the reference's
+// `index + b * N` (gripper_region_network.py:388, :334) formed in the address instead of as an (R, G) int64 tensor.
+__global__ __launch_bounds__(256) void gather_max_v4_kernel(const float* __restrict__ feat, int64_t num_rows, int F,
+                                                           const int64_t* __restrict__ rows, const int64_t* __restrict__ row_ids,
+                                                           int G, int64_t per_scene, int64_t scene_stride,
+                                                           float* __restrict__ out) {
+  __shared__ float4 part[4][64];
+  const int64_t r = blockIdx.x;
+  const int64_t rid = row_ids ? row_ids[r] : r;
+  const int64_t* idx = rows + rid * G;
+  const int64_t base = per_scene > 0 ? (rid / per_scene) * scene_stride : 0;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const float ninf = -__builtin_inff();
+  for (int c0 = 0; c0 < F; c0 += 256) {
+    const int ch = c0 + 4 * lane;
+    float4 m = make_float4(ninf, ninf, ninf, ninf);
+    if (ch < F) {
+      for (int g = wave; g < G; g += 16) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int gg = g + 4 * u;
+          int64_t row = gg < G ? idx[gg] : -1;
+          if (row >= 0) row += base;
+          v[u] = (row >= 0 && row < num_rows) ? *reinterpret_cast<const float4*>(feat + row * F + ch)
+                                              : make_float4(ninf, ninf, ninf, ninf);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          m.x = fmaxf(m.x, v[u].x); m.y = fmaxf(m.y, v[u].y); m.z = fmaxf(m.z, v[u].z); m.w = fmaxf(m.w, v[u].w);
+        }
+      }
+    }
+    part[wave][lane] = m;
+    __syncthreads();
+    {
+      const int t = threadIdx.x;                                  // channel c0 + t: component t & 3 of lane t >> 2
+      const float* p0 = reinterpret_cast<const float*>(&part[0][0]);
+      float y = fmaxf(fmaxf(p0[t], p0[256 + t]), fmaxf(p0[512 + t], p0[768 + t]));
+      if (c0 + t < F) out[r * F + c0 + t] = y;
+    }
+    __syncthreads();
+  }
+}
+
+static int launch_gather_max(const float* feat, int64_t num_rows, int64_t F, const int64_t* rows, const int64_t* row_ids,
+                             int64_t R, int64_t G, int64_t per_scene, int64_t scene_stride, float* out, void* stream) {
+  if (num_rows < 0 || F < 0 || R < 0 || G <= 0 || per_scene < 0 || scene_stride < 0) return REGNET_ERR_SHAPE;
   if (F >= (int64_t)1 << 31 || G >= (int64_t)1 << 31 || R >= (int64_t)1 << 31) return REGNET_ERR_UNSUPPORTED;
   if (R == 0 || F == 0) return REGNET_OK;
   if (!feat || !rows || !out) return REGNET_ERR_NULL;
-  hipLaunchKernelGGL(gather_max_kernel, dim3((unsigned)R), dim3(256), 0, as_stream(stream), feat, num_rows, (int)F,
-                     rows, (int)G, out);
+  const bool v4 = (F % 4 == 0) && ((reinterpret_cast<uintptr_t>(feat) & 15) == 0);
+  if (!v4) {
+    if (row_ids || per_scene > 0) return REGNET_ERR_UNSUPPORTED;    // (the scene-addressed form exists for 16-byte rows only)
+    hipLaunchKernelGGL(gather_max_kernel, dim3((unsigned)R), dim3(256), 0, as_stream(stream), feat, num_rows, (int)F,
+                       rows, (int)G, out);
+  } else {
+    hipLaunchKernelGGL(gather_max_v4_kernel, dim3((unsigned)R), dim3(256), 0, as_stream(stream), feat, num_rows, (int)F,
+                       rows, row_ids, (int)G, per_scene, scene_stride, out);
+  }
   REGNET_LAUNCH_CHECK();
   return REGNET_OK;
+}
+
+extern "C" int regnet_gather_max_f32(const float* feat, int64_t num_rows, int64_t F, const int64_t* rows, int64_t R,
+                                     int64_t G, float* out, void* stream) {
+  return launch_gather_max(feat, num_rows, F, rows, nullptr, R, G, 0, 0, out, stream);
+}
+
+extern "C" int regnet_gather_max_scene_f32(const float* feat, int64_t num_rows, int64_t F, const int64_t* rows,
+                                           const int64_t* row_ids, int64_t R, int64_t G, int64_t per_scene,
+                                           int64_t scene_stride, float* out, void* stream) {
+  if (per_scene <= 0) return REGNET_ERR_SHAPE;
+  return launch_gather_max(feat, num_rows, F, rows, row_ids, R, G, per_scene, scene_stride, out, stream);
 }
 
 // Training twin of gather_max_kernel: also records WHICH row gave the maximum (the backward scatters R x F values instead

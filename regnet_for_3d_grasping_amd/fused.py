@@ -236,16 +236,21 @@ def _premul_layers(first, Cf):
 
 
 @_on_tensor_device
-def pack_rows(feature, xyz, width):
-    """Channels-last rows [feature | xyz | 0] of every point: feature (B,Cf,N) or None, xyz (B,3,N) -> (B*N, width)."""
+def pack_rows(feature, xyz, width, mu=None):
+    """Channels-last rows [feature | xyz - mu | 0] of every point: feature (B,Cf,N) or None, xyz (B,3,N), mu (B,3,1) or None
+    -> (B*N, width)."""
     B, _, N = xyz.shape
     out = torch.empty((B * N, width), dtype=torch.float32, device=xyz.device)
     if feature is None:
         fptr, fb, fc, fn, Cf = None, 0, 0, 0, 0
     else:
         fptr, (fb, fc, fn), Cf = feature.data_ptr(), feature.stride(), feature.size(1)
-    _check(_L.regnet_pack_rows_f32(fptr, fb, fc, fn, Cf, xyz.data_ptr(), *xyz.stride(), B, N, width, out.data_ptr(),
-                                   _stream(xyz)), "pack_rows")
+    if mu is not None:
+        mu = mu.reshape(B, 3)
+        mu = mu if mu.is_contiguous() else mu.contiguous()
+    _check(_L.regnet_pack_rows_centred_f32(fptr, fb, fc, fn, Cf, xyz.data_ptr(), *xyz.stride(),
+                                           None if mu is None else mu.data_ptr(), B, N, width, out.data_ptr(),
+                                           _stream(xyz)), "pack_rows")
     return out
 
 
@@ -266,6 +271,8 @@ def chain3_order(count):
     """Processing order of sa_chain3's neighbourhoods by cost class (<= 32 members, 33..48, more), stable within a class.
     (The expensive class first instead: 994-1 005 against 995-1 000 scenes/s over three alternations -- no difference.)"""
     c = count.reshape(-1)
+    if c.is_cuda and c.dtype == torch.int64 and c.numel() <= (1 << 24):
+        return pn2_ext.class_order(c)       # a three-bin counting sort in one launch (six tensor ops + a radix sort before)
     return torch.argsort((c > 32).to(torch.uint8) + (c > 48).to(torch.uint8), stable=True)
 
 
@@ -431,7 +438,7 @@ def sa_group(module, xyz, ctr, first_tie=None):
     """Centroid gather + ball query given the sampled indices (modules.py:41, :238-239).  ``first_tie``: of the run that
     sampled ``ctr`` (kept in the plan: the next level's ``prefix_ok``)."""
     B, M = ctr.shape
-    new_xyz = torch.gather(xyz, 2, ctr[:, None, :].expand(B, 3, M))
+    new_xyz = pn2_ext.gather_points(xyz, ctr) if xyz.dtype == torch.float32 else torch.gather(xyz, 2, ctr[:, None, :].expand(B, 3, M))
     nbr, count = pn2_ext.ball_query(xyz, new_xyz, module.grouper.radius, module.grouper.num_neighbours)
     geo = {"ctr": ctr, "new_xyz": new_xyz, "nbr": nbr}
     if first_tie is not None:
@@ -455,12 +462,9 @@ def sa_group(module, xyz, ctr, first_tie=None):
         first = layers[0]
         if first.relu and first.N % 4 == 0 and layers[1].K == first.N:
             _, v_layer = _premul_layers(first, Cf)
-            if PREMUL_CENTRE:
-                mu = xyz.mean(dim=2, keepdim=True)
-                geo["src_xyz"], ctr_xyz = xyz - mu, new_xyz - mu
-            else:
-                geo["src_xyz"], ctr_xyz = xyz, new_xyz
-            geo["V"] = mlp_layer(pack_rows(None, ctr_xyz, 4), 4, v_layer, B * M)
+            # (the subtraction of the scene mean happens inside the packs: pack_rows(..., mu))
+            geo["mu"] = xyz.mean(dim=2, keepdim=True) if PREMUL_CENTRE else None
+            geo["V"] = mlp_layer(pack_rows(None, new_xyz, 4, geo["mu"]), 4, v_layer, B * M)
             # V = W_xyz . centre with the first layer's BatchNorm folded in: a function of the WEIGHTS too, unlike the rest
             # of the plan.  sa_features recomputes it when the block's weights changed since (a plan reused across an
             # optimizer step / load_state_dict)
@@ -516,19 +520,14 @@ def sa_features(module, xyz, feature, geo):
         # coordinates RELATIVE TO THE SCENE'S MEAN (the difference is unchanged, the magnitudes -- table-top scenes sit
         # ~0.75 m from the origin -- and with them the cancellation error of the subtraction shrink)
         if "V" in geo and geo.get("V_signature") == _signature(module.mlp):
-            src_xyz, V = geo["src_xyz"], geo["V"]       # already done by the geometry stage (sa_group), same weights
+            mu, V = geo["mu"], geo["V"]                  # already done by the geometry stage (sa_group), same weights
         elif "V" in geo:                                 # stale: the weights moved after the plan was made
-            src_xyz = geo["src_xyz"]
-            ctr_xyz = geo["new_xyz"] - xyz.mean(dim=2, keepdim=True) if PREMUL_CENTRE else geo["new_xyz"]
-            V = mlp_layer(pack_rows(None, ctr_xyz, 4), 4, v_layer, B * M)
+            mu = geo["mu"]
+            V = mlp_layer(pack_rows(None, geo["new_xyz"], 4, mu), 4, v_layer, B * M)
         else:
-            if PREMUL_CENTRE:
-                mu = xyz.mean(dim=2, keepdim=True)
-                src_xyz, ctr_xyz = xyz - mu, geo["new_xyz"] - mu
-            else:
-                src_xyz, ctr_xyz = xyz, geo["new_xyz"]
-            V = mlp_layer(pack_rows(None, ctr_xyz, 4), 4, v_layer, B * M)
-        U = mlp_layer(pack_rows(feature, src_xyz, width), width, u_layer, B * N1)
+            mu = xyz.mean(dim=2, keepdim=True) if PREMUL_CENTRE else None
+            V = mlp_layer(pack_rows(None, geo["new_xyz"], 4, mu), 4, v_layer, B * M)
+        U = mlp_layer(pack_rows(feature, xyz, width, mu), width, u_layer, B * N1)
         if supports_sa3_chain(layers) and U.size(1) == 512:
             # level 3: the same with 512-wide activations (layer 2 as two K-halves, csrc/rowchain.hip)
             pooled = sa3_premul_chain(U, V, geo["nbr"], module, layers, B, N1, M)

@@ -41,6 +41,13 @@ def _pool_rows(all_feature, rows):
     return flat[rows.reshape(-1)].view(rows.shape[0], rows.shape[1], F).max(dim=1)[0].unsqueeze(-1)
 
 
+def _scene_pool(all_feature, index):
+    """True when the pooling kernel can address by scene (region_ops.gather_max_scene): eval on the GPU, 16-byte feature
+    rows, int64 local indices."""
+    return (all_feature.is_cuda and not torch.is_grad_enabled() and all_feature.dim() == 3 and all_feature.shape[2] % 4 == 0
+            and all_feature.dtype == torch.float32 and index.dtype == torch.int64 and index.is_cuda)
+
+
 class _RowsCache(threading.local):
     """Per THREAD (a training call and an inference call on two threads must not see each other's copy)."""
     ref = None
@@ -267,13 +274,19 @@ class GripperRegionNetwork(nn.Module):
         out = [None, None, None, None, None, (None, None), (None, None), next_gt]
         self.last_valid_crops = int(len(gripper_mask))    # rows of the refine network in this call (host-known, no sync)
         if len(gripper_mask) >= 2:
-            if all_kept:
+            if all_kept and _scene_pool(all_feature, index_inall) and gripper_mask.dtype == torch.int64:
+                scene_off = None
+            elif all_kept:
                 scene_off = _scene_offsets(B, N_C, N, true_mask.device)
             else:
                 scene = torch.arange(B, device=true_mask.device).view(-1, 1).repeat(1, N_C).view(-1)[true_mask]
                 scene_off = scene.view(-1, 1) * N
-            rows = (index_inall.long() + scene_off)[gripper_mask]
-            gripper_feature = _pool_rows(all_feature, rows)                       # (m, F, 1)
+            if all_kept and _scene_pool(all_feature, index_inall) and gripper_mask.dtype == torch.int64:
+                gripper_feature = region_ops.gather_max_scene(_contiguous_rows(all_feature), index_inall, gripper_mask, N_C,
+                                                              N).unsqueeze(-1)
+            else:
+                rows = (index_inall.long() + scene_off)[gripper_mask]
+                gripper_feature = _pool_rows(all_feature, rows)                   # (m, F, 1)
             region_feature = group_feature_mp.view(-1, 128)[gripper_mask].contiguous()  # the 128-wide re-view quirk
             next_x_cls, next_x_reg = self.extrat_feature_refine(gripper_feature, region_feature, pooled=True)
             if next_gt is not None:
@@ -304,8 +317,13 @@ class GripperRegionNetwork(nn.Module):
         if large_groups is None:
             pc_group_more_xyz = pc_group_more[:, :, :, :6].reshape(B * N_C, -1, 6)
 
-        rows = (pc_group_index.long().view(B, N_C * N_G) + _scene_offsets(B, 1, N, pc_group_index.device)).view(B * N_C, N_G)
-        pooled = _pool_rows(all_feature, rows)                                    # (B*N_C, F, 1)
+        if _scene_pool(all_feature, pc_group_index):
+            # inference on the GPU: the reference's `index + b * N` is formed in the pooling kernel's address, not as a tensor
+            pooled = region_ops.gather_max_scene(_contiguous_rows(all_feature), pc_group_index.view(B * N_C, N_G), None,
+                                                 N_C, N).unsqueeze(-1)
+        else:
+            rows = (pc_group_index.long().view(B, N_C * N_G) + _scene_offsets(B, 1, N, pc_group_index.device)).view(B * N_C, N_G)
+            pooled = _pool_rows(all_feature, rows)                                # (B*N_C, F, 1)
         # inference without labels on the GPU: the head hands its regression over raw and ONE kernel decodes the arg-max
         # anchor of every centre (region_ops.stage2_decode) -- no anchor tensor, no gathers; every centre is kept
         fast = (ground_grasp is None and pooled.is_cuda and not torch.is_grad_enabled() and center_pc.dtype == torch.float32
@@ -464,8 +482,13 @@ def get_gripper_region_transform(group_points, group_index, grasp, region_num, g
         pos_t, valid_t = np_random.choice_rows_device(count.int(), region_num, 1, G)
     else:
         np_random.flush()
-        pos, valid = np_random.choice_rows(count.cpu().numpy(), region_num, 1)
-        pos_t, valid_t = torch.from_numpy(pos).to(dev), torch.from_numpy(valid).to(dev)
+        if count.is_cuda:
+            pos_pinned, valid = np_random.choice_rows_pinned(count.cpu().numpy(), region_num, 1)
+            pos_t = pos_pinned.to(dev, non_blocking=True)
+        else:
+            pos, valid = np_random.choice_rows(count.cpu().numpy(), region_num, 1)
+            pos_t = torch.from_numpy(pos).to(dev)
+        valid_t = torch.from_numpy(valid).to(dev)
         valid_ids = torch.from_numpy(np.nonzero(valid)[0]).to(dev)    # (the host knows which crops are valid: no device nonzero)
     if valid_ids is None:
         valid_ids = torch.nonzero(valid_t).view(-1)     # data-dependent length: the one synchronisation of the crop

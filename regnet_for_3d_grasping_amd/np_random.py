@@ -29,6 +29,27 @@ def choice_rows(counts, size, mode):
     return out.reshape(counts32.shape + (size,)), valid.astype(bool).reshape(counts32.shape)
 
 
+def choice_rows_pinned(counts, size, mode):
+    """``choice_rows`` with the positions written straight into PINNED host memory: -> (positions int64 torch tensor
+    counts.shape + (size,) in page-locked memory, valid bool ndarray).  ``positions.to(device, non_blocking=True)`` is then an
+    asynchronous DMA transfer (no staging copy, no blit kernel on the CUs: the drawn positions of a batch of 8 are 5 MB);
+    torch's host allocator keeps the block alive until that copy has run."""
+    import torch
+    counts32 = np.ascontiguousarray(counts, dtype=np.int32)
+    rows = counts32.size
+    out = torch.empty((rows, int(size)), dtype=torch.int64, pin_memory=True)
+    valid = np.empty((rows,), dtype=np.uint8)
+    name, key, pos, has_gauss, cached = np.random.get_state()
+    if name != "MT19937":
+        raise RuntimeError("numpy's global generator is not MT19937")
+    key = np.ascontiguousarray(key, dtype=np.uint32).copy()
+    cpos = ctypes.c_int32(int(pos))
+    _check(_L.regnet_np_choice_rows(key.ctypes.data, ctypes.addressof(cpos), counts32.ctypes.data, rows, int(size),
+                                    int(mode), out.data_ptr(), valid.ctypes.data), "np_choice_rows")
+    np.random.set_state((name, key, int(cpos.value), has_gauss, cached))
+    return out.view(tuple(counts32.shape) + (int(size),)), valid.astype(bool).reshape(counts32.shape)
+
+
 # ---- the same draws on the DEVICE (csrc/np_random_dev.hip): numpy's generator state lives in HBM -----------------------
 class _DeviceStream:
     """numpy's global MT19937 state, resident on one GPU.

@@ -97,6 +97,43 @@ def farthest_point_sample(points, num_centroids, chain=None):
     return index
 
 
+def gather_points(points, index, channels_last=False):
+    """points (B,C,N) float32, index (B,M) int64 -> (B,C,M): ``points[b, :, index[b, m]]`` (pn2_utils/function.py:11-26's
+    ``torch.gather``) as one native launch; any strides.  ``channels_last``: the result as a contiguous (B,M,C) tensor (rows of
+    a (B,N,C) cloud handed in as its transposed view).  An index outside [0, N) flags the device's status word
+    (``raise_if_fps_failed`` reports it where the caller synchronises) and yields 0."""
+    _need_f32(points, "points")
+    _need_i64(index, "index")
+    _eq(points.dim(), 3, "points must be (B, C, N)")
+    _eq(index.dim(), 2, "index must be (B, M)")
+    _eq(points.size(0), index.size(0), "points and index differ in batch size")
+    B, C, N = points.shape
+    M = index.size(1)
+    with torch.cuda.device(points.device):
+        if channels_last:
+            out = torch.empty((B, M, C), dtype=torch.float32, device=points.device)
+            ob, om, oc = out.stride()
+        else:
+            out = torch.empty((B, C, M), dtype=torch.float32, device=points.device)
+            ob, oc, om = out.stride()
+        _check(_L.regnet_gather_points_f32(points.data_ptr(), *points.stride(), B, C, N, index.data_ptr(), *index.stride(), M,
+                                           out.data_ptr(), ob, oc, om, _fps_flag(points.device).data_ptr(),
+                                           _stream(points)), "gather_points")
+    return out
+
+
+def class_order(count):
+    """count (...) int64 GPU tensor of ball-query member counts -> (count.numel(),) int64: the stable sort permutation by cost
+    class (count > 32) + (count > 48) (``torch.argsort(cls, stable=True)``), one launch (regnet_class_order_i64)."""
+    _need_i64(count, "count")
+    flat = count.reshape(-1)
+    flat = flat if flat.is_contiguous() else flat.contiguous()
+    with torch.cuda.device(count.device):
+        order = torch.empty((flat.numel(),), dtype=torch.int64, device=count.device)
+        _check(_L.regnet_class_order_i64(flat.data_ptr(), flat.numel(), order.data_ptr(), _stream(count)), "class_order")
+    return order
+
+
 _fps_flags = {}
 
 
@@ -116,7 +153,8 @@ def raise_if_fps_failed():
         if int(flag.item()):
             flag.zero_()
             raise RuntimeError("farthest_point_sample: a cooperating workgroup lost its partner (launch not fully "
-                               "resident?); the returned indices are incomplete")
+                               "resident?) -- the returned indices are incomplete -- or gather_points saw an index "
+                               "outside the cloud")
 
 
 def ball_query(points, centroids, radius, num_neighbours):

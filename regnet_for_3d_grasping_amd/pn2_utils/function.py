@@ -14,6 +14,9 @@ from .. import pn2_ext
 def gather_points(points, index):
     """points (B,C,N), index (B,M) -> (B,C,M): pick columns (function.py:11-26)."""
     b, c, _ = points.shape
+    if (points.is_cuda and points.dtype == torch.float32 and index.dtype == torch.int64 and index.is_cuda
+            and not (torch.is_grad_enabled() and points.requires_grad)):
+        return pn2_ext.gather_points(points, index)          # one native launch (csrc/gather.hip)
     return torch.gather(points, 2, index[:, None, :].expand(b, c, index.size(1)))
 
 

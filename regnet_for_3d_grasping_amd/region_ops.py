@@ -295,6 +295,27 @@ def crop_pick(cand, pos, valid, group_index):
     return index, index_inall
 
 
+def gather_max_scene(feature_rows, index, row_ids, per_scene, scene_stride):
+    """``gather_max`` with the scene offset formed in the address: feature_rows (B*N, F) contiguous (F % 4 == 0), index
+    (R_all, G) int64 LOCAL point ids per centre, row_ids (R,) int64 or None (= every row of ``index``), scene of row id r
+    = r // per_scene, its feature rows start at scene * scene_stride -> (R, F) max over G (negative ids are skipped)."""
+    _need_f32(feature_rows, "feature_rows")
+    _need_i64(index, "index")
+    feature_rows, index = feature_rows.contiguous(), index.contiguous()
+    G = index.shape[1]
+    F = feature_rows.shape[1]
+    if row_ids is not None:
+        _need_i64(row_ids, "row_ids")
+        row_ids = row_ids.contiguous()
+    R = index.shape[0] if row_ids is None else row_ids.numel()
+    with torch.cuda.device(feature_rows.device):
+        out = torch.empty((R, F), dtype=torch.float32, device=feature_rows.device)
+        _check(_L.regnet_gather_max_scene_f32(feature_rows.data_ptr(), feature_rows.shape[0], F, index.data_ptr(),
+                                              None if row_ids is None else row_ids.data_ptr(), R, G, int(per_scene),
+                                              int(scene_stride), out.data_ptr(), _stream(feature_rows)), "gather_max_scene")
+    return out
+
+
 def gather_max(feature_rows, rows):
     """feature_rows (R_all,F) contiguous, rows (R,G) int64 global row ids -> (R,F) max over G."""
     _need_f32(feature_rows, "feature_rows")
