@@ -56,15 +56,31 @@ def _stamp():
 
 
 REPO = os.path.dirname(os.path.dirname(HERE))
-# measurement twins of product sources (scripts/ablate/): the product translation units carry no measurement branches
-MEASURE_SOURCES = {"geometry.hip": os.path.join(REPO, "scripts", "ablate", "geometry_measure.hip")}
+# measurement twins of product sources: the product translation units carry no measurement branches; a twin is GENERATED from
+# the product source by a committed patch (scripts/ablate/*.patch) at build time, so it cannot drift behind the product --
+# a patch that no longer applies fails the measurement build instead of measuring another kernel
+MEASURE_PATCHES = {"geometry.hip": os.path.join(REPO, "scripts", "ablate", "geometry_measure.patch")}
+
+
+def measurement_twin(src, out_dir):
+    """Apply the measurement patch of product source ``src`` (a name in MEASURE_PATCHES) and return the generated file's path."""
+    os.makedirs(out_dir, exist_ok=True)
+    out = os.path.join(out_dir, src.replace(".hip", "_measure.hip"))
+    with open(MEASURE_PATCHES[src], "rb") as f:
+        patch = f.read()
+    res = subprocess.run(["patch", "-s", "-o", out, os.path.join(HERE, src)], input=patch, stdout=subprocess.PIPE,
+                         stderr=subprocess.STDOUT)
+    if res.returncode != 0:
+        raise RuntimeError("%s no longer applies to csrc/%s (re-base the measurement branches):\n%s" % (
+            MEASURE_PATCHES[src], src, res.stdout.decode(errors="replace")))
+    return out
 CHAIN_TRACE = ["-DCH_TRACE_H=\"%s\"" % os.path.join(REPO, "scripts", "ablate", "chain_trace.h")]
 
 
 def build_variant(out_path, defines, measure=False):
     """An extra copy of the library with -D defines applied to every source (A/B measurements only, e.g.
     ``build_variant('/tmp/x.so', ['-DRC_WAVES=4'])``); the product library is ``build()``'s.  ``measure=True`` swaps in
-    the measurement twins of ``MEASURE_SOURCES`` (the FPS_ABLATE / FPS_ONE_BARRIER / FPS_FORCE_MULTI branches live there)."""
+    the measurement twins generated from ``MEASURE_PATCHES`` (the FPS_ABLATE / FPS_ONE_BARRIER / FPS_FORCE_MULTI branches)."""
     hipcc = _hipcc()
     objs = []
     tmp = out_path + ".objs"
@@ -72,7 +88,7 @@ def build_variant(out_path, defines, measure=False):
     procs = []
     for src, extra in SOURCES:
         obj = os.path.join(tmp, src.replace(".hip", ".o"))
-        path = MEASURE_SOURCES.get(src, os.path.join(HERE, src)) if measure else os.path.join(HERE, src)
+        path = measurement_twin(src, tmp) if (measure and src in MEASURE_PATCHES) else os.path.join(HERE, src)
         procs.append(subprocess.Popen([hipcc] + COMMON + extra + ["-I", HERE] + list(defines) + ["-c", path, "-o", obj]))
         objs.append(obj)
     for p in procs:

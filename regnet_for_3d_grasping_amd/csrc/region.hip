@@ -99,34 +99,43 @@ extern "C" int regnet_radius_group_f32(const float* pc, int64_t pb, int64_t pn, 
 // coordinates in the same order, and every slot behind them repeats the FIRST positive (so a
 // furthest-point-sampling launch over a common, longer prefix of all scenes gives each scene the result of
 // sampling its own positives: a copy of the start point is at distance 0 from the selected set for ever).
-__global__ __launch_bounds__(1024) void select_positive_kernel(const float* __restrict__ pc, int64_t pb, int64_t pn,
-                                                               const float* __restrict__ score, int64_t sb, int N,
-                                                               float thr, int64_t* __restrict__ index,
-                                                               float* __restrict__ xyz_out, int32_t* __restrict__ count) {
-  __shared__ int wave_cnt[16];
-  __shared__ int base_s;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// Two passes, two barriers (round 5; before: N / 1024 rounds of three barriers each, 370 us per call beside the matrix
+// kernels): every wave owns a contiguous segment of the scene, counts its hits with ballots, the 16 segment totals are scanned,
+// and the wave walks its segment again writing each hit at (segment base + hits so far + hits in lower lanes).
+#define SP_WAVES 16
+__global__ __launch_bounds__(SP_WAVES * 64) void select_positive_kernel(const float* __restrict__ pc, int64_t pb, int64_t pn,
+                                                                       const float* __restrict__ score, int64_t sb, int N,
+                                                                       float thr, int64_t* __restrict__ index,
+                                                                       float* __restrict__ xyz_out, int32_t* __restrict__ count) {
+  __shared__ int wave_cnt[SP_WAVES];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.x;
   const float* p = pc + (int64_t)b * pb;
   const float* sc = score + (int64_t)b * sb;
   int64_t* idx = index + (int64_t)b * N;
   float* xo = xyz_out + (int64_t)b * 3 * N;
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
-  if (tid == 0) base_s = 0;
+  const int seg = ((N + SP_WAVES - 1) / SP_WAVES + 63) / 64 * 64;      // segment length: whole 64-point steps
+  const int lo = wave * seg, hi = lo + seg < N ? lo + seg : N;
+  int mine = 0;
+  for (int j0 = lo; j0 < hi; j0 += 64) {
+    const int j = j0 + lane;
+    mine += (int)__popcll(__ballot(j < hi && sc[j] > thr));
+  }
+  if (lane == 0) wave_cnt[wave] = mine;
   __syncthreads();
-  for (int j0 = 0; j0 < N; j0 += 1024) {
-    const int j = j0 + tid;
-    const bool hit = j < N && sc[j] > thr;
-    const unsigned long long m = __ballot(hit);
-    if (lane == 0) wave_cnt[wave] = (int)__popcll(m);
-    __syncthreads();
-    int before = base_s, total = 0;
+  int before = 0, cnt = 0;
 #pragma unroll
-    for (int w = 0; w < 16; ++w) {
-      const int v = wave_cnt[w];
-      before += w < wave ? v : 0;
-      total += v;
-    }
+  for (int w = 0; w < SP_WAVES; ++w) {
+    const int v = wave_cnt[w];
+    before += w < wave ? v : 0;
+    cnt += v;
+  }
+  for (int j0 = lo; j0 < hi; j0 += 64) {
+    const int j = j0 + lane;
+    const bool hit = j < hi && sc[j] > thr;
+    const unsigned long long m = __ballot(hit);
     if (hit) {
       const int pos = before + (int)__popcll(m & lt_mask);
       const float* r = p + (int64_t)j * pn;
@@ -135,17 +144,14 @@ __global__ __launch_bounds__(1024) void select_positive_kernel(const float* __re
       xo[N + pos] = r[1];
       xo[2 * N + pos] = r[2];
     }
-    __syncthreads();
-    if (tid == 0) base_s += total;
-    __syncthreads();
+    before += (int)__popcll(m);
   }
-  const int cnt = base_s;
   if (tid == 0) count[b] = cnt;
   if (cnt == 0) return;
   __threadfence_block();
   __syncthreads();
   const float fx = xo[0], fy = xo[N], fz = xo[2 * N];   // written by this workgroup above
-  for (int j = cnt + tid; j < N; j += 1024) {
+  for (int j = cnt + tid; j < N; j += SP_WAVES * 64) {
     xo[j] = fx;
     xo[N + j] = fy;
     xo[2 * N + j] = fz;
@@ -159,7 +165,7 @@ extern "C" int regnet_select_positive_f32(const float* pc, int64_t pb, int64_t p
   if (N >= (int64_t)1 << 31 || B >= (int64_t)1 << 31) return REGNET_ERR_UNSUPPORTED;
   if (B == 0) return REGNET_OK;
   if (!count || (N > 0 && (!pc || !score || !index || !xyz_out))) return REGNET_ERR_NULL;
-  hipLaunchKernelGGL(select_positive_kernel, dim3((unsigned)B), dim3(1024), 0, as_stream(stream), pc, pb, pn, score, sb,
+  hipLaunchKernelGGL(select_positive_kernel, dim3((unsigned)B), dim3(SP_WAVES * 64), 0, as_stream(stream), pc, pb, pn, score, sb,
                      (int)N, threshold, index, xyz_out, count);
   REGNET_LAUNCH_CHECK();
   return REGNET_OK;

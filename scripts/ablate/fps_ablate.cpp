@@ -3,7 +3,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
-#include "geometry_measure.hip"   // the measurement twin of csrc/geometry.hip (build with -I regnet_for_3d_grasping_amd/csrc)
+#include "geometry_measure.hip"   // the measurement twin GENERATED from csrc/geometry.hip: python -c "from regnet_for_3d_grasping_amd.csrc import build; build.measurement_twin('geometry.hip', 'scripts/ablate')" first (build with -I regnet_for_3d_grasping_amd/csrc)
 
 int main(int argc, char** argv) {
   int B = 8, N = argc > 1 ? atoi(argv[1]) : 25600, M = argc > 2 ? atoi(argv[2]) : 5120;

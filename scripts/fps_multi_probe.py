@@ -1,6 +1,6 @@
 """MEASURE (not argue) a 2-4-CU cooperative furthest point sampling at N = 25 600: the library's fps_multi_kernel -- the
 kernel that serves scenes beyond one CU's register file -- forced onto single-CU-sized scenes by measurement builds
-(-DFPS_FORCE_MULTI=G of scripts/ablate/geometry_measure.hip, built here with csrc/build.py:build_variant(measure=True)), against the default
+(-DFPS_FORCE_MULTI=G of the measurement twin csrc/build.py generates from csrc/geometry.hip + scripts/ablate/geometry_measure.patch, build_variant(measure=True)), against the default
 single-workgroup fps_sorted_kernel<25>.  One subprocess per library; outputs are compared bit for bit.
 
     python scripts/fps_multi_probe.py build      # authoring container (hipcc cross-compiles)
