@@ -925,7 +925,7 @@ def main():
                 # another run of this command on another box: durations differ by a few per cent)
                 roofline["frac_rocprof"] = round(roofline["executed_flop_per_launch"] / (rp_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 6)
             # whole step: executed flops of ALL matrix kernels of a batch / ms_per_step / peak
-            roofline["step_frac_executed"] = round(executed_gflop * args.batch / (dt / args.steps * 1e3) / 1e3
+            roofline["step_frac_executed"] = round(executed_gflop * args.batch / (dt / args.steps * 1e3)   # GFLOP / ms = TFLOP/s
                                                    / MFMA_F32_PEAK_TFLOPS, 6)
             roofline["frac_note"] = ("frac / achieved / frac_rocprof count EXECUTED flops (sa_chain_kernel skips padded point tiles: "
                                      "executed_share_of_algorithmic_flops); frac_algorithmic / achieved_algorithmic count SURVEY "

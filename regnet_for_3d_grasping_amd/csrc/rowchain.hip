@@ -47,6 +47,13 @@ typedef float rc_f32x4 __attribute__((ext_vector_type(4)));
 #define RC_SPREAD_FETCH 0                      // 1: a stage's LDS-DMA pieces are issued between its MFMA steps (measured 2 %
                                                // SLOWER per kernel, same step time); 0: all right behind the barrier
 #endif
+#ifndef RC_MIDSYNC
+#define RC_MIDSYNC (RC_WAVES == 8 && !RC_SPREAD_FETCH)   // 1: fp_head_chain / sa_premul_chain meet in the MIDDLE of a stage (ring of 4)
+#endif
+#define RC_MID_STAGES (RC_MIDSYNC ? 4 : RC_STAGES)
+#ifndef RC_SYNC_STEP
+#define RC_SYNC_STEP 7                         // the step (0 .. 15) of a stage behind which its barrier + fetch sit
+#endif
 #define RC_AFFINE_MAX 4096                     // floats of folded BN affine kept in LDS
 #define RC_INTERP_FLOATS 1536                  // + the interpolating prologue's tables: Wd4 (256 x 4) | scale1 (256) | shift1 (256)
 
@@ -82,9 +89,26 @@ __device__ __forceinline__ void rc_glds16(const float* gsrc, unsigned lds_dst) {
 template <int N> __device__ __forceinline__ void rc_wait_barrier() {
   asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "i"(N) : "memory");
 }
+// A workgroup barrier that orders LDS traffic only (__syncthreads() also waits for vmcnt(0): inside a pass that DRAINS the
+// ring's two or three stages in flight -- a load latency of stall per use; it was used twice per 24-stage block).
+__device__ __forceinline__ void rc_barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// The weight-stream ring.  Stage s of the (periodic) stream lives in ring slot s % RC_STAGES.
+// The weight-stream ring.  Stage s of the (periodic) stream lives in ring slot s % STAGES.
+//
+// Two hand-over schemes (round 5):
+//  MID = false (3 slots; rounds 2-4, still sa_premul_chain_kernel): the barrier sits at the
+//    stage BOUNDARY -- acquire() waits for the next stage, everybody meets, the stage behind the ones in flight is fetched into
+//    the slot consumed last.  Every stage then starts with the matrix pipe empty: barrier, four LDS-DMA issues with their
+//    address arithmetic, the first fragment's LDS round trip -- on both waves of a SIMD at once, because the barrier released
+//    them together (measured: 14 % of fp_head_chain_kernel's shader cycles per block are not MFMA issue, ~1 300 per stage).
+//  MID = true (4 slots; fp_head_chain_kernel, sa3_premul_chain_kernel): the barrier sits in the MIDDLE of a stage (step
+//    RC_SYNC_STEP of 16).  At that point every wave is inside stage s, so the slot of stage s - 1 is free: the fetch of stage
+//    s + 3 goes there; and the counted wait in front of the barrier makes stage s + 1 readable for everybody.  The stage
+//    boundary itself needs nothing: a wave runs from the last MFMA of stage s into the first fragment reads of stage s + 1
+//    without meeting anyone, and the DMA issue + barrier happen between two MFMA steps whose operands are already in registers.
+template <int STAGES, bool MID>
 struct RcRing {
+  static constexpr bool mid = MID;
   const float* src;        // this lane's source of piece 0 of the next stage to fetch
   const float* src_begin;  // ... of stream stage 0
   int fetch_idx;           // stream index (0 .. n_stages) of the next stage to fetch
@@ -93,6 +117,16 @@ struct RcRing {
   unsigned lds_lo, lds_hi; // ... in slot 0 / one past the last slot
   int slot;                // ring slot of the stage to be consumed next
 
+  __device__ __forceinline__ void init(const float* stream, int n, float* smem, int wave, int lane) {
+    n_stages = n;
+    src_begin = stream + (wave * RC_PIECES) * 256 + lane * 4;
+    src = src_begin;
+    fetch_idx = 0;
+    lds_lo = (unsigned)(uintptr_t)smem + (unsigned)(wave * RC_PIECES * 1024);
+    lds_hi = lds_lo + STAGES * RC_STAGE_FLOATS * 4;
+    lds_fetch = lds_lo;
+    slot = 0;
+  }
   __device__ __forceinline__ void fetch_piece(int j) {   // j = 0 .. RC_PIECES - 1, in order; the last one advances the ring
     rc_glds16(src + j * 256, lds_fetch + j * 1024);
     if (j == RC_PIECES - 1) {
@@ -106,31 +140,52 @@ struct RcRing {
 #pragma unroll
     for (int j = 0; j < RC_PIECES; ++j) fetch_piece(j);
   }
+  // Start of the ring: STAGES - 1 stages in flight; MID: stage 0 must be readable before its first fragment read (later
+  // stages become readable at the barrier in the middle of the stage before them).
+  __device__ __forceinline__ void prime() {
+#pragma unroll
+    for (int d = 0; d < STAGES - 1; ++d) fetch();
+    if (MID) rc_wait_barrier<(STAGES - 2) * RC_PIECES>();
+  }
   // Make the next stage readable (mine: counted wait; everybody's: barrier -- which also says that nobody reads the
   // slot consumed last any more, so the stage behind the ones in flight is fetched into it: right here, or -- with
-  // RC_SPREAD_FETCH -- one LDS-DMA piece at a time between the stage's MFMA steps (RC_FETCH_AT)).
+  // RC_SPREAD_FETCH -- one LDS-DMA piece at a time between the stage's MFMA steps (RC_FETCH_AT)).  MID: nothing to wait for.
   // The counted wait stays correct with other vector memory operations outstanding (activation loads, feature
   // stores, issued after the newest fetch): loads return in order among loads, so "at most RC_PIECES operations
   // outstanding" implies that at most the RC_PIECES newest LOADS are -- every piece of the stage wanted here is older
   // than those; extra operations only make the wait longer.  DRAIN (vmcnt(0)) is kept as a debugging switch.
   template <bool DRAIN> __device__ __forceinline__ int acquire() {
-    if (DRAIN) rc_wait_barrier<0>();
-    else rc_wait_barrier<(RC_STAGES - 2) * RC_PIECES>();
+    if (!MID) {
+      if (DRAIN) rc_wait_barrier<0>();
+      else rc_wait_barrier<(STAGES - 2) * RC_PIECES>();
 #if !RC_SPREAD_FETCH
-    fetch();
+      fetch();
 #endif
+    }
     const int s = slot;
-    slot = (slot + 1 == RC_STAGES) ? 0 : slot + 1;
+    slot = (slot + 1 == STAGES) ? 0 : slot + 1;
     return s;
   }
+  // MID, called behind step `step` of the 16 steps of EVERY stage: in flight are the stages s + 1 .. s + STAGES - 2; all but
+  // the newest STAGES - 3 of them must have landed (s + 1 is consumed next, without another meeting).
+  __device__ __forceinline__ void at_step(int step) {
+    if (MID && step == RC_SYNC_STEP) {
+      rc_wait_barrier<(STAGES - 3) * RC_PIECES>();
+      fetch();
+    }
+  }
 };
+
+typedef RcRing<RC_MID_STAGES, (RC_MIDSYNC != 0)> RcRingMid;    // fp_head_chain_kernel, sa3_premul_chain_kernel
+typedef RcRing<RC_STAGES, false> RcRingEdge;                    // sa_premul_chain_kernel (and RC_MIDSYNC=0 builds)
+#define RC_SA3_POOL_FLOATS (2 * RC_WAVES * 256)
 
 // One LDS-DMA piece of the next fetch behind step STEP_ of a 16-step stage (pieces spread evenly over the steps).
 #if RC_SPREAD_FETCH
 #define RC_FETCH_AT(RING_, STEP_)                                                              \
   if (((STEP_) + 1) % (16 / RC_PIECES) == 0) (RING_).fetch_piece(((STEP_) + 1) / (16 / RC_PIECES) - 1);
 #else
-#define RC_FETCH_AT(RING_, STEP_)
+#define RC_FETCH_AT(RING_, STEP_) (RING_).at_step(STEP_);
 #endif
 
 // Per-lane fragment offsets (floats) inside a stage.  A-stages are [32 rows][256 k], B-stages [64 rows][128 k]; in both
@@ -193,8 +248,8 @@ __device__ __forceinline__ RcFrag rc_frag_offsets() {
 // the N/16 accumulators are compile-time register arrays (a register array written at a run-time index would be
 // spilled), and the loop body -- 8 or 6 stages, 128 MFMAs each -- is small enough for the whole chain to stay in the
 // instruction cache.  Stream order: for each group, its A-stages then its B-stages.
-template <int M, int N, bool RELU_B>
-__device__ __forceinline__ void rc_pair(const rc_f32x4 (&xin)[16], rc_f32x4 (&xout)[N / 16], RcRing& ring,
+template <int M, int N, bool RELU_B, class Ring>
+__device__ __forceinline__ void rc_pair(const rc_f32x4 (&xin)[16], rc_f32x4 (&xout)[N / 16], Ring& ring,
                                         const float* __restrict__ smem, const float* __restrict__ affA,
                                         const float* __restrict__ affB, bool active, const RcFrag& fo) {
   static_assert(M % 128 == 0 && N % 64 == 0, "groups of 128 mid channels; B-stages of 64 output channels");
@@ -207,7 +262,7 @@ __device__ __forceinline__ void rc_pair(const rc_f32x4 (&xin)[16], rc_f32x4 (&xo
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       rc_f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-      const int slot = ring.acquire<false>();
+      const int slot = ring.template acquire<false>();
       {   // (waves without rows in the last pass compute on row 0's data: no branch around the MFMA stream)
         const float* st = smem + slot * RC_STAGE_FLOATS;
         rc_f32x4 w0n = *reinterpret_cast<const rc_f32x4*>(st + fo.a[0]);
@@ -239,7 +294,7 @@ __device__ __forceinline__ void rc_pair(const rc_f32x4 (&xin)[16], rc_f32x4 (&xo
     // ---- layer B, k-slice [128 ob, 128 ob + 128) for all N outputs
 #pragma unroll
     for (int v = 0; v < N / 64; ++v) {
-      const int slot = ring.acquire<false>();
+      const int slot = ring.template acquire<false>();
       {   // (waves without rows in the last pass compute on row 0's data: no branch around the MFMA stream)
         const float* st = smem + slot * RC_STAGE_FLOATS;
         rc_f32x4 w0n = *reinterpret_cast<const rc_f32x4*>(st + fo.b[0]);
@@ -284,7 +339,7 @@ __device__ __forceinline__ void rc_pair(const rc_f32x4 (&xin)[16], rc_f32x4 (&xo
 template <bool INTERP>
 __global__ __launch_bounds__(RC_THREADS, 2) void fp_head_chain_kernel(const RcArgs p) {
   extern __shared__ __attribute__((aligned(1024))) float smem[];   // ring | affine | wscore | ticket | (interp tables)
-  float* const aff = smem + RC_STAGES * RC_STAGE_FLOATS;
+  float* const aff = smem + RC_MID_STAGES * RC_STAGE_FLOATS;
   float* const wsc = aff + RC_AFFINE_MAX;
   float* const itab = wsc + 128 + 4;
   const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, g = lane >> 4;
@@ -296,15 +351,8 @@ __global__ __launch_bounds__(RC_THREADS, 2) void fp_head_chain_kernel(const RcAr
   __syncthreads();   // the tables are read after the ring's barriers, which do not wait for LDS writes (lgkmcnt)
 #endif
 
-  RcRing ring;
-  ring.n_stages = p.n_stages;
-  ring.src_begin = p.stream + (wave * RC_PIECES) * 256 + lane * 4;
-  ring.src = ring.src_begin;
-  ring.fetch_idx = 0;
-  ring.lds_lo = (unsigned)(uintptr_t)smem + (unsigned)(wave * RC_PIECES * 1024);
-  ring.lds_hi = ring.lds_lo + RC_STAGES * RC_STAGE_FLOATS * 4;
-  ring.lds_fetch = ring.lds_lo;
-  ring.slot = 0;
+  RcRingMid ring;
+  ring.init(p.stream, p.n_stages, smem, wave, lane);
   const RcFrag fo = rc_frag_offsets();
 
   // Row blocks (128 rows = one pass of the 8 waves over the whole weight stream) are handed out through a ticket
@@ -316,13 +364,12 @@ __global__ __launch_bounds__(RC_THREADS, 2) void fp_head_chain_kernel(const RcAr
   bool primed = false;
   for (;;) {
     if (tid == 0) *s_blk = atomicAdd(p.ticket, 1);
-    __syncthreads();
+    rc_barrier_lds();                          // (thread 0's wave waited for its atomic; nobody else drains anything)
     const long long tick = __builtin_amdgcn_readfirstlane(*s_blk);
     if (tick >= p.blk_count) break;
     const long long blk = p.blk_first + tick;
     if (!primed) {   // prologue of the ring: RC_STAGES - 1 stages in flight
-#pragma unroll
-      for (int d = 0; d < RC_STAGES - 1; ++d) ring.fetch();
+      ring.prime();
       primed = true;
     }
     // whole block: 8 waves x 16 rows; half block (the last round's worth of rows, so that the launch's tail is made of
@@ -444,27 +491,22 @@ __global__ __launch_bounds__(RC_THREADS, 2) void sa_premul_chain_kernel(const Sc
   for (int i = tid; i < p.affine_floats; i += RC_THREADS) aff[i] = p.affine[i];
   __syncthreads();
 
-  RcRing ring;
-  ring.n_stages = p.n_stages;
-  ring.src_begin = p.stream + (wave * RC_PIECES) * 256 + lane * 4;
-  ring.src = ring.src_begin;
-  ring.fetch_idx = 0;
-  ring.lds_lo = (unsigned)(uintptr_t)smem + (unsigned)(wave * RC_PIECES * 1024);
-  ring.lds_hi = ring.lds_lo + RC_STAGES * RC_STAGE_FLOATS * 4;
-  ring.lds_fetch = ring.lds_lo;
-  ring.slot = 0;
+  // (the round-2 hand-over, three slots: this kernel's 174 VGPRs leave room for other streams' waves on its CUs -- the region
+  // stage's and the geometry's small kernels -- as long as its LDS does too: with a fourth slot (150 KB) they lost that place,
+  // their launches took 3 x longer and the step gained nothing from this kernel's 1.5 %)
+  RcRingEdge ring;
+  ring.init(p.stream, p.n_stages, smem, wave, lane);
   const RcFrag fo = rc_frag_offsets();
   const int g4 = 4 * g;
 
   bool primed = false;
   for (;;) {
     if (tid == 0) *s_blk = atomicAdd(p.ticket, 1);
-    __syncthreads();
+    rc_barrier_lds();                          // (thread 0's wave waited for its atomic; nobody else drains anything)
     const long long blk = __builtin_amdgcn_readfirstlane(*s_blk);
     if (blk >= p.n_blocks) break;
     if (!primed) {
-#pragma unroll
-      for (int d = 0; d < RC_STAGES - 1; ++d) ring.fetch();
+      ring.prime();
       primed = true;
     }
     const bool half = blk >= p.n_full;                         // half block: one neighbourhood on waves 0-3
@@ -499,7 +541,7 @@ __global__ __launch_bounds__(RC_THREADS, 2) void sa_premul_chain_kernel(const Sc
 #pragma unroll
     for (int st8 = 0; st8 < 8; ++st8) {
       rc_f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-      const int slot = ring.acquire<false>();
+      const int slot = ring.template acquire<false>();
       {   // (waves without rows in the last pass compute on row 0's data: no branch around the MFMA stream)
         const float* st = smem + slot * RC_STAGE_FLOATS;
         rc_f32x4 w0n = *reinterpret_cast<const rc_f32x4*>(st + fo.a[0]);
@@ -531,7 +573,7 @@ __global__ __launch_bounds__(RC_THREADS, 2) void sa_premul_chain_kernel(const Sc
     // ---- layer 3 + max over the points, one stage (32 channels) at a time
     for (int s3 = 0; s3 < 16; ++s3) {
       rc_f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-      const int slot = ring.acquire<false>();
+      const int slot = ring.template acquire<false>();
       {   // (waves without rows in the last pass compute on row 0's data: no branch around the MFMA stream)
         const float* st = smem + slot * RC_STAGE_FLOATS;
         rc_f32x4 w0n = *reinterpret_cast<const rc_f32x4*>(st + fo.a[0]);
@@ -568,7 +610,7 @@ __global__ __launch_bounds__(RC_THREADS, 2) void sa_premul_chain_kernel(const Sc
       }
     }
     // ---- max over the 4 waves of each neighbourhood (the ring's next barriers separate this from the next pass's writes)
-    __syncthreads();
+    rc_barrier_lds();
 #pragma unroll
     for (int n = 0; n < RC_WAVES / 4; ++n) {
       const long long gn = grp0 + n;
@@ -605,36 +647,28 @@ struct Sc3Args {
 };
 
 __global__ __launch_bounds__(RC_THREADS, 2) void sa3_premul_chain_kernel(const Sc3Args p) {
-  extern __shared__ __attribute__((aligned(1024))) float smem[];   // ring | affine (3072) | pool (8 x 1024) | ticket
-  float* const aff = smem + RC_STAGES * RC_STAGE_FLOATS;
+  extern __shared__ __attribute__((aligned(1024))) float smem[];   // ring | affine (3072) | pool (2 x 8 x 256) | ticket
+  float* const aff = smem + RC_MID_STAGES * RC_STAGE_FLOATS;
   float* const pool = aff + 3072;
-  int* const s_blk = reinterpret_cast<int*>(pool + RC_WAVES * 1024);
+  int* const s_blk = reinterpret_cast<int*>(pool + RC_SA3_POOL_FLOATS);
   const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   for (int i = tid; i < p.affine_floats; i += RC_THREADS) aff[i] = p.affine[i];
   __syncthreads();
 
-  RcRing ring;
-  ring.n_stages = p.n_stages;
-  ring.src_begin = p.stream + (wave * RC_PIECES) * 256 + lane * 4;
-  ring.src = ring.src_begin;
-  ring.fetch_idx = 0;
-  ring.lds_lo = (unsigned)(uintptr_t)smem + (unsigned)(wave * RC_PIECES * 1024);
-  ring.lds_hi = ring.lds_lo + RC_STAGES * RC_STAGE_FLOATS * 4;
-  ring.lds_fetch = ring.lds_lo;
-  ring.slot = 0;
+  RcRingMid ring;
+  ring.init(p.stream, p.n_stages, smem, wave, lane);
   const RcFrag fo = rc_frag_offsets();
   const int g4 = 4 * g;
 
   bool primed = false;
   for (;;) {
     if (tid == 0) *s_blk = atomicAdd(p.ticket, 1);
-    __syncthreads();
+    rc_barrier_lds();                          // (thread 0's wave waited for its atomic; nobody else drains anything)
     const long long blk = __builtin_amdgcn_readfirstlane(*s_blk);
     if (blk >= p.n_blocks) break;
     if (!primed) {
-#pragma unroll
-      for (int d = 0; d < RC_STAGES - 1; ++d) ring.fetch();
+      ring.prime();
       primed = true;
     }
     const long long grp0 = blk * (RC_WAVES / 4);
@@ -672,7 +706,7 @@ __global__ __launch_bounds__(RC_THREADS, 2) void sa3_premul_chain_kernel(const S
       }
 #pragma unroll
       for (int rg = 0; rg < 16; ++rg) {
-        const int slot = ring.acquire<false>();
+        const int slot = ring.template acquire<false>();
         const float* st = smem + slot * RC_STAGE_FLOATS;
         rc_f32x4 w0n = *reinterpret_cast<const rc_f32x4*>(st + fo.a[0]);
         rc_f32x4 w1n = *reinterpret_cast<const rc_f32x4*>(st + fo.a[0] + 16 * 256);
@@ -687,6 +721,7 @@ __global__ __launch_bounds__(RC_THREADS, 2) void sa3_premul_chain_kernel(const S
           RC_PIN();
           const rc_f32x4 x = x0[kt];
           RC_MFMA8(w0, w1, x, x1[2 * rg], x1[2 * rg + 1])
+          RC_FETCH_AT(ring, kt)
         }
       }
     }
@@ -702,7 +737,7 @@ __global__ __launch_bounds__(RC_THREADS, 2) void sa3_premul_chain_kernel(const S
       rc_f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int kh = 0; kh < 2; ++kh) {
-        const int slot = ring.acquire<false>();
+        const int slot = ring.template acquire<false>();
         const float* st = smem + slot * RC_STAGE_FLOATS;
         rc_f32x4 w0n = *reinterpret_cast<const rc_f32x4*>(st + fo.a[0]);
         rc_f32x4 w1n = *reinterpret_cast<const rc_f32x4*>(st + fo.a[0] + 16 * 256);
@@ -717,6 +752,7 @@ __global__ __launch_bounds__(RC_THREADS, 2) void sa3_premul_chain_kernel(const S
           RC_PIN();
           const rc_f32x4 x = x1[16 * kh + kt];
           RC_MFMA8_T(w0, w1, x, acc0, acc1)
+          RC_FETCH_AT(ring, kt)
         }
       }
       // folded BN affine (+ ReLU) per channel (32 s3 + 16 t + j), max over this wave's 16 points: registers, then lane groups
@@ -731,21 +767,25 @@ __global__ __launch_bounds__(RC_THREADS, 2) void sa3_premul_chain_kernel(const S
       if (p.relu3) { m0 = fmaxf(m0, 0.f); m1 = fmaxf(m1, 0.f); }
       m0 = fmaxf(m0, __shfl_xor(m0, 16, 64)); m1 = fmaxf(m1, __shfl_xor(m1, 16, 64));
       m0 = fmaxf(m0, __shfl_xor(m0, 32, 64)); m1 = fmaxf(m1, __shfl_xor(m1, 32, 64));
+      // The per-wave maxima of 256 channels (8 steps) at a time, double-buffered: after every eighth step the four waves of a
+      // neighbourhood meet (LDS-only barrier) and 512 threads write 2 x 256 pooled values; the buffer is written again two
+      // chunks later, behind the next chunk's barrier.  (One 8 x 1024 buffer reduced at the end of the pass -- 32 KB -- left no
+      // room for the ring's fourth slot.)
+      const int chunk = s3 >> 3, cl = 32 * (s3 & 7);
+      float* const pw = pool + ((chunk & 1) * RC_WAVES + wave) * 256 + cl;
       if (g == 0) {
-        pool[wave * 1024 + 32 * s3 + j] = m0;
-        pool[wave * 1024 + 32 * s3 + 16 + j] = m1;
+        pw[j] = m0;
+        pw[16 + j] = m1;
       }
-    }
-    // ---- max over the 4 waves of each neighbourhood (the ring's next barriers separate this from the next pass's writes)
-    __syncthreads();
-#pragma unroll
-    for (int n = 0; n < RC_WAVES / 4; ++n) {
-      const long long gn = grp0 + n;
-      if (gn < p.groups)
-        for (int c = tid; c < 1024; c += RC_THREADS) {
-          const float* q = pool + (4 * n) * 1024 + c;
-          p.out[gn * p.ldo + c] = fmaxf(fmaxf(q[0], q[1024]), fmaxf(q[2048], q[3072]));
+      if ((s3 & 7) == 7) {
+        rc_barrier_lds();
+        const int n = tid >> 8, c = tid & 255;                // RC_THREADS = 512: neighbourhood n of the block, channel c of the chunk
+        const long long gn = grp0 + n;
+        if (gn < p.groups) {
+          const float* q = pool + ((chunk & 1) * RC_WAVES + 4 * n) * 256 + c;
+          p.out[gn * p.ldo + 256 * chunk + c] = fmaxf(fmaxf(q[0], q[256]), fmaxf(q[512], q[768]));
         }
+      }
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -823,7 +863,7 @@ extern "C" int regnet_sa3_premul_chain_f32(const float* U, int64_t ldu, const fl
   a.n_blocks = (groups + 1) / 2;
   a.ticket = ticket;
   const long long wgs = a.n_blocks < 256 ? a.n_blocks : 256;
-  const size_t lds = (size_t)(RC_STAGES * RC_STAGE_FLOATS + 3072 + RC_WAVES * 1024 + 4) * sizeof(float);
+  const size_t lds = (size_t)(RC_MID_STAGES * RC_STAGE_FLOATS + 3072 + RC_SA3_POOL_FLOATS + 4) * sizeof(float);
   int rc_attr = rc_allow_lds(reinterpret_cast<const void*>(sa3_premul_chain_kernel), lds);
   if (rc_attr) return rc_attr;
   hipLaunchKernelGGL(sa3_premul_chain_kernel, dim3((unsigned)wgs), dim3(RC_THREADS), lds, as_stream(stream_handle), a);
@@ -852,7 +892,7 @@ static int rc_launch_fp_head(RcArgs& a, bool interp, int64_t block_first, int64_
   a.blk_first = block_first; a.blk_count = block_count;
   const int cus = 256 * RC_WG_PER_CU;
   const long long wgs = block_count < cus ? block_count : cus;
-  const size_t lds = (size_t)(RC_STAGES * RC_STAGE_FLOATS + RC_AFFINE_MAX + 128 + 4 + (interp ? RC_INTERP_FLOATS : 0)) * sizeof(float);
+  const size_t lds = (size_t)(RC_MID_STAGES * RC_STAGE_FLOATS + RC_AFFINE_MAX + 128 + 4 + (interp ? RC_INTERP_FLOATS : 0)) * sizeof(float);
   const void* kernel = interp ? reinterpret_cast<const void*>(fp_head_chain_kernel<true>)
                               : reinterpret_cast<const void*>(fp_head_chain_kernel<false>);
   int rc_attr = rc_allow_lds(kernel, lds);

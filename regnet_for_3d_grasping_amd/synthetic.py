@@ -140,9 +140,31 @@ def calibrate_score_head(score_net, pc):
     affine to 2/0) so that eval-mode scores straddle the 0.5 centre-selection threshold instead of
     collapsing on one side.  Returns (mean, var)."""
     seg = score_net.extrat_featurePN2
+    from . import fused
+    if (pc.is_cuda and fused.ENABLED and not score_net.training and seg.k_score == 1
+            and fused.supports_rowchain(seg, seg.fp_modules[-1])):
+        # on the GPU: the fused forward's point feature (the last propagation block's output) through the head's four layers
+        # on the native layer kernel; conv_score's output is one matrix-vector product away -- no module-granular forward of
+        # the whole network (a cuDNN / MIOpen / rocBLAS pass over 8 x 25 600 points just to read one activation)
+        with torch.no_grad():
+            feat, _, _ = score_net(pc)                                   # (B, N, 256)
+            B, N, C = feat.shape
+            h = feat.reshape(B * N, C)
+            h = h if h.is_contiguous() else h.contiguous()
+            for layer in fused._packed_stack(seg.mlp, seg.mlp):
+                h = fused.mlp_layer(h, layer.K, layer, B * N)
+            w = seg.conv_score.weight.detach().reshape(-1).float()
+            x = torch.mv(h, w)
+            if seg.conv_score.bias is not None:
+                x = x + seg.conv_score.bias.detach().float()[0]
+            mean, var = float(x.mean()), float(x.var(unbiased=False))
+            seg.bn_score.running_mean.fill_(mean)
+            seg.bn_score.running_var.fill_(var)
+            seg.bn_score.weight.fill_(2.0)
+            seg.bn_score.bias.fill_(0.0)
+        return mean, var
     grabbed = {}
     hook = seg.conv_score.register_forward_hook(lambda m, i, o: grabbed.__setitem__("x", o.detach()))
-    from . import fused
     was = fused.ENABLED
     fused.ENABLED = False  # the hook needs the module-granular head
     try:

@@ -34,7 +34,7 @@ def test_bench_line_has_the_contract_fields():
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-5 and 0 < r["frac"] < 1
     assert r["traffic"] is None or r["traffic"] > 0
     # utilisation figures count EXECUTED flops; the algorithmic count is kept beside them
-    assert r["frac"] == r["frac_executed"] <= r["frac_algorithmic"] and 0 < r["step_frac_executed"] < 1
+    assert r["frac"] == r["frac_executed"] <= r["frac_algorithmic"] and 0.3 < r["step_frac_executed"] < 1
     assert r["executed_flop_per_launch"] <= r["algorithmic_units_per_launch"]
     if r["rocprof_avg_launch_ms"] is not None:
         assert r["rocprof_source"].startswith("profiles/") and 0 < r["frac_rocprof"] < 1
