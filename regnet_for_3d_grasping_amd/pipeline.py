@@ -365,6 +365,14 @@ class ForwardPipeline:
         s_mlp = self.s_mlps[self._n_featured % len(self.s_mlps)]
         self._n_featured += 1
         from . import fused
+        # accounting only (bench.py: config.host_late_feature_stages): was the feature stream already idle -- the previous
+        # batch's feature stage finished -- when this batch's stage is enqueued?  Then the launching thread, not the GPU, paced it.
+        prev = self.__dict__.get("_last_mlp_done")
+        if prev is not None and prev.query():
+            self.host_late_feature_stages = self.__dict__.get("host_late_feature_stages", 0) + 1
+        geo_pending = not item["geo_done"].query()
+        if geo_pending:
+            self.geometry_pending_at_enqueue = self.__dict__.get("geometry_pending_at_enqueue", 0) + 1
         with torch.cuda.stream(s_mlp), torch.no_grad():
             s_mlp.wait_event(item["geo_done"])
             # the last, partial round of the final chain kernel runs on a side stream beside the NEXT batch's first kernels
@@ -376,6 +384,7 @@ class ForwardPipeline:
                 fused.TAIL_SINK = None
             done = torch.cuda.Event()
             done.record(s_mlp)
+            self._last_mlp_done = done
             item["tail_done"] = list(tails or ())
         all_feature.record_stream(self.s_reg)
         score.record_stream(self.s_reg)
