@@ -22,6 +22,11 @@ score_net, region_net = pipeline.build_models(dev)
 pcs = [synthetic.make_batch(1000 + 8 * k, 8, 25600, device=dev) for k in range(4)]
 synthetic.calibrate_score_head(score_net, pcs[0])
 np.random.seed(0)
+if os.environ.get("PIPE_CALIB") == "1":        # as bench.py: the region head calibrated so that the refine network runs
+    synthetic.calibrate_region_head(region_net, lambda: pipeline.forward_scenes(score_net, region_net, pcs[0]))
+    np.random.seed(0)
+if os.environ.get("PIPE_DISTINCT"):
+    pcs = [synthetic.make_batch(1000 + 8 * k, 8, 25600, device=dev) for k in range(int(os.environ["PIPE_DISTINCT"]))]
 if os.environ.get("PIPE_TIMERS") == "1":
     import bench
     timer = bench.OpTimer(8); bench.install_timers(timer); timer.enabled = True
@@ -42,9 +47,9 @@ if os.environ.get("PIPE_NO_EVENT") == "1":      # no completion event behind a f
         out = orig_features(item)
         return out
     # (kept simple: see PIPE_REGION=0 for the variant without consumers)
-for _ in pipe.run(pcs[k % 4] for k in range(5)):
+for _ in pipe.run(pcs[k % len(pcs)] for k in range(5)):
     pass
 torch.cuda.synchronize()
-for _ in pipe.run(pcs[k % 4] for k in range(40)):
+for _ in pipe.run(pcs[k % len(pcs)] for k in range(40)):
     pass
 torch.cuda.synchronize()
