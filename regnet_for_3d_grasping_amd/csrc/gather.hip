@@ -332,41 +332,47 @@ extern "C" int regnet_gather_points_f32(const float* points, int64_t pb, int64_t
 
 // ---- processing order of the level-1 neighbourhoods by cost class (fused.chain3_order): class = (count > 32) + (count > 48),
 // order = the STABLE sort permutation by class (what torch.argsort(stable=True) of the class ids returns): a three-bin
-// counting sort by one workgroup -- per-thread counts over contiguous chunks, an exclusive scan over (class, thread), one
-// scatter.  n <= 2^24 elements (8 x 5 120 in a step).
-#define CO_THREADS 1024
+// counting sort by one workgroup.  n <= 2^24 elements (8 x 5 120 in a step).
+#define CO_WAVES 16
+#define CO_THREADS (CO_WAVES * 64)
+// Every wave owns a contiguous segment and walks it in coalesced 64-element steps: per class a ballot + popcount (pass 1: the
+// segment's three totals; pass 2: position = class base + hits of the class in earlier segments + so far in this one + in lower
+// lanes).  Two barriers, 2 x n / 1024 dependent-free 512-byte reads per wave (a thread-per-chunk version read 320-byte strides
+// lane by lane: 80 us for 40 960 elements).
 __global__ __launch_bounds__(CO_THREADS) void class_order_kernel(const long long* __restrict__ count, long long n,
                                                                  long long* __restrict__ order) {
-  __shared__ int cnt[3][CO_THREADS];
-  __shared__ int base[3];
-  const int t = threadIdx.x;
-  const long long per = (n + CO_THREADS - 1) / CO_THREADS;
-  const long long lo = (long long)t * per, hi = lo + per < n ? lo + per : n;
+  __shared__ int tot[3][CO_WAVES];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  const long long seg = ((n + CO_WAVES - 1) / CO_WAVES + 63) / 64 * 64;
+  const long long lo = (long long)wave * seg, hi = lo + seg < n ? lo + seg : n;
   int c0 = 0, c1 = 0, c2 = 0;
-  for (long long i = lo; i < hi; ++i) {
-    const long long c = count[i];
-    const int k = (c > 32) + (c > 48);
-    c0 += k == 0; c1 += k == 1; c2 += k == 2;
+  for (long long i0 = lo; i0 < hi; i0 += 64) {
+    const long long i = i0 + lane;
+    const long long c = i < hi ? count[i] : 0;
+    const int k = i < hi ? (c > 32) + (c > 48) : 3;
+    c0 += (int)__popcll(__ballot(k == 0)); c1 += (int)__popcll(__ballot(k == 1)); c2 += (int)__popcll(__ballot(k == 2));
   }
-  cnt[0][t] = c0; cnt[1][t] = c1; cnt[2][t] = c2;
+  if (lane == 0) { tot[0][wave] = c0; tot[1][wave] = c1; tot[2][wave] = c2; }
   __syncthreads();
-  // exclusive scan of each class over the threads (Hillis-Steele on three rows at once)
-  for (int off = 1; off < CO_THREADS; off <<= 1) {
-    int a0 = 0, a1 = 0, a2 = 0;
-    if (t >= off) { a0 = cnt[0][t - off]; a1 = cnt[1][t - off]; a2 = cnt[2][t - off]; }
-    __syncthreads();
-    cnt[0][t] += a0; cnt[1][t] += a1; cnt[2][t] += a2;
-    __syncthreads();
+  int all0 = 0, all1 = 0, p0 = 0, p1 = 0, p2 = 0;
+#pragma unroll
+  for (int w = 0; w < CO_WAVES; ++w) {
+    const int t0 = tot[0][w], t1 = tot[1][w], t2 = tot[2][w];
+    all0 += t0; all1 += t1;
+    if (w < wave) { p0 += t0; p1 += t1; p2 += t2; }
   }
-  if (t == 0) {
-    base[0] = 0; base[1] = cnt[0][CO_THREADS - 1]; base[2] = cnt[0][CO_THREADS - 1] + cnt[1][CO_THREADS - 1];
-  }
-  __syncthreads();
-  int p0 = base[0] + cnt[0][t] - c0, p1 = base[1] + cnt[1][t] - c1, p2 = base[2] + cnt[2][t] - c2;   // inclusive -> exclusive
-  for (long long i = lo; i < hi; ++i) {
-    const long long c = count[i];
-    const int k = (c > 32) + (c > 48);
-    if (k == 0) order[p0++] = i; else if (k == 1) order[p1++] = i; else order[p2++] = i;
+  p1 += all0; p2 += all0 + all1;            // class bases: [class 0 | class 1 | class 2]
+  for (long long i0 = lo; i0 < hi; i0 += 64) {
+    const long long i = i0 + lane;
+    const long long c = i < hi ? count[i] : 0;
+    const int k = i < hi ? (c > 32) + (c > 48) : 3;
+    const unsigned long long m0 = __ballot(k == 0), m1 = __ballot(k == 1), m2 = __ballot(k == 2);
+    if (k == 0) order[p0 + (int)__popcll(m0 & lt_mask)] = i;
+    else if (k == 1) order[p1 + (int)__popcll(m1 & lt_mask)] = i;
+    else if (k == 2) order[p2 + (int)__popcll(m2 & lt_mask)] = i;
+    p0 += (int)__popcll(m0); p1 += (int)__popcll(m1); p2 += (int)__popcll(m2);
   }
 }
 

@@ -43,7 +43,7 @@ def test_gather_points_flags_an_index_outside_the_cloud():
     pn2_ext.raise_if_fps_failed()          # the flag was cleared
 
 
-@pytest.mark.parametrize("n", [1, 7, 1024, 40960, 8 * 5120 + 3])
+@pytest.mark.parametrize("n", [1, 7, 63, 65, 1024, 1025, 40960, 8 * 5120 + 3, 100001])
 def test_class_order_is_the_stable_argsort(n):
     from regnet_for_3d_grasping_amd import fused, pn2_ext
     g = torch.Generator().manual_seed(n)
