@@ -20,7 +20,7 @@ SOURCES = [
     ("gather.hip", []),
     ("region.hip", ["-ffp-contract=off"]),
     ("grid.hip", ["-ffp-contract=off"]),
-    ("mlp.hip", []),
+    ("mlp.hip", ["-Wno-pass-failed"]),   # mlp_gemm_kernel<0> asks for 5 waves per SIMD to cap its registers; its LDS allows 3
     ("sa_chain.hip", ["-fno-slp-vectorize"]),   # SLP turns the layer-1 FMAs into v_pk_mul + separate adds
     ("rowchain.hip", ["-fno-slp-vectorize"]),
     ("heads.hip", []),

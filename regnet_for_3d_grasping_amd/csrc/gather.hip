@@ -333,7 +333,7 @@ extern "C" int regnet_gather_points_f32(const float* points, int64_t pb, int64_t
 // ---- processing order of the level-1 neighbourhoods by cost class (fused.chain3_order): class = (count > 32) + (count > 48),
 // order = the STABLE sort permutation by class (what torch.argsort(stable=True) of the class ids returns): a three-bin
 // counting sort by one workgroup.  n <= 2^24 elements (8 x 5 120 in a step).
-#define CO_WAVES 16
+#define CO_WAVES 8
 #define CO_THREADS (CO_WAVES * 64)
 // Every wave owns a contiguous segment and walks it in coalesced 64-element steps: per class a ballot + popcount (pass 1: the
 // segment's three totals; pass 2: position = class base + hits of the class in earlier segments + so far in this one + in lower

@@ -62,10 +62,14 @@ __device__ __forceinline__ int cell_of(const GridHeader& H, float x, float y, fl
          cell_coord(x, H.lo[0], H.inv_h, H.dim[0]);
 }
 
-__global__ __launch_bounds__(1024) void grid_bounds_kernel(const float* __restrict__ xyz, int64_t sb, int64_t sc,
+// GRID_WG threads per scene for the two one-workgroup-per-scene kernels (bounds, scan): 512, not 1024 -- eight waves of <= 32
+// registers find room on a CU whose SIMDs hold two ~200-register chain waves each; sixteen did not (the geometry of the batches
+// ahead then waited for whole CUs).  Results do not depend on it (min / max, integer sums).
+#define GRID_WG 512
+__global__ __launch_bounds__(GRID_WG) void grid_bounds_kernel(const float* __restrict__ xyz, int64_t sb, int64_t sc,
                                                            int64_t sn, int N, float h_req, char* __restrict__ ws,
                                                            long long slab) {
-  __shared__ float red[6][16];
+  __shared__ float red[6][GRID_WG / 64];
   __shared__ GridHeader hdr;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* base = xyz + (int64_t)blockIdx.x * sb;
@@ -74,7 +78,7 @@ __global__ __launch_bounds__(1024) void grid_bounds_kernel(const float* __restri
 
   float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
   float hi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
-  for (int j = tid; j < N; j += 1024) {
+  for (int j = tid; j < N; j += GRID_WG) {
     const float x = base[(int64_t)j * sn], y = base[sc + (int64_t)j * sn], z = base[2 * sc + (int64_t)j * sn];
     lo[0] = fminf(lo[0], x); hi[0] = fmaxf(hi[0], x);
     lo[1] = fminf(lo[1], y); hi[1] = fmaxf(hi[1], y);
@@ -94,7 +98,7 @@ __global__ __launch_bounds__(1024) void grid_bounds_kernel(const float* __restri
     float e[3], scale = 0.f;
     for (int a = 0; a < 3; ++a) {
       float l = red[a][0], hgh = red[3 + a][0];
-      for (int w = 1; w < 16; ++w) { l = fminf(l, red[a][w]); hgh = fmaxf(hgh, red[3 + a][w]); }
+      for (int w = 1; w < GRID_WG / 64; ++w) { l = fminf(l, red[a][w]); hgh = fmaxf(hgh, red[3 + a][w]); }
       hdr.lo[a] = l;
       e[a] = fmaxf(hgh - l, 0.f);
       scale = fmaxf(scale, fmaxf(fabsf(l), fabsf(hgh)));
@@ -126,7 +130,7 @@ __global__ __launch_bounds__(1024) void grid_bounds_kernel(const float* __restri
   __syncthreads();
   if (tid < (int)(sizeof(GridHeader) / 4)) reinterpret_cast<int*>(my)[tid] = reinterpret_cast<const int*>(&hdr)[tid];
   const int cells = hdr.cells;
-  for (int c = tid; c <= cells; c += 1024) cell_start[c] = 0;
+  for (int c = tid; c <= cells; c += GRID_WG) cell_start[c] = 0;
 }
 
 __global__ __launch_bounds__(256) void grid_count_kernel(const float* __restrict__ xyz, int64_t sb, int64_t sc,
@@ -140,13 +144,13 @@ __global__ __launch_bounds__(256) void grid_count_kernel(const float* __restrict
   atomicAdd(&grid_cell_start(my)[c + 1], 1);
 }
 
-__global__ __launch_bounds__(1024) void grid_scan_kernel(char* __restrict__ ws, long long slab) {
-  __shared__ unsigned wsum[16];
+__global__ __launch_bounds__(GRID_WG) void grid_scan_kernel(char* __restrict__ ws, long long slab) {
+  __shared__ unsigned wsum[GRID_WG / 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   char* my = ws + (long long)blockIdx.x * slab;
   const int cells = reinterpret_cast<const GridHeader*>(my)->cells;
   int* cell_start = grid_cell_start(my);
-  const int per = (cells + 1023) / 1024;   // <= 64
+  const int per = (cells + GRID_WG - 1) / GRID_WG;
   const int beg = tid * per, end = min(cells, beg + per);
   unsigned local = 0;
   for (int c = beg; c < end; ++c) local += (unsigned)cell_start[c + 1];
@@ -159,7 +163,7 @@ __global__ __launch_bounds__(1024) void grid_scan_kernel(char* __restrict__ ws, 
   if (lane == 63) wsum[wave] = incl;
   __syncthreads();
   unsigned run = incl - local;
-  for (int w = 0; w < 16; ++w) run += (w < wave) ? wsum[w] : 0u;
+  for (int w = 0; w < GRID_WG / 64; ++w) run += (w < wave) ? wsum[w] : 0u;
   for (int c = beg; c < end; ++c) {   // each thread rewrites only its own chunk, after having read it
     const unsigned cnt = (unsigned)cell_start[c + 1];
     cell_start[c + 1] = (int)run;     // first slot of cell c
@@ -557,9 +561,9 @@ static int build_grid(const float* xyz, int64_t sb, int64_t sc, int64_t sn, int6
                       hipStream_t st) {
   const long long slab = grid_slab_bytes(N);
   const dim3 per_point((unsigned)((N + 255) / 256), (unsigned)B);
-  hipLaunchKernelGGL(grid_bounds_kernel, dim3((unsigned)B), dim3(1024), 0, st, xyz, sb, sc, sn, (int)N, h, (char*)ws, slab);
+  hipLaunchKernelGGL(grid_bounds_kernel, dim3((unsigned)B), dim3(GRID_WG), 0, st, xyz, sb, sc, sn, (int)N, h, (char*)ws, slab);
   if (N > 0) hipLaunchKernelGGL(grid_count_kernel, per_point, dim3(256), 0, st, xyz, sb, sc, sn, (int)N, (char*)ws, slab);
-  hipLaunchKernelGGL(grid_scan_kernel, dim3((unsigned)B), dim3(1024), 0, st, (char*)ws, slab);
+  hipLaunchKernelGGL(grid_scan_kernel, dim3((unsigned)B), dim3(GRID_WG), 0, st, (char*)ws, slab);
   if (N > 0) hipLaunchKernelGGL(grid_scatter_kernel, per_point, dim3(256), 0, st, xyz, sb, sc, sn, (int)N, (char*)ws, slab);
   REGNET_LAUNCH_CHECK();
   return REGNET_OK;

@@ -117,7 +117,9 @@ __device__ __forceinline__ void xcd_tile(unsigned vblock, int& tm, int& tn, int 
 }
 
 template <int AMODE, bool POOL>
-__global__ __launch_bounds__(MLP_THREADS, AMODE == 2 ? 3 : MLP_MIN_WAVES) void mlp_gemm_kernel(const MlpArgs p) {
+// (AMODE 0 -- the region heads' small layers on the side stream -- is compiled for 5 waves per SIMD: 88 registers instead of
+// "whatever 4 waves allow" (126), so that its workgroups find room on CUs whose SIMDs hold two 208-register chain waves)
+__global__ __launch_bounds__(MLP_THREADS, AMODE == 2 ? 3 : (AMODE == 0 ? 5 : MLP_MIN_WAVES)) void mlp_gemm_kernel(const MlpArgs p) {
   // one LDS block: [2][BM][LDS_LD] A tiles, [2][BN][LDS_LD] W tiles; re-used by the epilogue as
   // per-wave transposition buffers (4 x 64 x 36 floats)
   __shared__ __attribute__((aligned(16))) float smem[2 * BM * LDS_LD + 2 * BN * LDS_LD];

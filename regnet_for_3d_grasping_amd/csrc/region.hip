@@ -100,9 +100,9 @@ extern "C" int regnet_radius_group_f32(const float* pc, int64_t pb, int64_t pn, 
 // furthest-point-sampling launch over a common, longer prefix of all scenes gives each scene the result of
 // sampling its own positives: a copy of the start point is at distance 0 from the selected set for ever).
 // Two passes, two barriers (round 5; before: N / 1024 rounds of three barriers each, 370 us per call beside the matrix
-// kernels): every wave owns a contiguous segment of the scene, counts its hits with ballots, the 16 segment totals are scanned,
+// kernels): every wave owns a contiguous segment of the scene, counts its hits with ballots, the segment totals are scanned,
 // and the wave walks its segment again writing each hit at (segment base + hits so far + hits in lower lanes).
-#define SP_WAVES 16
+#define SP_WAVES 8    // (eight waves of 40 registers fit beside two ~200-register chain waves per SIMD; sixteen needed 160 free registers)
 __global__ __launch_bounds__(SP_WAVES * 64) void select_positive_kernel(const float* __restrict__ pc, int64_t pb, int64_t pn,
                                                                        const float* __restrict__ score, int64_t sb, int N,
                                                                        float thr, int64_t* __restrict__ index,
