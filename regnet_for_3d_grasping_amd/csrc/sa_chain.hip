@@ -202,11 +202,12 @@ __device__ __forceinline__ void chain_group(const ChainArgs& p, const float* __r
 }
 
 // Measurement hook: scripts/wg_timeline.py builds a variant with -DCH_TRACE_H='"<repo>/scripts/ablate/chain_trace.h"', which
-// defines the two macros (per-workgroup start / end stamps + placement) and its own debug export; the product compiles none.
+// defines the three macros (per-workgroup start / end stamps + placement) and its own debug export; the product compiles none.
 #ifdef CH_TRACE_H
 #include CH_TRACE_H
 #else
 #define CH_TRACE_BEGIN()
+#define CH_TRACE_MID()
 #define CH_TRACE_END()
 #endif
 
@@ -289,6 +290,7 @@ __global__ __launch_bounds__(CH_THREADS, 2) void sa_chain_kernel(const ChainArgs
     }
   }
   __syncthreads();
+  CH_TRACE_MID();
 
   if (npt == 2) chain_group<2>(p, sW2, sW3, sW1, sS2, sT2, sPart, role, x, gs, valid, w3a, w3b, tid, lane, fr, fh, t_row0, t_c4);
   else chain_group<1>(p, sW2, sW3, sW1, sS2, sT2, sPart, role, x, gs, valid, w3a, w3b, tid, lane, fr, fh, t_row0, t_c4);

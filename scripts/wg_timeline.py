@@ -59,12 +59,22 @@ def run(label, blocks, mode=6):
         o = m[np.argsort(s[m])]
         gaps.extend((s[o][1:] - e[o][:-1]).tolist())
     gaps = np.asarray(gaps)
+    # workgroups are handed out in class order (fused.chain3_order): duration by twentieth of the launch, and the trace's own
+    # stamps say how long a workgroup takes from its first instruction (weight staging included) to its last
+    d = e - s
+    setup = (t[:, 3] >> 8) / 100.0
+    print("   set-up (start -> weights staged + neighbourhood gathered, us) by twentieth:", " ".join("%.1f" % setup[i].mean() for i in np.array_split(np.arange(NB), 20)))
+    parts = np.array_split(np.arange(NB), 20)
+    print("   workgroup duration by twentieth of the block range (us):", " ".join("%.0f" % d[i].mean() for i in parts))
+    print("   sum of workgroup durations / (CUs x span) = %.3f; sum of between-workgroup gaps / (CUs x span) = %.3f" % (
+        d.sum() / (len(ids) * e.max()), gaps.sum() / (len(ids) * e.max())))
     print("   workgroups per CU: min %d max %d; idle time between consecutive workgroups of a CU: median %.2f us, p90 %.1f, max %.1f, sum per CU %.1f us"
           % (per_cu.min(), per_cu.max(), np.median(gaps), np.percentile(gaps, 90), gaps.max(), gaps.sum() / len(ids)))
 
 
 run("alone", 0)
-run("1 CU held", 1)
-run("8 CUs held, one per XCD", 8)
-run("16 CUs held, two per XCD", 16)
-run("8 CUs of ONE XCD held", 64, 16 + 7)
+if os.environ.get("HELD", "1") == "1":
+    run("1 CU held", 1)
+    run("8 CUs held, one per XCD", 8)
+    run("16 CUs held, two per XCD", 16)
+    run("8 CUs of ONE XCD held", 64, 16 + 7)
