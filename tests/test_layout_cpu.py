@@ -144,3 +144,28 @@ def test_density_matched_generator_reproduces_the_reference_histogram():
     # the fixtures' generator: same bytes as before the keyword existed
     assert hashlib.sha256(synthetic.make_scene(1000).tobytes()).hexdigest().startswith("8d35fe7b114468ee")
     assert np.array_equal(synthetic.make_batch(1000, 1, 512)[0].numpy(), synthetic.make_scene(1000, 512))
+
+
+def test_experiment_patches_still_apply_to_the_product_sources():
+    """scripts/ablate/*.patch are measured-and-not-kept kernels and measurement switches kept as patches against the product sources
+    (DESIGN.md par. 13.3, 13.7): one that stops applying no longer describes the product.  ``historical_*`` are records of earlier
+    rounds' experiments against sources that have moved on; ``geometry_measure.patch`` writes a twin file (csrc/build.py)."""
+    import glob
+    import os
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("patch") is None:
+        import pytest
+        pytest.skip("no patch(1) here")
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    live = sorted(p for p in glob.glob(os.path.join(repo, "scripts", "ablate", "*.patch"))
+                  if not os.path.basename(p).startswith("historical_") and os.path.basename(p) != "geometry_measure.patch")
+    assert len(live) >= 4
+    for path in live:
+        r = subprocess.run(["patch", "--dry-run", "-s", "-p1", "-i", path], cwd=repo, capture_output=True, text=True)
+        assert r.returncode == 0, (os.path.basename(path), r.stdout[-400:], r.stderr[-400:])
+    from regnet_for_3d_grasping_amd.csrc import build
+    with tempfile.TemporaryDirectory() as tmp:
+        twin = build.measurement_twin("geometry.hip", tmp)
+        assert os.path.getsize(twin) > os.path.getsize(os.path.join(repo, "regnet_for_3d_grasping_amd", "csrc", "geometry.hip"))
