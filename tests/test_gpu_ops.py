@@ -575,6 +575,29 @@ def test_select_positive_matches_oracle():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("N", [1, 10, 63, 64, 65, 511, 513, 1025, 25600])
+def test_select_positive_segment_edges(N):
+    """Clouds shorter than one wave's segment, one point past a segment boundary, and the bench size: every wave of the
+    workgroup walks its own contiguous segment (csrc/region.hip: SP_WAVES)."""
+    import numpy as np
+    from oracle import region_oracle
+    from regnet_for_3d_grasping_amd import region_ops
+    rng = np.random.default_rng(N)
+    pc = torch.tensor(rng.normal(size=(3, N, 6)), dtype=torch.float32)
+    score = torch.tensor(rng.uniform(size=(3, N)), dtype=torch.float32)
+    score[1] = 1.0             # every point positive
+    score[2, :-1] = 0.0        # at most the last one
+    want = region_oracle.select_positive(pc, score, 0.5)
+    got = region_ops.select_positive(pc.cuda(), score.cuda(), 0.5)
+    assert torch.equal(got[2].cpu(), want[2])
+    for b in range(3):
+        n = int(want[2][b])
+        assert torch.equal(got[0][b, :n].cpu(), want[0][b, :n])
+        if n:
+            assert torch.equal(got[1][b].cpu(), want[1][b])
+
+
+@pytest.mark.gpu
 def test_centre_picker_batched_sampling_equals_per_scene(monkeypatch):
     import numpy as np
     from regnet_for_3d_grasping_amd import get_regiondataset as grd, synthetic
