@@ -68,6 +68,10 @@ LEVEL_EVENTS = False
 # ... but for the FIRST batch of a run only: nothing else is on the chip while its geometry is computed, so its level-1 block
 # may start as soon as level 1's ball query is there (levels 2-3 and the 3-NN searches then run beside it)
 FIRST_BATCH_LEVEL_EVENTS = True
+# The first sampling launch of a run as TWO launches on the two sampling streams: the first batch alone, the rest of the look-ahead
+# beside it -- the first batch's centroids are there when ITS 8 workgroups are done, not when all 160 are (14 alternating 20-step runs on one
+# box: 7.943 -> 7.913 ms per step, medians 7.934 -> 7.913; outputs do not depend on how scenes are grouped into launches)
+SPLIT_FIRST_LAUNCH = True
 GRAPH_MAX_POINTS = 4 * 25600   # graphs="auto": batches of at most this many points replay hipGraphs (launch-bound shapes)
 
 
@@ -519,7 +523,12 @@ class ForwardPipeline:
                     if pcs:
                         if first_launch:
                             self.first_launch_batches = len(pcs)
-                        sampled.extend(self._sample_group(pcs, first=first_launch))
+                        if (first_launch and SPLIT_FIRST_LAUNCH and len(pcs) > 1 and len(self.s_fps) > 1
+                                and not self._one_sampling_stream):
+                            sampled.extend(self._sample_group(pcs[:1], first=True))
+                            sampled.extend(self._sample_group(pcs[1:], first=False))
+                        else:
+                            sampled.extend(self._sample_group(pcs, first=first_launch))
                         first_launch = False
                 if not sampled and not geo_q:
                     break
