@@ -1282,6 +1282,12 @@ static int fps_num_cus() {
 #ifndef FPS_COOP
 #define FPS_COOP 1       // 1: scenes beyond 25 600 points sample with fps_cluster_kernel<.., true> (several picks per exchange)
 #endif
+#ifndef FPS_COOP_MIN_N
+#define FPS_COOP_MIN_N FPS_RESIDENT_MAX   // scenes with MORE points sample on cooperating workgroups ...
+#endif
+#ifndef FPS_COOP_SLICE
+#define FPS_COOP_SLICE FPS_RESIDENT_MAX   // ... ceil(N / this) of them (measurement builds lower both: scripts/fps_coop_probe.sh)
+#endif
 #ifndef FPS_CLUSTER_MIN_PICKS_SMALL
 #define FPS_CLUSTER_MIN_PICKS_SMALL 512   // 4096 < N <= 8192: runs at least this long take the cluster kernel too
 #endif
@@ -1295,8 +1301,11 @@ static int fps_num_cus() {
 static const bool fps_coop_enabled = FPS_CLUSTERS != 0 && FPS_COOP != 0;
 static int64_t fps_xchg_offset_floats(int64_t B, int64_t N) { return (B * N + 3) / 4 * 4; }   // 16-byte aligned behind B x N words
 
+static bool fps_takes_coop_cluster_kernel(int64_t B, int64_t N, int64_t M);
 extern "C" int64_t regnet_fps_workspace_bytes(int64_t B, int64_t N, int64_t M) {
   (void)M;
+  if (N <= FPS_RESIDENT_MAX && fps_takes_coop_cluster_kernel(B, N, M))   // (measurement builds only: FPS_COOP_MIN_N < FPS_RESIDENT_MAX)
+    return fps_xchg_offset_floats(B, N) * (int64_t)sizeof(float) + B * (int64_t)FPS_XCHG_BYTES + FPS_STATUS_BYTES;
 #if FPS_CLUSTERS
   if (N > 8192 && N <= FPS_RESIDENT_MAX && M >= 1024 && M <= FPS_CLUSTER_MAX_PICKS)
     return B * N * (int64_t)sizeof(unsigned);   // fps_cluster_kernel: the sort's permutation
@@ -1310,8 +1319,8 @@ extern "C" int64_t regnet_fps_workspace_bytes(int64_t B, int64_t N, int64_t M) {
 
 // scenes beyond one CU's registers whose sampling runs on 2..4 cooperating workgroups (fps_cluster_kernel<.., true>)
 static bool fps_takes_coop_cluster_kernel(int64_t B, int64_t N, int64_t M) {
-  return fps_coop_enabled && N > FPS_RESIDENT_MAX && N <= FPS_MULTI_MAX && M >= 1024 && M <= FPS_CLUSTER_MAX_PICKS &&
-         ((N + FPS_RESIDENT_MAX - 1) / FPS_RESIDENT_MAX) * B <= fps_num_cus();
+  return fps_coop_enabled && N > FPS_COOP_MIN_N && N <= FPS_MULTI_MAX && M >= 1024 && M <= FPS_CLUSTER_MAX_PICKS &&
+         ((N + FPS_COOP_SLICE - 1) / FPS_COOP_SLICE) <= 4 && ((N + FPS_COOP_SLICE - 1) / FPS_COOP_SLICE) * B <= fps_num_cus();
 }
 
 extern "C" int64_t regnet_fps_status_offset_bytes(int64_t B, int64_t N, int64_t M) {
@@ -1368,7 +1377,22 @@ static int fps_launch(const float* xyz, int64_t sb, int64_t sc, int64_t sn, int6
   // order only if all points of a thread share one reference lane (j mod RB), i.e. T % RB == 0 or
   // one point per thread.  Hence T = RB (PPT 1) up to 512 points and T in {512, 1024} above.
   if (regnet_fps_workspace_bytes(B, N, M) > 0 && !workspace) return REGNET_ERR_NULL;
-  if (N <= 64) FPS_CASE(64, 1);
+  const bool coop = fps_takes_coop_cluster_kernel(B, N, M);
+  if (coop) {
+    // several exact picks per round on 2..4 cooperating workgroups per scene (fps_cluster_kernel<.., true>)
+    if (!workspace) return REGNET_ERR_NULL;
+    const int G = (int)((N + FPS_COOP_SLICE - 1) / FPS_COOP_SLICE);
+    const int Bpad = (int)((B + 7) / 8 * 8);                                       // a scene's workgroups on one XCD
+    const int64_t Nh = (N + G - 1) / G;
+    hipError_t e = hipMemsetAsync(workspace + fps_xchg_offset_floats(B, N), 0, (size_t)B * FPS_XCHG_BYTES + FPS_STATUS_BYTES,
+                                  st);   // tags 0 = nothing published, status 0 = no poll gave up
+    if (e != hipSuccess) return (int)e;
+    if (Nh <= 12288) FPS_COOP_CASE(12);
+    else if (Nh <= 16384) FPS_COOP_CASE(16);
+    else if (Nh <= 20480) FPS_COOP_CASE(20);
+    else FPS_COOP_CASE(25);
+  }
+  else if (N <= 64) FPS_CASE(64, 1);
   else if (N <= 128) FPS_CASE(128, 1);
   else if (N <= 256) FPS_CASE(256, 1);
   else if (N <= 512) FPS_CASE(512, 1);
@@ -1392,20 +1416,6 @@ static int fps_launch(const float* xyz, int64_t sb, int64_t sc, int64_t sn, int6
   else if (N <= 16384) FPS_WAVE_CASE(16);
   else if (N <= 20480) FPS_WAVE_CASE(20);
   else if (N <= FPS_RESIDENT_MAX) FPS_WAVE_CASE(25);
-  else if (fps_takes_coop_cluster_kernel(B, N, M)) {
-    // several exact picks per round on 2..4 cooperating workgroups per scene (fps_cluster_kernel<.., true>)
-    if (!workspace) return REGNET_ERR_NULL;
-    const int G = (int)((N + FPS_RESIDENT_MAX - 1) / FPS_RESIDENT_MAX);
-    const int Bpad = (int)((B + 7) / 8 * 8);                                       // a scene's workgroups on one XCD
-    const int64_t Nh = (N + G - 1) / G;
-    hipError_t e = hipMemsetAsync(workspace + fps_xchg_offset_floats(B, N), 0, (size_t)B * FPS_XCHG_BYTES + FPS_STATUS_BYTES,
-                                  st);   // tags 0 = nothing published, status 0 = no poll gave up
-    if (e != hipSuccess) return (int)e;
-    if (Nh <= 12288) FPS_COOP_CASE(12);
-    else if (Nh <= 16384) FPS_COOP_CASE(16);
-    else if (Nh <= 20480) FPS_COOP_CASE(20);
-    else FPS_COOP_CASE(25);
-  }
   else if (N <= FPS_MULTI_MAX && M < 32768 /* 15-bit round tag */ &&
            ((N + FPS_RESIDENT_MAX - 1) / FPS_RESIDENT_MAX) * B <= fps_num_cus()) {
     if (!workspace) return REGNET_ERR_NULL;
