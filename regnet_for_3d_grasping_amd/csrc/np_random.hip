@@ -16,6 +16,9 @@
 #include <stdlib.h>
 
 #include "../../include/regnet_hip.h"
+#if !defined(__HIP_DEVICE_COMPILE__)
+#include <immintrin.h>
+#endif
 
 // host-only translation unit that hipcc also parses for the device: the AVX2 clones exist in the host pass only
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -64,9 +67,81 @@ HOST_SIMD_CLONES void mt_twist(uint32_t* key) {
   key[N - 1] = key[M - 1] ^ (y >> 1) ^ ((uint32_t)(-(int32_t)(y & 1)) & MATRIX_A);
 }
 
+// ---- AVX-512 forms (host pass only; chosen at run time): the same arithmetic 16 words at a time.  The twist's second loop
+// reads words it has just written, 227 positions back: further than a vector.  Consumption: candidates are masked, compared and
+// COMPRESSED in a register (vpcompressd), widened to int64 and stored as two full vectors -- the slots behind the accepted
+// ones are overwritten by the next store, so a chunk is only taken while 16 more outputs fit in the row.
+#if !defined(__HIP_DEVICE_COMPILE__)
+#define TGT512 __attribute__((target("avx512f,avx512vl,avx512dq,popcnt")))
+bool has_avx512() {
+  static const bool v = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512vl") &&
+                        __builtin_cpu_supports("avx512dq") && getenv("REGNET_NP_RANDOM_SCALAR") == nullptr;
+  return v;
+}
+TGT512 inline void twist_range_512(uint32_t* key, int a, int b, int off) {
+  const __m512i upper = _mm512_set1_epi32((int)0x80000000u), lower = _mm512_set1_epi32(0x7fffffff);
+  const __m512i one = _mm512_set1_epi32(1), mat = _mm512_set1_epi32((int)0x9908b0dfu), zero = _mm512_setzero_si512();
+  int i = a;
+  for (; i + 16 <= b; i += 16) {
+    const __m512i x0 = _mm512_loadu_si512(key + i), x1 = _mm512_loadu_si512(key + i + 1), xm = _mm512_loadu_si512(key + i + off);
+    const __m512i y = _mm512_or_si512(_mm512_and_si512(x0, upper), _mm512_and_si512(x1, lower));
+    const __m512i mag = _mm512_and_si512(_mm512_sub_epi32(zero, _mm512_and_si512(y, one)), mat);
+    _mm512_storeu_si512(key + i, _mm512_xor_si512(_mm512_xor_si512(xm, _mm512_srli_epi32(y, 1)), mag));
+  }
+  for (; i < b; ++i) {
+    const uint32_t y = (key[i] & 0x80000000u) | (key[i + 1] & 0x7fffffffu);
+    key[i] = key[i + off] ^ (y >> 1) ^ ((uint32_t)(-(int32_t)(y & 1)) & 0x9908b0dfu);
+  }
+}
+TGT512 void mt_twist_512(uint32_t* key) {
+  const int N = 624, M = 397;
+  twist_range_512(key, 0, N - M, M);
+  twist_range_512(key, N - M, N - 1, M - N);
+  const uint32_t y = (key[N - 1] & 0x80000000u) | (key[0] & 0x7fffffffu);
+  key[N - 1] = key[M - 1] ^ (y >> 1) ^ ((uint32_t)(-(int32_t)(y & 1)) & 0x9908b0dfu);
+}
+TGT512 void mt_temper_512(const uint32_t* key, uint32_t* out) {
+  const __m512i b = _mm512_set1_epi32((int)0x9d2c5680u), c = _mm512_set1_epi32((int)0xefc60000u);
+  for (int i = 0; i < 624; i += 16) {
+    __m512i y = _mm512_loadu_si512(key + i);
+    y = _mm512_xor_si512(y, _mm512_srli_epi32(y, 11));
+    y = _mm512_xor_si512(y, _mm512_and_si512(_mm512_slli_epi32(y, 7), b));
+    y = _mm512_xor_si512(y, _mm512_and_si512(_mm512_slli_epi32(y, 15), c));
+    y = _mm512_xor_si512(y, _mm512_srli_epi32(y, 18));
+    _mm512_storeu_si512(out + i, y);
+  }
+}
+// whole 16-candidate chunks of cand[p ..] while 16 more outputs fit behind out[*pi]; -> the new p
+TGT512 int wr_chunks_512(const uint32_t* cand, int p, uint32_t mask, uint32_t rng, int64_t* out, int64_t* pi, int64_t size) {
+  const __m512i vmask = _mm512_set1_epi32((int)mask), vrng = _mm512_set1_epi32((int)rng);
+  int64_t i = *pi;
+  while (p + 16 <= 624 && i + 16 <= size) {
+    const __m512i v = _mm512_and_si512(_mm512_loadu_si512(cand + p), vmask);
+    const __mmask16 k = _mm512_cmple_epu32_mask(v, vrng);
+    const __m512i c = _mm512_maskz_compress_epi32(k, v);
+    _mm512_storeu_si512(out + i, _mm512_cvtepu32_epi64(_mm512_castsi512_si256(c)));
+    _mm512_storeu_si512(out + i + 8, _mm512_cvtepu32_epi64(_mm512_extracti64x4_epi64(c, 1)));
+    i += __builtin_popcount((unsigned)k);
+    p += 16;
+  }
+  *pi = i;
+  return p;
+}
+#else
+inline bool has_avx512() { return false; }
+inline void mt_twist_512(uint32_t*) {}
+inline void mt_temper_512(const uint32_t*, uint32_t*) {}
+inline int wr_chunks_512(const uint32_t*, int p, uint32_t, uint32_t, int64_t*, int64_t*, int64_t) { return p; }
+#endif
+
+inline void mt_temper_any(const uint32_t* key, uint32_t* out) {
+  if (has_avx512()) mt_temper_512(key, out);
+  else mt_temper(key, out);
+}
+
 inline void mt_refill(MT& s) {   // precondition: s.pos == 624
-  mt_twist(s.key);
-  mt_temper(s.key, s.out);
+  if (has_avx512()) { mt_twist_512(s.key); mt_temper_512(s.key, s.out); }
+  else { mt_twist(s.key); mt_temper(s.key, s.out); }
   s.pos = 0;
 }
 
@@ -89,6 +164,7 @@ inline void draw_with_replacement(MT& s, uint32_t n, int64_t size, int64_t* out)
   while (i < size) {
     if (s.pos == 624) mt_refill(s);
     int p = s.pos;
+    if (has_avx512()) p = wr_chunks_512(s.out, p, mask, rng, out, &i, size);
     for (; p < 624 && i < size; ++p) {
       const uint32_t v = s.out[p] & mask;
       out[i] = v;
@@ -100,17 +176,22 @@ inline void draw_with_replacement(MT& s, uint32_t n, int64_t size, int64_t* out)
 
 // permutation(n)[:size]: Fisher-Yates from the top, j = random_interval(i) by masked rejection; a rejected candidate
 // swaps element i with itself and leaves i unchanged
-inline void draw_without_replacement(MT& s, uint32_t n, int64_t size, int64_t* out, int64_t* scratch) {
+inline void draw_without_replacement(MT& s, uint32_t n, int64_t size, int64_t* out, uint32_t* scratch) {
   for (uint32_t i = 0; i < n; ++i) scratch[i] = i;
   uint32_t i = n - 1;
+  // mask = smallest 2^k - 1 >= i (numpy recomputes it from i in every call of random_interval): i falls by at most one per step,
+  // so it halves at most once per step -- a compare and a conditional move on the loop's dependency chain (i -> mask -> candidate ->
+  // accepted -> i) instead of five shift-or pairs; 32-bit scratch (n < 2^31)
+  uint32_t mask = mask_for(i);
   while (i >= 1) {
     if (s.pos == 624) mt_refill(s);
     int p = s.pos;
     for (; p < 624 && i >= 1; ++p) {
-      const uint32_t v = s.out[p] & mask_for(i);
+      mask = (i <= (mask >> 1)) ? (mask >> 1) : mask;
+      const uint32_t v = s.out[p] & mask;
       const uint32_t ok = v <= i;
       const uint32_t j = ok ? v : i;
-      const int64_t t = scratch[j]; scratch[j] = scratch[i]; scratch[i] = t;
+      const uint32_t t = scratch[j]; scratch[j] = scratch[i]; scratch[i] = t;
       i -= ok;
     }
     s.pos = p;
@@ -131,13 +212,13 @@ extern "C" int regnet_np_choice_rows(uint32_t* mt_key, int32_t* mt_pos, const in
   MT s;
   s.key = mt_key;
   s.pos = *mt_pos;
-  mt_temper(s.key, s.out);   // words at positions >= pos are still to be consumed
+  mt_temper_any(s.key, s.out);   // words at positions >= pos are still to be consumed
   int64_t maxn = 0;
   for (int64_t r = 0; r < rows; ++r) {
     if (counts[r] < 0) return REGNET_ERR_SHAPE;
     if (counts[r] > maxn) maxn = counts[r];
   }
-  int64_t* scratch = (int64_t*)malloc(sizeof(int64_t) * (size_t)(maxn > 0 ? maxn : 1));
+  uint32_t* scratch = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)(maxn > 0 ? maxn : 1));
   if (!scratch) return REGNET_ERR_UNSUPPORTED;
   for (int64_t r = 0; r < rows; ++r) {
     const int64_t n = counts[r];
