@@ -67,10 +67,12 @@ def parse():
     ap.add_argument("--first-launch-groups", type=int, default=4,
                     help="sampling groups the FIRST sampling launch of a run takes (it finds the chip idle); the line reports "
                          "the resulting look-ahead (config.sampling_lookahead_batches) and value_no_lookahead beside the headline")
-    ap.add_argument("--train-steps", type=int, default=8,
+    ap.add_argument("--train-steps", type=int, default=24,
                     help="forward bench only: training iterations (configs[3] shapes, batch --train-batch) timed AFTER the timed "
                          "region for the line's \"train\" object (5 warm-up iterations first); 0 = skip")
     ap.add_argument("--train-batch", type=int, default=8)
+    ap.add_argument("--train-graphs", choices=("auto", "on", "off"), default="auto",
+                    help="replay the fixed-shape part of a training iteration as hipGraphs (train_step._TrunkGraphs); auto = the module switch")
     ap.add_argument("--train-distinct-batches", type=int, default=4,
                     help="training measurement: distinct batches the iterations cycle through (labels and scenes resident)")
     ap.add_argument("--train-timeline-steps", type=int, default=3,
@@ -344,6 +346,7 @@ class HostBlockedTime:
 
     def __init__(self):
         self.seconds, self.calls, self._saved = 0.0, 0, []
+        self.log = []       # (name, seconds) of every blocking call, in order (measure_train slices it per iteration)
 
     def _wrap(self, owner, name, needs_cuda_self):
         orig = getattr(owner, name)
@@ -356,8 +359,10 @@ class HostBlockedTime:
             try:
                 return orig(*a, **k)
             finally:
-                outer.seconds += time.perf_counter() - t
+                d = time.perf_counter() - t
+                outer.seconds += d
                 outer.calls += 1
+                outer.log.append((name, d))
         self._saved.append((owner, name, orig))
         setattr(owner, name, timed)
 
@@ -415,6 +420,29 @@ def gpu_timeline(step_fn, n):
         return {"error": repr(exc)[:200]}
 
 
+def train_phases(marks):
+    """RefineTrainer.phase_marks of the timed iterations (after a synchronisation) -> per-iteration durations and, for
+    replayed iterations, the median split of an iteration of the trunk's stream: forward / head backward / wait for the
+    region stage and its backward / trunk backward / all-reduce + optimizers; ``busy_ms`` = the four pieces of own work."""
+    if not marks:
+        return {}
+    iters = []
+    for a, b in zip(marks[:-1], marks[1:]):
+        iters.append(a["start"].elapsed_time(b["start"]))
+    iters.append(marks[-1]["start"].elapsed_time(marks[-1]["end"]))
+    out = {"iteration_ms": [round(x, 3) for x in iters], "iteration_median_ms": round(float(np.median(iters)), 3)}
+    full = [m for m in marks if all(k in m for k in ("forward", "head", "joined", "trunk", "end"))]
+    if full:
+        def med(a, b):
+            return round(float(np.median([m[a].elapsed_time(m[b]) for m in full])), 3)
+        ph = {"forward_ms": med("start", "forward"), "head_backward_ms": med("forward", "head"),
+              "region_wait_ms": med("head", "joined"), "trunk_backward_ms": med("joined", "trunk"),
+              "allreduce_optimizer_ms": med("trunk", "end"), "iterations": len(full)}
+        ph["busy_ms"] = round(ph["forward_ms"] + ph["head_backward_ms"] + ph["trunk_backward_ms"] + ph["allreduce_optimizer_ms"], 3)
+        out["phases"] = ph
+    return out
+
+
 def _cpu_model():
     try:
         with open("/proc/cpuinfo") as f:
@@ -459,7 +487,7 @@ def measure_train(args, rank, world, dev, steps, warmup, batch):
     import gc
     gc_was_on = gc.isenabled()
     trainer = RefineTrainer(score_net.to(dev), region_net.to(dev), pipeline.PARAMS, pipeline.GRIPPER_PARAMS,
-                            gc_interval=args.gc_interval)
+                            gc_interval=args.gc_interval, graphs={"auto": None, "on": True, "off": False}[args.train_graphs])
     np.random.seed(rank)
     # HIP events around the native 1x1-convolution kernels (forward / input gradient / weight gradient: the MFMA work of
     # the iteration) on the stream they are launched on, inside the timed region
@@ -488,9 +516,14 @@ def measure_train(args, rank, world, dev, steps, warmup, batch):
     blocked = HostBlockedTime()
     region_steps = refine_steps = 0
     allreduce_ms = []
+    trainer.phase_marks = []         # HIP events on the trunk's stream at the phase boundaries of every iteration
+    host_marks, blocked_at = [], []
+    replays_before = trainer.graph_replays
     with blocked:
         t0 = time.perf_counter()
         for _ in range(steps):
+            host_marks.append(time.perf_counter())
+            blocked_at.append(len(blocked.log))
             nxt = trainer.prefetch(batches[(it + 1) % distinct][0])
             pc, target, records = batches[it % distinct]
             loss, parts = trainer.step(pc, target, records, plan=ahead)
@@ -499,17 +532,52 @@ def measure_train(args, rank, world, dev, steps, warmup, batch):
             refine_steps += parts.get("refine") is not None
             if trainer.bucket is not None and trainer.bucket.last_ms is not None:
                 allreduce_ms.append(trainer.bucket.last_ms)
+        host_marks.append(time.perf_counter())
+        blocked_at.append(len(blocked.log))
         t_enqueued = time.perf_counter() - t0
         fence()
         dt_local = time.perf_counter() - t0
     dt = sharding.max_over_ranks(dt_local, dev)
     timer.enabled = False
+    marks, trainer.phase_marks = trainer.phase_marks, None
+    replays = trainer.graph_replays - replays_before
+    accounting_steps = 0
+    if replays:
+        # the timed iterations replayed hipGraphs: no wrapper ran.  The contractions' launch durations (the `roofline` object)
+        # come from a few extra EAGER iterations outside the timed region -- the same launches issued one by one
+        accounting_steps, saved = 4, trainer.graphs
+        trainer.graphs = False
+        timer.enabled = True
+        for _ in range(accounting_steps):
+            nxt = trainer.prefetch(batches[(it + 1) % distinct][0])
+            trainer.step(*batches[it % distinct], plan=ahead)
+            ahead, it = nxt, it + 1
+        torch.cuda.synchronize()
+        timer.enabled = False
+        trainer.graphs = saved
     for name, fn in originals.items():
         setattr(conv1x1_train, name, fn)
+    # per-iteration figures, all from this (un-profiled) timed region: the trunk stream's cadence and phases from the HIP
+    # events, the launching thread's time per iteration, and what each blocking read of an iteration waited
+    phases = train_phases(marks)
+    host_iter = [round((b - a) * 1e3, 3) for a, b in zip(host_marks[:-1], host_marks[1:])]
+    reads = [blocked.log[a:b] for a, b in zip(blocked_at[:-1], blocked_at[1:])]
+    n_reads = max((len(r) for r in reads), default=0)
+    read_wait = []
+    for j in range(n_reads):
+        col = [r[j] for r in reads if len(r) > j]
+        read_wait.append({"call": col[0][0], "median_ms": round(float(np.median([d for _, d in col])) * 1e3, 3),
+                          "max_ms": round(max(d for _, d in col) * 1e3, 3)})
     # where the GPU has nothing to run: a few MORE iterations under torch's profiler (kernel start / end stamps of every
-    # stream -> union of busy intervals), outside the timed region
-    gpu_idle = gpu_timeline(lambda k: trainer.step(*batches[(it + k) % distinct]), args.train_timeline_steps) \
-        if args.train_timeline_steps > 0 else None
+    # stream -> union of busy intervals), outside the timed region, with the same one-batch geometry look-ahead
+    state = {"ahead": ahead, "it": it}
+
+    def profiled_step(_k):
+        nxt_ = trainer.prefetch(batches[(state["it"] + 1) % distinct][0])
+        trainer.step(*batches[state["it"] % distinct], plan=state["ahead"])
+        state["ahead"], state["it"] = nxt_, state["it"] + 1
+
+    gpu_idle = gpu_timeline(profiled_step, args.train_timeline_steps) if args.train_timeline_steps > 0 else None
     # what the trainer's own collection (every TRAIN_GC_INTERVAL iterations) costs: one collection timed here, amortised below
     t1 = time.perf_counter()
     gc.collect()
@@ -518,12 +586,22 @@ def measure_train(args, rank, world, dev, steps, warmup, batch):
         gc.enable()
     if rank != 0:
         return None
-    _, roofline = roofline_of(timer.summary(), steps, B)
+    _, roofline = roofline_of(timer.summary(), accounting_steps or steps, B)
+    if roofline and accounting_steps:
+        roofline["accounting_note"] = ("the %d timed iterations replayed hipGraphs; launch durations are from %d extra eager "
+                                       "iterations outside the timed region" % (steps, accounting_steps))
     grads = sum(p.numel() for net in (score_net, region_net) for p in net.parameters())
     return {"metric": "train scenes/sec (%s-pt ScoreNet+GRN+Refine training iteration)" % _pts(N),
             "value": round(B * steps * world / dt, 3), "unit": "scenes/s", "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic", "roofline": roofline,
+            # every timed iteration by itself (HIP events on the trunk's stream, iteration i = start mark i -> start mark i + 1,
+            # the last one -> its own end mark): a stall shows as an outlier here, a slow host as a level shift of
+            # host_iteration_ms; the phases split the trunk stream's time into its own work and the wait for the region stage
+            "ms_per_step_median": phases.get("iteration_median_ms"), "iteration_ms": phases.get("iteration_ms"),
+            "host_iteration_ms": host_iter, "trunk_stream": phases.get("phases"),
+            "graph_replays": replays,
+            "readback_wait_ms": read_wait,
             # the launching thread: wall time of the timed iterations minus the time it was BLOCKED in a device->host read or
             # a synchronisation (waiting for the GPU); host_ms_per_step ~ ms_per_step means the iteration is paced by the host
             "host_ms_per_step": round((dt_local - blocked.seconds) / steps * 1e3, 3),

@@ -344,6 +344,164 @@ class GeometryPrefetcher:
         return handle["plan"]
 
 
+
+# RefineTrainer: replay the fixed-shape part of an iteration -- ScoreNet's forward, the segmentation head's backward, the trunk's
+# backward: ~450 of an iteration's ~590 launches, 11-12 ms of the launching thread's time at 8 x 25 600 -- as three hipGraphs
+# (``_TrunkGraphs``) once this many eager iterations of the same shape have run (every lazily built cache must exist before
+# a capture).  The region stage in between is the reference's host code (data-dependent sizes, numpy's stream) and stays
+# eager.  Module switch, like the others: nothing in the product reads the environment.
+TRAIN_GRAPHS = True
+GRAPH_WARMUP_ITERATIONS = 2
+
+
+def _clone_plan(plan):
+    """A geometry plan with every tensor cloned (static addresses for a captured forward); other entries are kept."""
+    return {kind: [{k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in level.items()} for level in plan[kind]]
+            for kind in ("sa", "fp")}
+
+
+class _TrunkGraphs:
+    """hipGraph replays of the fixed-shape part of ONE training iteration shape (B, N) of ``RefineTrainer``:
+
+        g_forward   ScoreNet forward with labels (train-mode BatchNorm incl. running statistics, dropout from the graph-safe
+                    generator state) + the score loss + the feature map's contiguous rows for the region stage's pools
+        g_head      the segmentation head's backward (``torch.autograd.grad`` down to the 256-channel point feature)
+        g_trunk     the trunk's backward from the point feature's gradient -- a STATIC buffer the head's backward writes and
+                    the region stage's pools add to (``region_ops.set_feature_grad_sink``)
+
+    captured once from the same autograd graph the eager iteration builds (same kernels, same order, same streams' worth of
+    work) over static copies of the inputs -- the batch, its labels, its geometry plan (20 index / distance tensors, copied in
+    by two ``_foreach_copy_`` launches) -- and one private memory pool (~30 GB at 8 x 25 600: the activations an eager
+    iteration allocates and frees).  Parameter gradients land in static tensors (``p.grad`` of the ScoreNet parameters, or the
+    ``GradientBucket``'s views when a process group exists: captured as in-place accumulations behind ``prepare()``'s fill).
+    Valid while the parameters keep their addresses (optimizer steps and ``load_state_dict`` update in place) and the
+    module switches their values; ``matches`` is checked every step and a mismatch drops back to the eager path."""
+
+    def __init__(self, trainer, pc, pc_score, plan):
+        import gc
+        import weakref
+
+        from . import conv1x1_train, fused
+        net = trainer.score_net
+        seg = net.extrat_featurePN2
+        dev = pc.device
+        self.key = self._key(pc, pc_score)
+        self.params = [p for p in net.parameters() if p.requires_grad]
+        self.signature = self._signature()
+        self.head = [p for m in (seg.mlp, seg.conv_score, seg.bn_score) for p in m.parameters() if p.requires_grad]
+        self.pc, self.target = pc.clone(), pc_score.clone()
+        self.plan = _clone_plan(plan)
+        self.plan_tensors = fused.plan_tensors(self.plan)
+        self.stream = torch.cuda.Stream(dev)
+        bucket = trainer.bucket
+        if bucket is not None:
+            bucket.prepare()                 # p.grad = the bucket's views: the captured accumulations are in-place adds
+        else:
+            for p in self.params:
+                p.grad = None                # the captured backward ASSIGNS: these tensors are the static gradients
+        cur = torch.cuda.current_stream(dev)
+        self.stream.wait_stream(cur)
+        # no destructor of a stale graph may run while a stream captures (pipeline._StageGraphs): collect now, collector off
+        gc.collect()
+        gc_was_enabled = gc.isenabled()
+        gc.disable()
+        grabbed = {}
+        hook = seg.register_forward_hook(lambda _m, _i, out: grabbed.__setitem__("feat", out[0]))
+        # The captured forward sees every parameter through a fresh LEAF that shares its storage (optimizer steps and
+        # ``load_state_dict`` update in place, so replays read the current values).  Why not the parameters themselves: a
+        # parameter's gradient-accumulator node belongs to the stream of the iteration that created it and lives as long as
+        # ANY graph of that iteration (a loss a caller still holds); the autograd engine synchronises a backward with that
+        # node's stream even when ``autograd.grad`` only captures the gradient -- for a node of an earlier eager iteration that
+        # is a stream outside the capture (observed: hipStreamEndCapture crashes).  Fresh leaves get their nodes inside it.
+        named = [(n, p) for n, p in net.named_parameters() if p.requires_grad]
+        alias = {n: p.detach().requires_grad_(True) for n, p in named}
+        alias_of = {id(p): alias[n] for n, p in named}
+        head_ids = {id(p) for p in self.head}
+        trunk = [p for p in self.params if id(p) not in head_ids]
+        try:
+            self.g_forward, self.g_head, self.g_trunk = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.enable_grad():
+                with torch.cuda.graph(self.g_forward, stream=self.stream):
+                    all_feature, self.score, self.loss = torch.func.functional_call(
+                        net, alias, (self.pc, self.target, None), {"plan": self.plan})
+                    self.total = self.loss.sum()
+                    self.all_feature = all_feature.detach()
+                    self.rows = self.all_feature.contiguous().view(-1, all_feature.shape[2])
+                feat = grabbed["feat"]
+                before = conv1x1_train.reserve_stream_slots(HEAD_BACKWARD_FREE_SLOTS)
+                try:
+                    with torch.cuda.graph(self.g_head, stream=self.stream, pool=self.g_forward.pool()):
+                        grads = torch.autograd.grad(self.total, [feat] + [alias_of[id(p)] for p in self.head], retain_graph=True,
+                                                    allow_unused=True)
+                        self.g_feat = grads[0]
+                        if bucket is not None:
+                            for p, g in zip(self.head, grads[1:]):
+                                if g is not None:
+                                    p.grad.add_(g)
+                finally:
+                    conv1x1_train.reserve_stream_slots(before)
+                if not (self.g_feat.is_contiguous() and tuple(self.g_feat.shape) == tuple(feat.shape)):
+                    raise RuntimeError("the point feature's gradient is not a contiguous (B, C, N) tensor")
+                self.head_grads = [(p, g) for p, g in zip(self.head, grads[1:]) if g is not None]
+                with torch.cuda.graph(self.g_trunk, stream=self.stream, pool=self.g_forward.pool()):
+                    tgrads = torch.autograd.grad([feat], [alias_of[id(p)] for p in trunk], [self.g_feat], allow_unused=True)
+                    if bucket is not None:
+                        for p, g in zip(trunk, tgrads):
+                            if g is not None:
+                                p.grad.add_(g)
+                self.trunk_grads = [(p, g) for p, g in zip(trunk, tgrads) if g is not None]
+                if bucket is None:
+                    for p, g in self.trunk_grads + self.head_grads:
+                        p.grad = g
+        finally:
+            hook.remove()
+            if gc_was_enabled:
+                gc.enable()
+        cur.wait_stream(self.stream)
+        # (the captured autograd graph has been consumed; what is kept are plain tensors in the graphs' pool)
+        self.score, self.loss, self.total = self.score.detach(), self.loss.detach(), self.total.detach()
+        if bucket is not None:
+            bucket.mark_touched([p for p, _ in self.head_grads + self.trunk_grads])
+            self.touched = [i for i, t in enumerate(bucket.touched) if t]
+            self.static_grads = None
+        else:
+            self.static_grads = self.trunk_grads + self.head_grads
+        self._weakref = weakref
+        self.replays = 0
+
+    @staticmethod
+    def _key(pc, pc_score):
+        return (tuple(pc.shape), pc.dtype, tuple(pc_score.shape), pc_score.dtype, pc.device.index)
+
+    def _signature(self):
+        from . import bn_train, conv1x1_train
+        from .pn2_utils import modules
+        switches = tuple((m.__name__, k, v) for m in (conv1x1_train, bn_train, modules) for k, v in sorted(vars(m).items())
+                         if k.isupper() and isinstance(v, (bool, int, float)))
+        return (tuple(p.data_ptr() for p in self.params), switches, HEAD_BACKWARD_FREE_SLOTS)
+
+    def matches(self, pc, pc_score):
+        return self._key(pc, pc_score) == self.key and self._signature() == self.signature
+
+    def load(self, pc, pc_score, plan):
+        """This iteration's batch, labels and geometry plan -> the static buffers (on the current stream)."""
+        from . import fused
+        self.pc.copy_(pc)
+        self.target.copy_(pc_score)
+        src = fused.plan_tensors(plan)
+        if len(src) != len(self.plan_tensors) or any(a.shape != b.shape or a.dtype != b.dtype for a, b in zip(src, self.plan_tensors)):
+            raise RuntimeError("the geometry plan of this batch does not have the captured plan's layout")
+        torch._foreach_copy_(self.plan_tensors, src)
+
+    def feature_leaf(self):
+        """The replayed feature map as a fresh autograd leaf for the region stage, its contiguous rows already made."""
+        from . import gripper_region_network
+        leaf = self.all_feature.detach().requires_grad_(True)
+        gripper_region_network._rows_cache.ref = self._weakref.ref(leaf)
+        gripper_region_network._rows_cache.flat = self.rows
+        return leaf
+
+
 class RefineTrainer:
     """The reference's full training iteration (``--mode train``, train.py:347-384): ScoreNet and the
     grasp-region/refine network are trained together, one Adam + StepLR each,
@@ -353,8 +511,10 @@ class RefineTrainer:
     initialised.  BatchNorm running statistics stay per rank, as ``nn.DataParallel`` keeps them per replica (only device
     0's survive there; here ``broadcast_module_state`` before saving a checkpoint gives every rank rank 0's)."""
 
-    def __init__(self, score_net, region_net, params, gripper_params, lr=0.001, reduce="sum", gc_interval=None):
-        """``gc_interval``: every iteration builds and drops an autograd graph of a few thousand Python objects; CPython's
+    def __init__(self, score_net, region_net, params, gripper_params, lr=0.001, reduce="sum", gc_interval=None, graphs=None):
+        """``graphs``: replay ScoreNet's forward / the head's backward / the trunk's backward as hipGraphs (``_TrunkGraphs``)
+        once GRAPH_WARMUP_ITERATIONS eager iterations of a shape have run; None = the module switch TRAIN_GRAPHS (GPU only).
+        ``gc_interval``: every iteration builds and drops an autograd graph of a few thousand Python objects; CPython's
         automatic cyclic collector then runs a full collection every ~10 iterations that takes 60-100 ms with the device idle
         (measured: iterations of 59.5 ms with spikes of 106-157 ms; none with the collector off).  With ``gc_interval=N`` the
         trainer switches the automatic collector OFF (process-wide, like the "manual GC" switches of large training
@@ -373,6 +533,16 @@ class RefineTrainer:
         self.sched_region = torch.optim.lr_scheduler.StepLR(self.opt_region, step_size=5, gamma=0.5)
         self.geometry = GeometryPrefetcher(score_net)
         self._region_stream = None
+        self._marks = None
+        self.graphs = graphs
+        self._graphs = None              # _TrunkGraphs of the shape the last iterations had
+        self._eager_shape = (None, 0)    # (shape key, eager iterations of it so far)
+        self.graph_replays = 0           # iterations served by replays (bench.py reports it)
+        # measurement hook (bench.py --train): a list makes every iteration append {name: HIP event} marks on the stream
+        # the trunk runs on -- "start", and for a replayed iteration "forward", "head", "joined" (the region stage and its
+        # backward have been waited for), "trunk"; "end" behind the optimizers -- so that the trunk stream's own busy time is
+        # read from events, without a profiler
+        self.phase_marks = None
         # both networks' gradients in ONE flat buffer: one all-reduce per training iteration (28.3 MB for the reference's
         # 5 542 531 + 1 524 396 parameters)
         self.bucket = None           # created by the first step that finds a process group (_ensure_bucket)
@@ -399,10 +569,6 @@ class RefineTrainer:
         ``early_head_backward`` (used by ``step``): the score loss is back-propagated through the segmentation head
         right after the ScoreNet forward (see EARLY_HEAD_BACKWARD); ``parts['early']`` then carries what ``step`` needs
         to finish the backward pass, and the returned total has the same VALUE but only the region losses' graph."""
-        import contextlib
-        import io
-
-        from .get_regiondataset import get_grasp_allobj
         grabbed = {}
         hook = None
         if early_head_backward and torch.is_grad_enabled():
@@ -418,11 +584,10 @@ class RefineTrainer:
         parts = {"score": loss, "stage2": None, "refine": None}
         total = loss.sum()
         feat = grabbed.get("feat")
-        region_stream = contextlib.nullcontext()
+        forward_done = None
         if feat is not None and feat.requires_grad and total.requires_grad:
             seg = self.score_net.extrat_featurePN2
             head = [p for m in (seg.mlp, seg.conv_score, seg.bn_score) for p in m.parameters() if p.requires_grad]
-            forward_done = None
             if feat.is_cuda:
                 forward_done = torch.cuda.Event()
                 forward_done.record()
@@ -439,21 +604,33 @@ class RefineTrainer:
             all_feature = all_feature.detach().requires_grad_(True)
             parts["early"] = (feat, grads[0], head, grads[1:], total, all_feature)
             total = total.detach()       # its gradient is already out; what is added below is the region stage's share
-            if forward_done is not None:
-                # the region stage on its OWN stream, behind the forward only: its device->host reads would otherwise wait
-                # for the head's backward just enqueued on this stream (autograd runs a node's backward on the stream of its
-                # forward and orders streams itself; ``step`` joins the streams before the optimizer)
-                if self._region_stream is None:
-                    self._region_stream = torch.cuda.Stream(feat.device)
-                self._region_stream.wait_event(forward_done)
-                region_stream = torch.cuda.stream(self._region_stream)
-                parts["region_stream"] = self._region_stream
+        total = self._region_stage(pc, output_score, all_feature, grasp_records, total, parts, forward_done)
+        return total, parts
+
+    def _region_stage(self, pc, output_score, all_feature, grasp_records, total, parts, forward_done=None):
+        """Centre selection, grouping, grasp-region + refine networks and their losses (train.py:354-372) -> ``total`` plus the
+        region losses (``parts`` filled in).  ``forward_done``: an event recorded behind ScoreNet's forward when more work (the
+        segmentation head's backward) has been enqueued on the current stream since -- the stage then runs on its OWN stream
+        behind that event only: its device->host reads would otherwise wait for that work (autograd runs a node's backward on
+        the stream of its forward and orders streams itself; ``step`` joins the streams before the optimizer)."""
+        import contextlib
+        import io
+
+        from .get_regiondataset import get_grasp_allobj
+        region_stream = contextlib.nullcontext()
+        if forward_done is not None:
+            if self._region_stream is None:
+                self._region_stream = torch.cuda.Stream(all_feature.device)
+            self._region_stream.wait_event(forward_done)
+            region_stream = torch.cuda.stream(self._region_stream)
+            parts["region_stream"] = self._region_stream
         with region_stream:
             try:
                 with contextlib.redirect_stdout(io.StringIO()):
                     if all_feature.is_cuda:
                         # the feature map as contiguous rows (what both pools gather from: a 210 MB transpose at B = 8), enqueued
-                        # BEFORE the stage's first device->host read instead of between its host-paced launches
+                        # BEFORE the stage's first device->host read instead of between its host-paced launches (a replayed
+                        # forward has made them already: ``_TrunkGraphs`` seeds the cache)
                         from . import gripper_region_network
                         gripper_region_network._contiguous_rows(all_feature, detach=all_feature.requires_grad)
                     g = get_grasp_allobj(pc, output_score, self.params, grasp_records, defer_large_groups=True)
@@ -467,12 +644,99 @@ class RefineTrainer:
                     parts["refine"] = loss_refine_tuple[0]
             except (RuntimeError, IndexError, ValueError, ArithmeticError) as exc:   # the reference uses a bare except (train.py:430)
                 parts["region_error"] = repr(exc)
-        return total, parts
+        return total
+
+    def _graphs_for(self, pc, pc_score, plan):
+        """The ``_TrunkGraphs`` to replay this iteration with, or None for an eager iteration."""
+        on = TRAIN_GRAPHS if self.graphs is None else self.graphs
+        if not (on and EARLY_HEAD_BACKWARD and pc.is_cuda and pc_score is not None and pc_score.is_cuda):
+            return None
+        G = self._graphs
+        if G is not None:
+            if G.matches(pc, pc_score):
+                return G
+            self._graphs = None          # another shape / moved parameters / flipped switches: eager again, then a new capture
+            self._eager_shape = (None, 0)
+        key = _TrunkGraphs._key(pc, pc_score)
+        if self._eager_shape[0] != key or self._eager_shape[1] < GRAPH_WARMUP_ITERATIONS:
+            return None
+        geo = GeometryPrefetcher.acquire(plan, pc.device)
+        with torch.no_grad():
+            self._graphs = _TrunkGraphs(self, pc, pc_score, geo if geo is not None else self.score_net.plan(pc))
+        return self._graphs
+
+    def _step_graphed(self, G, pc, pc_score, grasp_records, plan):
+        """``step`` with the fixed-shape part replayed (``_TrunkGraphs``); the region stage, its backward, the all-reduce and
+        the optimizers are the eager iteration's."""
+        from . import region_ops
+        dev = pc.device
+        cur = torch.cuda.current_stream(dev)
+        geo = GeometryPrefetcher.acquire(plan, dev)
+        if geo is None:
+            with torch.no_grad():
+                geo = self.score_net.plan(pc)
+        G.load(pc, pc_score, geo)
+        marks = self._marks
+        if self.bucket is None:
+            self.opt_region.zero_grad()
+            for p, g in G.static_grads:      # (an eager iteration in between would have replaced them)
+                p.grad = g
+        else:
+            self.bucket.prepare()
+            for i in G.touched:
+                self.bucket.touched[i] = True
+        G.g_forward.replay()
+        forward_done = torch.cuda.Event(enable_timing=marks is not None)
+        forward_done.record()
+        G.g_head.replay()
+        if marks is not None:
+            marks["forward"] = forward_done
+            self._mark("head")
+        parts = {"score": G.loss.clone(), "stage2": None, "refine": None}
+        with torch.enable_grad():
+            leaf = G.feature_leaf()
+            total = self._region_stage(pc, G.score, leaf, grasp_records, G.total.clone(), parts, forward_done)
+            side = parts.pop("region_stream", None)
+            if side is not None:
+                cur.wait_stream(side)
+            if total.requires_grad:
+                head_done = torch.cuda.Event()
+                head_done.record()
+                region_ops.set_feature_grad_sink(G.g_feat, head_done)
+                try:
+                    total.backward()
+                finally:
+                    region_ops.set_feature_grad_sink(None)
+                if side is not None:
+                    cur.wait_stream(side)
+                if leaf.grad is not None:
+                    G.g_feat.add_(leaf.grad.transpose(1, 2))
+        self._mark("joined")
+        G.g_trunk.replay()
+        self._mark("trunk")
+        G.replays += 1
+        self.graph_replays += 1
+        return total.detach(), parts
+
+    def _mark(self, name):
+        if self._marks is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self._marks[name] = ev
 
     def step(self, pc, pc_score, grasp_records, plan=None):
         self.score_net.train()
         self.region_net.train()
         self._ensure_bucket()
+        self._marks = {} if (self.phase_marks is not None and pc.is_cuda) else None
+        self._mark("start")
+        G = self._graphs_for(pc, pc_score, plan)
+        if G is not None:
+            total, parts = self._step_graphed(G, pc, pc_score, grasp_records, plan)
+            return self._finish_step(total, parts)
+        if pc.is_cuda and pc_score is not None:
+            key = _TrunkGraphs._key(pc, pc_score)
+            self._eager_shape = (key, self._eager_shape[1] + 1 if self._eager_shape[0] == key else 1)
         if self.bucket is None:      # single process: gradients stay where autograd puts them (no accumulate-into-view adds)
             self.opt_score.zero_grad()
             self.opt_region.zero_grad()
@@ -516,17 +780,27 @@ class RefineTrainer:
                         extra = region_feature.grad.transpose(1, 2)
                         g_feat = extra if g_feat is None else g_feat + extra
                 torch.autograd.backward([feat], [g_feat])
+        return self._finish_step(total.detach(), parts)
+
+    def _finish_step(self, total, parts):
+        """The single gradient all-reduce, the two optimizer steps, housekeeping.  What is handed back carries no autograd
+        graph: a caller that keeps ``parts`` must not keep the iteration's activations (and its AccumulateGrad nodes) alive."""
+        parts = {k: (v.detach() if isinstance(v, torch.Tensor) else v) for k, v in parts.items()}
         if self.bucket is not None:
             self.bucket.reduce_gradients()
         self.opt_score.step()
         self.opt_region.step()
+        if self._marks is not None:
+            self._mark("end")
+            self.phase_marks.append(self._marks)
+            self._marks = None
         from . import gripper_region_network
         gripper_region_network.forget_rows()     # the iteration's contiguous feature rows (210 MB at B = 8) and their graph
         self._iterations += 1
         if self.gc_interval and self._iterations % self.gc_interval == 0:
             import gc
             gc.collect()
-        return total.detach(), parts
+        return total, parts
 
     def end_epoch(self):
         from . import pn2_ext
