@@ -1099,6 +1099,9 @@ def main():
                             "steps": train_line["steps"], "warmup": train_line["warmup"],
                             "batch_per_gpu": args.train_batch, "roofline": train_line["roofline"],
                             "allreduce_ms": train_line["allreduce_ms"], "workload": train_line["config"]["workload"],
+                            "ms_per_step_median": train_line["ms_per_step_median"], "iteration_ms": train_line["iteration_ms"],
+                            "host_iteration_ms": train_line["host_iteration_ms"], "trunk_stream": train_line["trunk_stream"],
+                            "graph_replays": train_line["graph_replays"], "readback_wait_ms": train_line["readback_wait_ms"],
                             "host_ms_per_step": train_line["host_ms_per_step"],
                             "host_blocked_ms_per_step": train_line["host_blocked_ms_per_step"],
                             "gpu_idle_ms_per_step": train_line["gpu_idle_ms_per_step"], "gpu_timeline": train_line["gpu_timeline"],

@@ -321,6 +321,19 @@ int regnet_rowsum_neg_f32(const float* x, int64_t rows, int64_t K, float* out, v
 int regnet_heads_chain_f32(const float* x, int64_t ldx, int64_t Kx, int64_t n, const int64_t* descr, int64_t layers,
                            float* out_a, int64_t lda, float* out_b, int64_t ldb, void* stream);
 
+/* regnet_heads_tree_f32: the same two trees for MANY rows (the 512 centres of 8 scenes, the 4000 of test.py:68) in one launch.
+ * A workgroup takes 32 rows; the wide trunk activation (pointnet2.py:174 / :240: 1024 columns) is produced 256 columns at a
+ * time and consumed at once by BOTH branches' first layers, whose weights the caller concatenates row-wise (N2 = 512 for
+ * 1024 -> 256 | 256, 256 for 1024 -> 128 | 128); their outputs accumulate in registers, so no row count needs the trunk in
+ * LDS and every weight fragment feeds two row blocks.  Same operand mapping and K order as regnet_heads_chain_f32: same bits.
+ * descr: (2 + tails) records of 11 int64 [W, scale, shift (device addresses, packed as above), K, Kpad, N, relu, src,
+ * src_off, dst, dst_off]; record 0 = trunk (K = Kx, Kpad = ceil16(Kx), N = Nt a multiple of 256), record 1 = the joined
+ * first layers (K = Kpad = Nt, N = N2 in {256, 512}), then tails <= 4 in execution order with src 0 = the stage-2 rows / 1 =
+ * the tail buffer read from column src_off (multiple of 4) on, dst 1 = the tail buffer at column dst_off, 4 / 5 = out_a (n,
+ * lda) / out_b (n, ldb).  REGNET_ERR_UNSUPPORTED beyond 160 KiB of LDS.                                                  */
+int regnet_heads_tree_f32(const float* x, int64_t ldx, int64_t Kx, int64_t n, const int64_t* descr, int64_t tails,
+                          float* out_a, int64_t lda, float* out_b, int64_t ldb, void* stream);
+
 /* The same heads in TRAINING mode, one layer per call (pointnet2.py:174-188, :240-253: nn.Conv1d(K, N, 1) with bias ->
  * nn.BatchNorm1d(N) on batch statistics -> [ReLU], on the R labelled centres / valid crops of the iteration): six launches
  * per layer forward and seven backward through torch, on a stream the host paces.

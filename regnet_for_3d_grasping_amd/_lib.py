@@ -49,6 +49,7 @@ SIGNATURES = {
     "regnet_ce_rows_f32": (_int, [_vp, _i64, _vp, _vp, _vp, _i64, _f32, _vp, _vp, _vp]),
     "regnet_refine_loss_rows_f32": (_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _f32, _f32, _i64, _vp, _vp, _vp, _vp, _vp]),
     "regnet_heads_chain_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
+    "regnet_heads_tree_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
     "regnet_head_layer_train_supported": (_int, [_i64, _i64, _i64]),
     "regnet_head_layer_train_fwd_f32": (_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _i64, _i64, _i64, _int,
                                                _vp, _vp, _vp, _vp]),

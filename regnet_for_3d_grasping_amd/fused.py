@@ -947,6 +947,48 @@ def _heads_chain(x, L, plan, n_a, n_b):
     return out_a, out_b
 
 
+HEADS_TREE = True    # more rows than HEADS_CHAIN_MAX_ROWS: ONE launch of csrc/heads.hip's heads_tree_kernel (32 rows per workgroup,
+                     # the trunk activation chunked through LDS) instead of a split-K GEMM + its reduction per layer
+
+
+def _heads_tree(net, x, L, trunk, first, tails, n_a, n_b):
+    """x (n, K) rows -> (out_a (n, n_a), out_b (n, n_b)) by ``regnet_heads_tree_f32``.  ``trunk``: layer name; ``first``: the
+    two branches' first layers (their packed weights / folded BatchNorm concatenated row-wise, cached on ``net`` with the
+    packed layers' signature); ``tails``: [(layer, src, src_off, dst, dst_off)] in execution order."""
+    n = x.shape[0]
+    x = x if x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0 else x.contiguous().clone()
+    la, lb = L[first[0]], L[first[1]]
+    cache = getattr(net, "_regnet_heads_tree", None)
+    key = (la.W.data_ptr(), lb.W.data_ptr(), la.scale.data_ptr(), lb.scale.data_ptr())
+    if cache is None or cache[0] != key:
+        joined = (torch.cat([la.W[:la.N], lb.W[:lb.N]]).contiguous(), torch.cat([la.scale, lb.scale]).contiguous(),
+                  torch.cat([la.shift, lb.shift]).contiguous())
+        cache = (key, joined)
+        net._regnet_heads_tree = cache
+    W2, s2, t2 = cache[1]
+    lt = L[trunk]
+    descr = [lt.W.data_ptr(), lt.scale.data_ptr(), lt.shift.data_ptr(), lt.K, lt.Kpad, lt.N, lt.relu, 0, 0, 0, 0,
+             W2.data_ptr(), s2.data_ptr(), t2.data_ptr(), lt.N, lt.N, la.N + lb.N, la.relu, 0, 0, 0, 0]
+    for name, src, src_off, dst, dst_off in tails:
+        lay = L[name]
+        descr += [lay.W.data_ptr(), lay.scale.data_ptr(), lay.shift.data_ptr(), lay.K, lay.Kpad, lay.N, lay.relu, src, src_off,
+                  dst, dst_off]
+    import ctypes
+    arr = (ctypes.c_int64 * len(descr))(*descr)
+    out_a = torch.empty((n, n_a), dtype=torch.float32, device=x.device)
+    out_b = torch.empty((n, n_b), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _check(_L.regnet_heads_tree_f32(x.data_ptr(), x.stride(0), x.shape[1], n, ctypes.addressof(arr), len(tails),
+                                        out_a.data_ptr(), n_a, out_b.data_ptr(), n_b, _stream(x)), "heads_tree")
+    return out_a, out_b
+
+
+def _tree_ok(L, trunk, first, x):
+    la, lb, lt = L[first[0]], L[first[1]], L[trunk]
+    return (HEADS_TREE and x.shape[1] % 4 == 0 and lt.N % 256 == 0 and la.K == lb.K == lt.N and la.relu == lb.relu
+            and la.N % 16 == 0 and la.N + lb.N in (256, 512))
+
+
 _TWOSTAGE_PLAN = [("conv", 0, 1), ("conv_cls2", 1, 2), ("conv_cls3", 2, 3), ("conv_cls4", 3, 4),
                   ("conv_reg2", 1, 2), ("conv_reg3", 2, 3), ("conv_reg4", 3, 5)]
 _REFINE_PLAN = [("conv_formal", 0, 1), ("conv_formal_cls2", 1, 2), ("conv_formal_cls3", 2, 4),
@@ -973,6 +1015,16 @@ def twostage_forward(net, mp_x, raw_reg=False):
         if not raw_reg:
             x_reg[:, :, 7:] = torch.sigmoid(x_reg[:, :, 7:])
         return x_cls, x_reg
+    if _tree_ok(L, "conv", ("conv_cls2", "conv_reg2"), x) and L["conv_cls3"].K == L["conv_cls2"].N:
+        n2, n3 = L["conv_cls2"].N, L["conv_cls3"].N
+        x_cls, x_reg = _heads_tree(net, x, L, "conv", ("conv_cls2", "conv_reg2"),
+                                   [("conv_cls3", 0, 0, 1, 0), ("conv_reg3", 0, n2, 1, _round_up(n3, 16)),
+                                    ("conv_cls4", 1, 0, 4, 0), ("conv_reg4", 1, _round_up(n3, 16), 5, 0)],
+                                   L["conv_cls4"].N, L["conv_reg4"].N)
+        x_reg = x_reg.view(n, -1, net.k_reg_no_anchor)
+        if not raw_reg:
+            x_reg[:, :, 7:] = torch.sigmoid(x_reg[:, :, 7:])
+        return x_cls, x_reg
     h = mlp_layer(x, L["conv"].K, L["conv"], n)
     x_cls = _chain(h, L, ["conv_cls2", "conv_cls3", "conv_cls4"])
     x_reg = _chain(h, L, ["conv_reg2", "conv_reg3", "conv_reg4"]).view(n, -1, net.k_reg_no_anchor)
@@ -988,6 +1040,12 @@ def refine_forward(net, x):
     L = _packed_named(net, _REFINE)
     if HEADS_CHAIN and n <= HEADS_CHAIN_MAX_ROWS and (x.numel() // max(n, 1)) % 16 == 0:
         return _heads_chain(x.reshape(n, -1), L, _REFINE_PLAN, L["conv_formal_cls3"].N, L["conv_formal_reg3"].N)
+    rows = x.reshape(n, -1)
+    if _tree_ok(L, "conv_formal", ("conv_formal_cls2", "conv_formal_reg2"), rows):
+        n2 = L["conv_formal_cls2"].N
+        return _heads_tree(net, rows, L, "conv_formal", ("conv_formal_cls2", "conv_formal_reg2"),
+                           [("conv_formal_cls3", 0, 0, 4, 0), ("conv_formal_reg3", 0, n2, 5, 0)],
+                           L["conv_formal_cls3"].N, L["conv_formal_reg3"].N)
     h = mlp_layer(x.reshape(n, -1).contiguous(), L["conv_formal"].K, L["conv_formal"], n)
     return (_chain(h, L, ["conv_formal_cls2", "conv_formal_cls3"]),
             _chain(h, L, ["conv_formal_reg2", "conv_formal_reg3"]))

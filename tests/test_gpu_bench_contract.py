@@ -55,7 +55,7 @@ def test_bench_under_torch_distributed_run_single_rank():
 
 def test_bench_line_carries_the_round3_fields():
     d = _line([sys.executable, "bench.py", "--steps", "6", "--warmup", "2", "--cpu-scenes", "0", "--latency-runs", "0",
-               "--no-lookahead-steps", "4", "--train-steps", "2"])
+               "--no-lookahead-steps", "4", "--train-steps", "6"])
     assert d["config"]["sampling_lookahead_batches"] == 6          # all six batches of the run were sampled by the first launch
     assert d["value_no_lookahead"] > 0 and "fps-group 1" in d["value_no_lookahead_note"]
     assert d["config"]["hip_graphs"] is False                       # 8 x 25 600 is not a launch-bound shape: one launch per kernel
@@ -64,6 +64,16 @@ def test_bench_line_carries_the_round3_fields():
     assert t["allreduce_ms"] is None                                # one rank: no collective
     assert 0 < t["host_ms_per_step"] <= t["ms_per_step"] * 1.05 and t["host_blocked_ms_per_step"] >= 0
     assert t["distinct_batches"] == 4 and t["bucket_bytes"] is None
+    # every timed iteration by itself (HIP events), its median, the launching thread's time per iteration, the blocking reads;
+    # all six iterations replayed hipGraphs (train_step._TrunkGraphs, captured during the five warm-up iterations), and the
+    # trunk stream's phases add up to an iteration
+    assert len(t["iteration_ms"]) == len(t["host_iteration_ms"]) == 6 and t["graph_replays"] == 6
+    assert min(t["iteration_ms"]) <= t["ms_per_step_median"] <= max(t["iteration_ms"])
+    ph = t["trunk_stream"]
+    assert ph["iterations"] == 6 and 0 < ph["busy_ms"] <= t["ms_per_step_median"] * 1.02
+    assert abs(ph["busy_ms"] + ph["region_wait_ms"] - t["ms_per_step_median"]) <= 0.1 * t["ms_per_step_median"]
+    assert t["readback_wait_ms"] and all(r["median_ms"] >= 0 for r in t["readback_wait_ms"])
+    assert "hipGraphs" in t["roofline"]["accounting_note"]
     g = t["gpu_timeline"]
     assert g is not None and ("error" in g or (g["busy_ms_per_step"] > 0 and g["idle_ms_per_step"] >= 0))
 

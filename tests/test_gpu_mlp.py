@@ -505,11 +505,13 @@ def test_fp_head_chain_interp_equals_interp_affine_then_chain(B, Nd, Ns):
     assert torch.equal(F2, F) and torch.equal(s2, s)
 
 
-@pytest.mark.parametrize("n", [1, 16, 64, 449, 512])
+@pytest.mark.parametrize("n", [1, 16, 33, 64, 257, 449, 512, 4000])
 def test_heads_chain_kernel_matches_the_layerwise_heads(n):
-    """fused.HEADS_CHAIN: the grasp-region head (7 layers) and the refine head (5 layers) as ONE launch each
-    (csrc/heads.hip: 16 rows per workgroup through the whole tree, activations in LDS) against the layer-by-layer split-K
-    path and against torch's own modules in float64 (pointnet2.py:174-188, :240-253)."""
+    """The grasp-region head (7 layers) and the refine head (5 layers) as ONE launch each -- fused.HEADS_CHAIN (csrc/heads.hip
+    heads_chain_kernel: 16 rows per workgroup through the whole tree, activations in LDS; the product's path up to 256 rows)
+    and fused.HEADS_TREE (heads_tree_kernel: 32 rows per workgroup, the trunk activation chunked; beyond 256 rows, up to the
+    4000 centres of test.py:68) -- against each other (same operand mapping and K order: the same bits), against the
+    layer-by-layer split-K path and against torch's own modules in float64 (pointnet2.py:174-188, :240-253)."""
     from regnet_for_3d_grasping_amd import fused, synthetic
     from regnet_for_3d_grasping_amd.gripper_region_network import GripperRegionNetwork
     net = GripperRegionNetwork(training=True, group_num=256, gripper_num=64, grasp_score_threshold=0.5, radius=0.06,
@@ -520,14 +522,18 @@ def test_heads_chain_kernel_matches_the_layerwise_heads(n):
     x2 = torch.randn(n, 256, 1, generator=g).to(DEV)
     x3 = torch.randn(n, 384, 1, generator=g).to(DEV)
     outs = {}
-    for flag in (True, False):
-        old, fused.HEADS_CHAIN = (fused.HEADS_CHAIN, fused.HEADS_CHAIN_MAX_ROWS), flag
-        fused.HEADS_CHAIN_MAX_ROWS = 1 << 20          # (the product uses the one-launch kernel up to 256 rows)
+    for flag, (chain, tree) in (("chain", (True, False)), ("tree", (False, True)), (False, (False, False))):
+        old = (fused.HEADS_CHAIN, fused.HEADS_CHAIN_MAX_ROWS, fused.HEADS_TREE)
+        fused.HEADS_CHAIN, fused.HEADS_TREE = chain, tree
+        fused.HEADS_CHAIN_MAX_ROWS = 1 << 20          # (the product uses heads_chain_kernel up to 256 rows only)
         try:
             with torch.no_grad():
                 outs[flag] = fused.twostage_forward(net.extrat_feature_region, x2) + fused.refine_forward(net.extrat_feature_refine, x3)
         finally:
-            fused.HEADS_CHAIN, fused.HEADS_CHAIN_MAX_ROWS = old
+            fused.HEADS_CHAIN, fused.HEADS_CHAIN_MAX_ROWS, fused.HEADS_TREE = old
+    for a, b in zip(outs["tree"], outs["chain"]):
+        assert a.shape == b.shape and torch.equal(a, b)
+    outs[True] = outs["tree"]
     for a, b in zip(outs[True], outs[False]):
         assert a.shape == b.shape
         torch.testing.assert_close(a, b, rtol=0, atol=2e-5)
