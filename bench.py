@@ -70,6 +70,9 @@ def parse():
     ap.add_argument("--train-steps", type=int, default=24,
                     help="forward bench only: training iterations (configs[3] shapes, batch --train-batch) timed AFTER the timed "
                          "region for the line's \"train\" object (5 warm-up iterations first); 0 = skip")
+    ap.add_argument("--single-rank-group", action="store_true",
+                    help="--gpus 1 only: initialise a ONE-rank RCCL process group anyway and run what a multi-GPU job runs on it "
+                         "(config.collective, the gradient bucket's all-reduce): scripts/scale_driver.sh at N = 1")
     ap.add_argument("--train-batch", type=int, default=8)
     ap.add_argument("--train-graphs", choices=("auto", "on", "off"), default="auto",
                     help="replay the fixed-shape part of a training iteration as hipGraphs (train_step._TrunkGraphs); auto = the module switch")
@@ -235,37 +238,16 @@ def pmc_traffic(kernel):
         return None
 
 
-def rocprof_launch(kernel):
-    """(average launch duration in ms, source file) of ``kernel``'s family in the committed rocprofv3 --kernel-trace --stats
-    summary of this same command (profiles/rocprof_launch_ms.json, written by scripts/rocprof_summary.py --json from the trace
-    whose text form is the file named in its "source"); (None, None) when there is no such entry."""
-    path = os.path.join(REPO, "profiles", "rocprof_launch_ms.json")
-    try:
-        with open(path) as f:
-            doc = json.load(f)
-        return doc["families"][kernel]["avg_launch_ms"], doc.get("source")
-    except (OSError, ValueError, KeyError):
-        return None, None
-
-
-def traffic_source():
-    """Is profiles/pmc_traffic.json still about THIS library?  Every kernel name the PMC passes recorded (``kernel_names`` per
-    family, scripts/collect_pmc.py) must be a kernel of the library that is loaded now (``nm -C`` of the .so: the kernel
-    handles carry rocprofv3's demangled spelling).  -> {"file", "stale": True / False / None (no names recorded or no nm),
-    "missing": [...]}."""
+def _library_kernels():
+    """Kernel names (rocprofv3's demangled spelling, template arguments kept, parameter list dropped) defined by the library
+    that is loaded now; empty set when ``nm`` is not usable."""
     import subprocess
     from regnet_for_3d_grasping_amd import _lib
-    path = os.path.join(REPO, "profiles", "pmc_traffic.json")
-    out = {"file": "profiles/pmc_traffic.json", "stale": None, "missing": []}
     try:
-        with open(path) as f:
-            recorded = sorted({n for v in json.load(f).values() if isinstance(v, dict) for n in v.get("kernel_names", [])})
         syms = subprocess.run(["nm", "-C", "--defined-only", _lib.LIB_PATH], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
                               text=True, timeout=60).stdout
-    except (OSError, ValueError, subprocess.SubprocessError):
-        return out
-    if not recorded or not syms:
-        return out
+    except (OSError, subprocess.SubprocessError):
+        return set()
     have = set()
     for line in syms.splitlines():
         parts = line.split(" ", 2)
@@ -280,6 +262,49 @@ def traffic_source():
                     name = name[:i]
                     break
             have.add(name)
+    return have
+
+
+def rocprof_launch(kernel, batch, points):
+    """(average launch duration in ms, source file, note) of ``kernel``'s family in the committed rocprofv3 --kernel-trace
+    --stats summary of this same command (profiles/rocprof_launch_ms.json, written by scripts/rocprof_summary.py --json from
+    the trace whose text form is the file named in its "source").  The duration is handed out only when the trace is about
+    THIS run: same scenes per batch and points per scene (the file's "workload"), and every kernel name it recorded for the
+    family still defined by the loaded library; otherwise (None, source, why)."""
+    path = os.path.join(REPO, "profiles", "rocprof_launch_ms.json")
+    try:
+        with open(path) as f:
+            doc = json.load(f)
+        fam = doc["families"][kernel]
+    except (OSError, ValueError, KeyError):
+        return None, None, "no committed trace entry for this kernel family"
+    src = doc.get("source")
+    wl = doc.get("workload") or {"batch": 8, "points": 25600}      # (files written before the field existed: the default command)
+    if (int(wl.get("batch", 0)), int(wl.get("points", 0))) != (int(batch), int(points)):
+        return None, src, "stale: the committed trace is of batch %s x %s points, this run of %d x %d" % (
+            wl.get("batch"), wl.get("points"), batch, points)
+    have = _library_kernels()
+    missing = [n for n in fam.get("kernel_names", []) if have and n not in have]
+    if missing:
+        return None, src, "stale: the loaded library no longer defines %s" % ", ".join(missing)
+    return fam["avg_launch_ms"], src, None
+
+
+def traffic_source():
+    """Is profiles/pmc_traffic.json still about THIS library?  Every kernel name the PMC passes recorded (``kernel_names`` per
+    family, scripts/collect_pmc.py) must be a kernel of the library that is loaded now (``nm -C`` of the .so: the kernel
+    handles carry rocprofv3's demangled spelling).  -> {"file", "stale": True / False / None (no names recorded or no nm),
+    "missing": [...]}."""
+    path = os.path.join(REPO, "profiles", "pmc_traffic.json")
+    out = {"file": "profiles/pmc_traffic.json", "stale": None, "missing": []}
+    try:
+        with open(path) as f:
+            recorded = sorted({n for v in json.load(f).values() if isinstance(v, dict) for n in v.get("kernel_names", [])})
+    except (OSError, ValueError):
+        return out
+    have = _library_kernels()
+    if not recorded or not have:
+        return out
     out["missing"] = [n for n in recorded if n not in have]
     out["stale"] = bool(out["missing"])
     return out
@@ -420,6 +445,31 @@ def gpu_timeline(step_fn, n):
         return {"error": repr(exc)[:200]}
 
 
+_REAL_STDOUT = None
+
+
+def guard_stdout():
+    """The contract is ONE JSON line on stdout.  Libraries write there too -- RCCL prints a five-line version banner to the
+    C-level stdout of rank 0 when its first communicator comes up, and C stdio flushes it at exit, AFTER the line.  So file
+    descriptor 1 is pointed at stderr for the whole run and the line is written to the real stdout by ``emit`` at the end."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(obj):
+    """The run's one JSON line, to the process's real stdout."""
+    data = (json.dumps(obj) + "\n").encode()
+    sys.stdout.flush()
+    if _REAL_STDOUT is None:
+        sys.stdout.write(data.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_REAL_STDOUT, data)
+
+
 def train_phases(marks):
     """RefineTrainer.phase_marks of the timed iterations (after a synchronisation) -> per-iteration durations and, for
     replayed iterations, the median split of an iteration of the trunk's stream: forward / head backward / wait for the
@@ -530,8 +580,8 @@ def measure_train(args, rank, world, dev, steps, warmup, batch):
             ahead, it = nxt, it + 1
             region_steps += "region_error" not in parts
             refine_steps += parts.get("refine") is not None
-            if trainer.bucket is not None and trainer.bucket.last_ms is not None:
-                allreduce_ms.append(trainer.bucket.last_ms)
+            if trainer.bucket is not None and trainer.bucket.last_allreduce_ms() is not None:
+                allreduce_ms.append(trainer.bucket.last_ms)      # (the most recent gradient all-reduce whose events completed)
         host_marks.append(time.perf_counter())
         blocked_at.append(len(blocked.log))
         t_enqueued = time.perf_counter() - t0
@@ -633,7 +683,7 @@ def run_train(args, rank, world, dev, collective=None):
         if collective is not None:
             res["config"]["collective"] = dict(collective, bucket_bytes=res["config"].pop("bucket_bytes", None),
                                                allreduce_ms=res["allreduce_ms"])
-        print(json.dumps(res))
+        emit(res)
 
 
 def roofline_of(agg, steps, batch, critical=None):
@@ -718,6 +768,7 @@ def sa_chain_executed_share(score_net, pcs):
 
 def main():
     args = parse()
+    guard_stdout()
     from regnet_for_3d_grasping_amd import sharding
     rank, local_rank, world = sharding.env_world()
     if not torch.cuda.is_available():
@@ -740,7 +791,16 @@ def main():
             raise SystemExit("bench.py --gpus %d: the process group's backend is %r, not nccl (= RCCL on ROCm)" % (world, dist.get_backend()))
     # what the process group really is (backend, world size, RCCL version, a startup all-reduce proving `world` distinct
     # ranks / devices, the gradient-bucket-sized all-reduce's duration and bus bandwidth): config.collective of both lines
-    collective = sharding.describe_collective(dev) if world > 1 else None
+    if world == 1 and args.single_rank_group:
+        # the multi-GPU code path on one GPU: a one-rank RCCL communicator, every collective of the job issued on it
+        sharding.SINGLE_RANK_GROUP = True
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        pinned = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else []
+        sharding.init("nccl", dev)
+    collective = sharding.describe_collective(dev) if sharding.group_active() else None
     if collective is not None:
         collective["pinned_cores"] = len(pinned)
         if collective["distinct_ranks_by_allreduce"] != world or (not one_device and collective["distinct_devices"] != world):
@@ -760,7 +820,7 @@ def main():
         args.batch = args.train_batch = args.global_batch // world
     if args.train:
         run_train(args, rank, world, dev, collective)
-        if world > 1:
+        if torch.distributed.is_initialized():
             torch.distributed.destroy_process_group()
         return
 
@@ -848,6 +908,7 @@ def main():
     main_summary = timer.summary() if rank == 0 else None
     dt = sharding.max_over_ranks(dt, dev)
     first_launch_batches = pipe.first_launch_batches
+    first_launch_split = getattr(pipe, "first_launch_split", None)
     graph_replays = pipe.graph_replays
     graph_accounting_steps = 0
     if graph_replays and rank == 0:
@@ -996,9 +1057,12 @@ def main():
             roofline["achieved"] = round(roofline["achieved_algorithmic"] * k_share, 4)
             roofline["frac_executed"] = roofline["frac"]
             roofline["executed_flop_per_launch"] = round(roofline["algorithmic_units_per_launch"] * k_share)
-            rp_ms, rp_src = rocprof_launch(roofline["kernel"])
+            rp_ms, rp_src, rp_note = rocprof_launch(roofline["kernel"], args.batch, args.points)
             roofline["rocprof_avg_launch_ms"] = rp_ms
             roofline["rocprof_source"] = rp_src
+            roofline["frac_rocprof"] = None
+            if rp_note:
+                roofline["rocprof_note"] = rp_note
             if rp_ms:
                 # the same fraction from the committed trace's duration instead of this run's events (the trace is of
                 # another run of this command on another box: durations differ by a few per cent)
@@ -1035,6 +1099,9 @@ def main():
                        # batches the pipeline pulled from its input before the first result could exist (the first sampling
                        # launch of the timed run); steady state: up to 2 x sampling_group_batches
                        "sampling_lookahead_batches": first_launch_batches,
+                       # ... issued as this many launches of these sizes (pipeline.SPLIT_FIRST_LAUNCH: batch 1 alone on one
+                       # sampling stream so that its features start 0.5 ms earlier, the rest on the other); null = one launch
+                       "sampling_first_launch_split": list(first_launch_split) if first_launch_split else None,
                        # distinct batches the steps cycle through (seeds 1000 + (k*W + rank)*B ...)
                        "distinct_batches": distinct,
                        # automatic garbage collections of the host interpreter inside the timed region (all threads)
@@ -1113,8 +1180,8 @@ def main():
             res["cpu_baseline"] = cpu_baseline(args, args.cpu_scenes, (score_net, region_net))
             res["parity"] = res["cpu_baseline"].pop("parity")
             res["speedup_vs_cpu_baseline"] = round(res["value"] / res["cpu_baseline"]["value"], 1)
-        print(json.dumps(res))
-    if world > 1:
+        emit(res)
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

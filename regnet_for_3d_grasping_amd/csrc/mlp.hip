@@ -116,6 +116,11 @@ __device__ __forceinline__ void xcd_tile(unsigned vblock, int& tm, int& tn, int 
   tn = (int)(t % tiles_n);
 }
 
+// The occupancy REQUEST of AMODE 0 cannot be met (the tile's LDS allows 3 workgroups' worth of waves per SIMD); what it is for is
+// the register cap that comes with it.  The backend says so once per instantiation: silenced for THIS kernel only, so that a
+// failed unroll / vectorise remark anywhere else in the file is still seen; build.py checks that the kernel does not spill.
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wpass-failed"
 template <int AMODE, bool POOL>
 // (AMODE 0 -- the region heads' small layers on the side stream -- is compiled for 5 waves per SIMD: 88 registers instead of
 // "whatever 4 waves allow" (126), so that its workgroups find room on CUs whose SIMDs hold two 208-register chain waves)
@@ -442,6 +447,7 @@ __global__ __launch_bounds__(MLP_THREADS, AMODE == 2 ? 3 : (AMODE == 0 ? 5 : MLP
   }
 #endif
 }
+#pragma clang diagnostic pop
 
 #if MLP_TRACE
 static unsigned long long* g_mlp_trace = nullptr;   // set by the harness before a launch

@@ -199,7 +199,8 @@ class ForwardPipeline:
         self.geometry_ahead = max(1, int(geometry_ahead))
         self.level_events = LEVEL_EVENTS  # geometry and features synchronise per network level (see _geometry)
         self.split_chain_tail = True      # see _features   # batches whose ball-query / 3-NN geometry runs ahead of the features
-        self.first_launch_batches = None  # what the first sampling launch of the last ``run`` really took (bench.py reports it)
+        self.first_launch_batches = None  # batches the first sampling look-ahead of the last ``run`` took (bench.py reports it)
+        self.first_launch_split = None    # ... and, when it was issued as two launches (SPLIT_FIRST_LAUNCH), their sizes
         self._one_sampling_stream = False
         dev = next(score_net.parameters()).device
         self.device = dev
@@ -523,8 +524,11 @@ class ForwardPipeline:
                     if pcs:
                         if first_launch:
                             self.first_launch_batches = len(pcs)
+                            self.first_launch_split = None
                         if (first_launch and SPLIT_FIRST_LAUNCH and len(pcs) > 1 and len(self.s_fps) > 1
                                 and not self._one_sampling_stream):
+                            # (two launches on two streams: batch 1 alone, then the rest of the look-ahead)
+                            self.first_launch_split = (1, len(pcs) - 1)
                             sampled.extend(self._sample_group(pcs[:1], first=True))
                             sampled.extend(self._sample_group(pcs[1:], first=False))
                         else:

@@ -12,12 +12,20 @@ from .. import pn2_ext
 
 
 def gather_points(points, index):
-    """points (B,C,N), index (B,M) -> (B,C,M): pick columns (function.py:11-26)."""
+    """points (B,C,N), index (B,M) -> (B,C,M): pick columns (function.py:11-26).  The PUBLIC operator: ``torch.gather``, like
+    the reference -- an index outside [0, N) is a device-side assertion, not a silent zero."""
     b, c, _ = points.shape
+    return torch.gather(points, 2, index[:, None, :].expand(b, c, index.size(1)))
+
+
+def gather_sampled_points(points, index):
+    """``gather_points`` for indices THIS package produced (furthest point sampling, ball query: always in range): one native
+    launch (csrc/gather.hip: an out-of-range index would read as zero and only set the shared status word) instead of
+    ATen's expanded-index gather.  Internal call sites only; callers' own indices go through ``gather_points``."""
     if (points.is_cuda and points.dtype == torch.float32 and index.dtype == torch.int64 and index.is_cuda
             and not (torch.is_grad_enabled() and points.requires_grad)):
-        return pn2_ext.gather_points(points, index)          # one native launch (csrc/gather.hip)
-    return torch.gather(points, 2, index[:, None, :].expand(b, c, index.size(1)))
+        return pn2_ext.gather_points(points, index)
+    return gather_points(points, index)
 
 
 class FarthestPointSample(Function):

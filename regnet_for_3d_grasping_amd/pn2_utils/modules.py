@@ -192,7 +192,7 @@ class _SetAbstraction(nn.Module):
         if self.num_centroids == -1:
             return None, xyz
         index = self.sampler(xyz)
-        return index, _F.gather_points(xyz, index)
+        return index, _F.gather_sampled_points(xyz, index)
 
     def _reduce(self, x):
         return torch.max(x, 3)[0]
@@ -335,7 +335,7 @@ class PointNetSAModuleMSG(nn.Module):
             self.grouper.append(QueryGrouper(radius, k))
 
     def forward(self, xyz, feature=None):
-        new_xyz = _F.gather_points(xyz, self.sampler(xyz)) if self.num_centroids > 0 else xyz
+        new_xyz = _F.gather_sampled_points(xyz, self.sampler(xyz)) if self.num_centroids > 0 else xyz
         outs = []
         for mlp, grouper in zip(self.mlp, self.grouper):
             group_feature, _ = grouper(new_xyz, xyz, feature, use_xyz=self.use_xyz)

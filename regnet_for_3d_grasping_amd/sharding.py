@@ -10,6 +10,19 @@ import os
 import torch
 
 
+# A process group of ONE rank normally counts as "not distributed" (no collective is issued, no bucket is built).  With this
+# switch on it counts: `scripts/scale_driver.sh` at N = 1 (bench.py --single-rank-group) then runs the SAME code a multi-GPU
+# job runs -- the RCCL communicator, `describe_collective`, the gradient bucket's side-stream all-reduce -- on a one-GPU box.
+SINGLE_RANK_GROUP = False
+
+
+def group_active():
+    """True when collectives should be issued: an initialised process group of more than one rank (or of one rank under
+    SINGLE_RANK_GROUP)."""
+    import torch.distributed as dist
+    return bool(dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or SINGLE_RANK_GROUP))
+
+
 def env_world():
     """(rank, local_rank, world_size) from the torch.distributed.run environment (1-process default)."""
     return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
@@ -59,7 +72,7 @@ def describe_collective(device, probe_elements=7066927 + 128, probe_iters=5):
     import time
 
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not group_active():
         return None
     world, rank = dist.get_world_size(), dist.get_rank()
     backend = str(dist.get_backend())

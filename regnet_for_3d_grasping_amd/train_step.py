@@ -29,7 +29,7 @@ def allreduce_gradients(parameters, reduce="sum"):
     parameters no rank touched keep ``grad is None`` (Adam leaves their state alone, like a single process).
     ``reduce='mean'`` divides by the world size.  Returns the number of gradient elements reduced."""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not _distributed():
         return 0
     params = [p for p in parameters if p.requires_grad]
     if not params:
@@ -72,31 +72,36 @@ HEAD_BACKWARD_FREE_SLOTS = 64
 
 
 def _distributed():
-    import torch.distributed as dist
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    from . import sharding
+    return sharding.group_active()
 
 
 class GradientBucket:
-    """ONE persistent flat fp32 buffer for the gradients of one or several networks, and ONE all-reduce per step.
+    """ONE persistent flat fp32 buffer for the gradients of one or several networks, and ONE gradient all-reduce per step.
 
-    Layout (a function of the parameter list only, fixed at construction, identical on every rank):
-    ``[grad(p_0) | grad(p_1) | ... | presence(p_0..p_n-1)]`` over every trainable parameter of ``modules`` in order.
-    ``prepare()`` (instead of ``zero_grad``) zeroes the buffer with one fill and points every ``p.grad`` at its slice, so
-    autograd ACCUMULATES STRAIGHT INTO the buffer -- nothing is gathered or concatenated per step (the round-1/2
-    ``allreduce_gradients`` built a new buffer with ``torch.cat`` twice per step).  Which parameters received a gradient
-    is recorded by post-accumulate hooks on the host (no device read).  ``reduce()`` writes the presence flags into the
-    tail and issues the single all-reduce -- on a side stream for GPU tensors, bracketed by events (``last_ms``) --
-    then drops ``p.grad`` of parameters NO rank touched (the reference's never-used ``linear_cls``, the region network
-    of a step in which every rank took the fallback of train.py:430-435), so optimizers skip them exactly as in a single
-    process; that decision needs the reduced flags on the host: one small read per step, after the collective.
-    A rank that skipped a loss still issues the same collective of the same length (its slices hold zeros)."""
+    Layout (a function of the parameter list only, fixed at construction, identical on every rank): ``flat`` =
+    ``[grad(p_0) | grad(p_1) | ... ]`` over every trainable parameter of ``modules`` in order, ``flags`` = one presence word
+    per parameter.  ``prepare()`` (instead of ``zero_grad``) zeroes the buffer with one fill and points every ``p.grad`` at its
+    slice, so autograd ACCUMULATES STRAIGHT INTO the buffer -- nothing is gathered or concatenated per step.  Which
+    parameters received a gradient is recorded by post-accumulate hooks on the host (no device read).
+    ``reduce_gradients()`` issues two collectives on a side stream: first the presence flags (n_params words, < 1 KB) --
+    they depend on nothing the device is still computing, so that all-reduce and the copy of its result to pinned memory run
+    AHEAD of the backward still in flight -- then the gradients, behind the compute stream (bracketed by events:
+    ``last_ms``).  The host needs the reduced flags before the optimizers (a parameter NO rank touched -- the reference's
+    never-used ``linear_cls``, the region network of a step in which every rank took the fallback of train.py:430-435 --
+    keeps ``grad is None``, so optimizers skip it exactly as in a single process) and gets them without waiting for the
+    backward or the gradient all-reduce: the launching thread keeps running ahead of the device (round 5 read the flags out
+    of the gradient all-reduce's own buffer: one collective, but a host stall of a whole backward per iteration -- 5 ms of
+    a 46 ms iteration once the iteration was replayed from hipGraphs).  A rank that skipped a loss still issues the same
+    two collectives of the same lengths (its slices hold zeros)."""
 
     def __init__(self, modules, reduce="sum"):
         self.params = [p for m in modules for p in m.parameters() if p.requires_grad]
         self.reduce = reduce
         self.n_grad = sum(p.numel() for p in self.params)
         dev = self.params[0].device if self.params else torch.device("cpu")
-        self.flat = torch.zeros(self.n_grad + len(self.params), dtype=torch.float32, device=dev)
+        self.flat = torch.zeros(self.n_grad, dtype=torch.float32, device=dev)
+        self.flags = torch.zeros(len(self.params), dtype=torch.float32, device=dev)
         self.views, offset = [], 0
         for p in self.params:
             if p.dtype != torch.float32:
@@ -106,11 +111,13 @@ class GradientBucket:
         self.touched = [False] * len(self.params)
         for i, p in enumerate(self.params):
             p.register_post_accumulate_grad_hook(lambda _p, i=i: self.touched.__setitem__(i, True))
-        self.collectives = 0            # all-reduces issued so far (tests assert one per step)
-        self.last_ms = None             # event-timed duration of the last all-reduce (GPU tensors)
+        self.collectives = 0            # gradient all-reduces issued so far
+        self.last_ms = None             # event-timed duration of the last gradient all-reduce (GPU tensors)
         self._comm_stream = None
         self._events = None
         self._host_flags = None
+        self._local_flags = None
+        self._timing_pending = False
 
     def mark_touched(self, params):
         """Gradients written into ``p.grad`` by hand (``torch.autograd.grad`` results) do not fire the accumulate hooks."""
@@ -128,12 +135,12 @@ class GradientBucket:
 
     def _world(self):
         import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if _distributed():
             return dist, dist.get_world_size()
         return None, 1
 
     def reduce_gradients(self):
-        """The step's single collective; afterwards ``p.grad`` is the reduced gradient, or None where no rank had one.
+        """The step's collectives; afterwards ``p.grad`` is the reduced gradient, or None where no rank had one.
         Returns the number of gradient elements reduced (0 without a process group)."""
         dist, world = self._world()
         local = self.touched
@@ -142,38 +149,53 @@ class GradientBucket:
                 if not t:
                     p.grad = None
             return 0
-        flags = torch.tensor([1.0 if t else 0.0 for t in local], dtype=torch.float32)
         if self.flat.is_cuda:
             dev = self.flat.device
             if self._comm_stream is None:
                 self._comm_stream = torch.cuda.Stream(dev)
                 self._events = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 self._host_flags = torch.empty(len(self.params), dtype=torch.float32).pin_memory()
+                self._local_flags = torch.empty(len(self.params), dtype=torch.float32).pin_memory()
             cur = torch.cuda.current_stream(dev)
-            self.flat[self.n_grad:].copy_(flags.pin_memory(), non_blocking=True)
-            self._comm_stream.wait_stream(cur)
+            self._local_flags.copy_(torch.tensor([1.0 if t else 0.0 for t in local], dtype=torch.float32))
+            with torch.cuda.stream(self._comm_stream):
+                # the flags: nothing here waits for the compute stream
+                self.flags.copy_(self._local_flags, non_blocking=True)
+                dist.all_reduce(self.flags, op=dist.ReduceOp.SUM)
+                self._host_flags.copy_(self.flags, non_blocking=True)
+                flags_done = torch.cuda.Event()
+                flags_done.record()
+            self._comm_stream.wait_stream(cur)                # the gradients: behind the backward
             with torch.cuda.stream(self._comm_stream):
                 self._events[0].record()
                 dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
                 self._events[1].record()
-                self._host_flags.copy_(self.flat[self.n_grad:], non_blocking=True)
-                done = torch.cuda.Event()
-                done.record()
-            cur.wait_stream(self._comm_stream)       # the optimizer's kernels queue behind the collective
-            done.synchronize()                        # host: only the flags are needed here
-            self.last_ms = self._events[0].elapsed_time(self._events[1])
+                if self.reduce == "mean":
+                    self.flat /= world
+            cur.wait_stream(self._comm_stream)                # the optimizer's kernels queue behind the collective
+            flags_done.synchronize()                          # host: the flags only (microseconds; the backward is still running)
             present = self._host_flags.tolist()
+            self._timing_pending = True
         else:
-            self.flat[self.n_grad:] = flags
+            self.flags.copy_(torch.tensor([1.0 if t else 0.0 for t in local], dtype=torch.float32))
+            dist.all_reduce(self.flags, op=dist.ReduceOp.SUM)
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
-            present = self.flat[self.n_grad:].tolist()
+            if self.reduce == "mean":
+                self.flat /= world
+            present = self.flags.tolist()
         self.collectives += 1
-        if self.reduce == "mean":
-            self.flat[:self.n_grad] /= world
         for p, n in zip(self.params, present):
             if n <= 0:
                 p.grad = None
         return self.n_grad
+
+    def last_allreduce_ms(self):
+        """Event-timed duration of the most recent gradient all-reduce whose events have completed (GPU tensors), else None.
+        Does not block: a collective still in flight leaves the previous value."""
+        if self._events is not None and self._timing_pending and self._events[1].query():
+            self.last_ms = self._events[0].elapsed_time(self._events[1])
+            self._timing_pending = False
+        return self.last_ms
 
 
 def broadcast_module_state(*modules, src=0):
@@ -183,7 +205,7 @@ def broadcast_module_state(*modules, src=0):
     see identical (all-reduced) gradients -- without this an unseeded ``construct_scorenet(load_flag=False)``
     would silently train N different models.  No-op without an initialised process group."""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not _distributed():
         return 0
     tensors = []
     for m in modules:
@@ -213,7 +235,7 @@ def broadcast_buffers(*modules, src=0):
     (utils.py:129-133, train.py:467-468).  Call before evaluating or saving on a rank other than ``src`` --
     ``save_checkpoint`` does.  No-op without a process group.  Returns the number of elements broadcast."""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not _distributed():
         return 0
     total = 0
     by_dtype = {}
@@ -434,10 +456,9 @@ class _TrunkGraphs:
                         grads = torch.autograd.grad(self.total, [feat] + [alias_of[id(p)] for p in self.head], retain_graph=True,
                                                     allow_unused=True)
                         self.g_feat = grads[0]
-                        if bucket is not None:
-                            for p, g in zip(self.head, grads[1:]):
-                                if g is not None:
-                                    p.grad.add_(g)
+                        if bucket is not None:      # (multi-tensor adds: a handful of nodes instead of one per parameter)
+                            pairs = [(p.grad, g) for p, g in zip(self.head, grads[1:]) if g is not None]
+                            torch._foreach_add_([a for a, _ in pairs], [b for _, b in pairs])
                 finally:
                     conv1x1_train.reserve_stream_slots(before)
                 if not (self.g_feat.is_contiguous() and tuple(self.g_feat.shape) == tuple(feat.shape)):
@@ -446,9 +467,8 @@ class _TrunkGraphs:
                 with torch.cuda.graph(self.g_trunk, stream=self.stream, pool=self.g_forward.pool()):
                     tgrads = torch.autograd.grad([feat], [alias_of[id(p)] for p in trunk], [self.g_feat], allow_unused=True)
                     if bucket is not None:
-                        for p, g in zip(trunk, tgrads):
-                            if g is not None:
-                                p.grad.add_(g)
+                        pairs = [(p.grad, g) for p, g in zip(trunk, tgrads) if g is not None]
+                        torch._foreach_add_([a for a, _ in pairs], [b for _, b in pairs])
                 self.trunk_grads = [(p, g) for p, g in zip(trunk, tgrads) if g is not None]
                 if bucket is None:
                     for p, g in self.trunk_grads + self.head_grads:

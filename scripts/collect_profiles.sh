@@ -18,7 +18,9 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch 
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o p -- python $REPO/bench.py $EXTRA --cpu-scenes 0 --exclusive-steps 0 --latency-runs 0 --train-steps 0 --no-lookahead-steps 0 --real-density-steps 0 --steps 4 > $OUT/pmc_write.log 2>&1
 cd $REPO
 DB=$(find $OUT/prof -name "*results.db" | head -1)
-python scripts/rocprof_summary.py $DB --json $OUT/rocprof_launch_ms.json --tag $TAG --steps 37 > $OUT/kernel_stats.txt
+# (the workload the trace is of goes into the JSON: bench.py refuses to price another batch / point count with it)
+WB=$(echo " $EXTRA" | sed -n 's/.* --batch \([0-9]*\).*/\1/p'); WP=$(echo " $EXTRA" | sed -n 's/.* --points \([0-9]*\).*/\1/p')
+python scripts/rocprof_summary.py $DB --json $OUT/rocprof_launch_ms.json --tag $TAG --steps 37 --batch ${WB:-8} --points ${WP:-25600} > $OUT/kernel_stats.txt
 python scripts/collect_pmc.py $OUT/pmc_fetch $OUT/pmc_write > $OUT/pmc_traffic.json
 # the raw traces are large; keep the summaries and the trace database only
 rm -rf $OUT/pmc_fetch $OUT/pmc_write

@@ -21,7 +21,7 @@ def rows_of(path):
     return list(cur.execute("select name, total_calls, total_duration, average, percentage from top_kernels"))
 
 
-def main(path, top=45, json_path=None, tag=None, steps=None):
+def main(path, top=45, json_path=None, tag=None, steps=None, batch=8, points=25600):
     rows = rows_of(path)
     total = sum(float(r[2]) for r in rows)
     print("# rocprofv3 --kernel-trace --stats summary of %s" % path)
@@ -47,6 +47,7 @@ def main(path, top=45, json_path=None, tag=None, steps=None):
             f["kernel_names"].sort()
         out = {"source": "profiles/%s_pipeline_kernel_stats.txt" % tag if tag else os.path.basename(path),
                "what": "rocprofv3 --kernel-trace --stats of `python bench.py` (scripts/collect_profiles.sh), per kernel family",
+               "workload": {"batch": int(batch), "points": int(points)},     # bench.py hands the durations out to such runs only
                "steps_traced_incl_warmup": steps, "total_kernel_ms": round(total / 1e3, 3), "families": fams}
         with open(json_path, "w") as fh:
             json.dump(out, fh, indent=1, sort_keys=True)
@@ -56,10 +57,11 @@ def main(path, top=45, json_path=None, tag=None, steps=None):
 if __name__ == "__main__":
     args = sys.argv[1:]
     opts = {}
-    for flag in ("--json", "--tag", "--steps"):
+    for flag in ("--json", "--tag", "--steps", "--batch", "--points"):
         if flag in args:
             i = args.index(flag)
             opts[flag] = args[i + 1]
             del args[i:i + 2]
     main(args[0], json_path=opts.get("--json"), tag=opts.get("--tag"),
-         steps=int(opts["--steps"]) if "--steps" in opts else None)
+         steps=int(opts["--steps"]) if "--steps" in opts else None, batch=int(opts.get("--batch", 8)),
+         points=int(opts.get("--points", 25600)))

@@ -37,6 +37,7 @@ def main():
 
         class F64:
             gather_points = staticmethod(F32.gather_points)
+        gather_sampled_points = staticmethod(F32.gather_sampled_points)
 
             @staticmethod
             def farthest_point_sample(points, m):

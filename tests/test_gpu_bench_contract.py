@@ -14,9 +14,9 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _line(cmd, env=None):
     out = subprocess.run(cmd, cwd=REPO, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, text=True)
     assert out.returncode == 0, out.stderr[-2000:]
-    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, out.stdout[-2000:]            # exactly ONE JSON line on stdout
-    return json.loads(lines[0])
+    lines = out.stdout.splitlines()
+    assert len(lines) == 1 and lines[0].startswith("{"), out.stdout[-2000:]    # exactly ONE line on stdout, and it is the JSON line
+    return json.loads(lines[0])                                               # (libraries' banners -- RCCL's -- go to stderr)
 
 
 def test_bench_line_has_the_contract_fields():

@@ -19,7 +19,8 @@ def test_gather_points_equals_torch_gather(B, C, N, M):
     for view in (pts.permute(0, 2, 1), pts.permute(0, 2, 1).contiguous(), pts.permute(0, 2, 1)[:, :max(1, C - 1), :]):
         want = torch.gather(view, 2, idx[:, None, :].expand(B, view.shape[1], M))
         assert torch.equal(pn2_ext.gather_points(view, idx), want)
-        assert torch.equal(fn.gather_points(view, idx), want)                      # the operator API takes the native launch
+        assert torch.equal(fn.gather_points(view, idx), want)                      # the public operator: torch.gather, as the reference
+        assert torch.equal(fn.gather_sampled_points(view, idx), want)              # the package's own (in-range) indices: one native launch
         assert torch.equal(pn2_ext.gather_points(view, idx, channels_last=True), want.transpose(1, 2).contiguous())
     rows = torch.gather(pts, 1, idx.unsqueeze(-1).expand(B, M, C))             # get_regiondataset.py:288: rows of a (B,N,C) cloud
     assert torch.equal(pn2_ext.gather_points(pts.transpose(1, 2), idx, channels_last=True), rows)

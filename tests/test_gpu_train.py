@@ -21,6 +21,7 @@ def _fp64_reference_grads(net32, pc, target):
 
     class F64:
         gather_points = staticmethod(F32.gather_points)
+        gather_sampled_points = staticmethod(F32.gather_sampled_points)
 
         @staticmethod
         def farthest_point_sample(points, m):

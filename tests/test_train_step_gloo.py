@@ -183,8 +183,8 @@ def test_refine_trainer_two_ranks_one_rank_without_region_stage(tmp_path):
         assert r0["has_grad"][k] == r1["has_grad"][k], k
         moved += int(r0["has_grad"][k])
     # rank 1 received the region network's gradients from rank 0; the never-used layer stays grad-less everywhere
-    # ONE collective per iteration, same length on both ranks: every gradient of BOTH networks + one flag per parameter
-    assert r0["all_reduce_sizes"] == r1["all_reduce_sizes"] == [r0["n_grad"] + r0["n_params"]]
+    # same collectives on both ranks: one flag per parameter, then ONE all-reduce of every gradient of BOTH networks
+    assert r0["all_reduce_sizes"] == r1["all_reduce_sizes"] == [r0["n_params"], r0["n_grad"]]
     assert r1["has_grad"]["region.extrat_feature_region.conv.weight"]
     assert not r0["has_grad"]["region.extrat_feature_region.linear_cls.weight"]
     assert moved > 80
@@ -193,7 +193,7 @@ def test_refine_trainer_two_ranks_one_rank_without_region_stage(tmp_path):
 def test_refine_trainer_two_ranks_one_rank_without_refine_loss(tmp_path):
     r0, r1 = _run_refine(tmp_path, fail_rank=-1, no_refine_rank=0)
     assert r0["stage2"] and not r0["refine"] and r1["stage2"]
-    assert r0["all_reduce_sizes"] == r1["all_reduce_sizes"] == [r0["n_grad"] + r0["n_params"]]
+    assert r0["all_reduce_sizes"] == r1["all_reduce_sizes"] == [r0["n_params"], r0["n_grad"]]
     for k in r0["params"]:
         assert torch.equal(r0["params"][k], r1["params"][k]), k
         assert r0["has_grad"][k] == r1["has_grad"][k], k

@@ -114,7 +114,8 @@ def test_four_ranks_one_collective_per_iteration_and_rank0_checkpoint(tmp_path):
     all_seeds = [s for p in parts for step in p["seeds"] for s in step]
     assert len(set(all_seeds)) == 2 * world and sorted(all_seeds) == list(range(6000, 6000 + 2 * world))
     for p in parts:
-        assert p["calls"] == [p0["n_grad"] + p0["n_params"]] * 2          # ONE collective per iteration, same length everywhere
+        # per iteration: the presence flags (one word per parameter), then ONE gradient collective; same lengths everywhere
+        assert p["calls"] == [p0["n_params"], p0["n_grad"]] * 2
         for k in p0["params"]:
             assert torch.equal(p["params"][k], p0["params"][k]), k         # lazily created bucket broadcast rank 0's start
         assert torch.equal(p["stats_after"], p0["stats_before"])           # save_checkpoint: every rank holds rank 0's buffers
