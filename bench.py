@@ -588,6 +588,8 @@ def measure_train(args, rank, world, dev, steps, warmup, batch):
         fence()
         dt_local = time.perf_counter() - t0
     dt = sharding.max_over_ranks(dt_local, dev)
+    if trainer.bucket is not None and trainer.bucket.last_allreduce_ms() is not None:
+        allreduce_ms.append(trainer.bucket.last_ms)          # the last iteration's (its events have completed now)
     timer.enabled = False
     marks, trainer.phase_marks = trainer.phase_marks, None
     replays = trainer.graph_replays - replays_before
@@ -785,7 +787,11 @@ def main():
         # of the cores, so that N ranks' region-stage host threads do not fight over them
         # (sharding.pin_rank: a contiguous share of the GPU's NUMA node, affinity mask + OpenMP / torch pools)
         pinned = sharding.pin_rank(local_rank, world, None if one_device else local_rank)
-        sharding.init("gloo" if one_device else "nccl", dev)   # RCCL; forward: only the barrier + max-over-ranks of the contract
+        # RCCL; forward: only the barrier + max-over-ranks of the contract.  The streams of the workload are bound first.
+        if not args.train:
+            from regnet_for_3d_grasping_amd import pipeline as _pl
+            _pl.reserve_streams(dev, args.fps_streams, args.mlp_streams)
+        sharding.init("gloo" if one_device else "nccl", dev, reserve=("train",) if args.train else ("forward", "train"))
         import torch.distributed as dist
         if not one_device and str(dist.get_backend()) != "nccl":
             raise SystemExit("bench.py --gpus %d: the process group's backend is %r, not nccl (= RCCL on ROCm)" % (world, dist.get_backend()))
@@ -799,7 +805,10 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         pinned = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else []
-        sharding.init("nccl", dev)
+        if not args.train:
+            from regnet_for_3d_grasping_amd import pipeline as _pl
+            _pl.reserve_streams(dev, args.fps_streams, args.mlp_streams)
+        sharding.init("nccl", dev, reserve=("train",) if args.train else ("forward", "train"))
     collective = sharding.describe_collective(dev) if sharding.group_active() else None
     if collective is not None:
         collective["pinned_cores"] = len(pinned)

@@ -139,6 +139,37 @@ class _StageGraphs:
         return slot
 
 
+_stream_pools = {}
+
+
+def reserve_streams(device, fps_streams=2, mlp_streams=1):
+    """The HIP streams of a ``ForwardPipeline`` on ``device`` -- created once per (device, counts) and shared by every
+    pipeline built afterwards -- as {"fps": [...], "mlp": [...], "geo": stream, "reg": stream}.
+
+    The HIP runtime binds a stream to a hardware queue when its handle is first used, in order of first use, and the
+    binding matters: with the feature stream bound FIRST (e.g. a caller reading ``s_mlp.cuda_stream`` before the first
+    ``run``) a step takes 9.1 ms instead of 8.4 (scripts/stream_order_probe.py); with RCCL's streams bound before these --
+    ``init_process_group("nccl")`` ahead of the first pipeline -- 8.5 instead of 7.75 (scripts/ablate/group_overhead_ab.sh:
+    every chain kernel 3 % slower, the plain layers 30 %, the side streams' small kernels queueing behind one another).  So
+    they are bound HERE, in the order the first ``run`` would use them -- sampling, features, geometry, region -- and
+    ``sharding.init`` calls this BEFORE it creates the process group."""
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    key = (idx, max(1, int(fps_streams)), max(1, int(mlp_streams)))
+    pool = _stream_pools.get(key)
+    if pool is None:
+        # Priorities: FPS and the region stage are chains of small / single-CU kernels (the latter separated by host
+        # syncs) -- they must not queue behind the big MLP launches.
+        pool = {"fps": [torch.cuda.Stream(dev, priority=-1) for _ in range(key[1])]}
+        pool["geo"] = torch.cuda.Stream(dev, priority=-1)
+        pool["mlp"] = [torch.cuda.Stream(dev, priority=0) for _ in range(key[2])]
+        pool["reg"] = torch.cuda.Stream(dev, priority=-1)
+        for st in tuple(pool["fps"]) + tuple(pool["mlp"]) + (pool["geo"], pool["reg"]):
+            _ = st.cuda_stream
+        _stream_pools[key] = pool
+    return pool
+
+
 def _graph_key(pc):
     return (tuple(pc.shape), tuple(pc.stride()), pc.dtype, pc.device.index)
 
@@ -206,19 +237,11 @@ class ForwardPipeline:
         self.device = dev
         # Priorities: FPS and the region stage are chains of small / single-CU kernels (the latter
         # separated by host syncs) -- they must not queue behind the big MLP launches.
-        self.s_fps = [torch.cuda.Stream(dev, priority=-1) for _ in range(max(1, int(fps_streams)))]
+        pool = reserve_streams(dev, fps_streams, mlp_streams)
+        self.s_fps, self.s_geo, self.s_mlps, self.s_reg = pool["fps"], pool["geo"], pool["mlp"], pool["reg"]
         self._n_sampled = 0
-        self.s_geo = torch.cuda.Stream(dev, priority=-1)
-        self.s_mlps = [torch.cuda.Stream(dev, priority=0) for _ in range(max(1, int(mlp_streams)))]
         self.s_mlp = self.s_mlps[0]
         self._n_featured = 0
-        self.s_reg = torch.cuda.Stream(dev, priority=-1)
-        # The HIP runtime binds a stream to a hardware queue when its handle is first used, in order of first use, and the
-        # binding matters: with the feature stream bound FIRST (e.g. a caller reading ``s_mlp.cuda_stream`` before the first
-        # ``run``) a step takes 9.1 ms instead of 8.4 (scripts/stream_order_probe.py).  Bind them here, in the order the
-        # first ``run`` would: sampling, features, geometry, region.
-        for s in tuple(self.s_fps) + tuple(self.s_mlps) + (self.s_geo, self.s_reg):
-            _ = s.cuda_stream
 
     # -- stages -------------------------------------------------------------------------------
     def _sample_group(self, pcs, first=False):

@@ -76,6 +76,28 @@ def _distributed():
     return sharding.group_active()
 
 
+_stream_pools = {}
+
+
+def reserve_streams(device):
+    """The side streams of a training iteration on ``device`` -- {"geometry": the next batch's sampling / grouping (low
+    priority... the same ``priority=-1`` class the pipeline uses), "region": the region stage beside the head's backward,
+    "capture": hipGraph captures, "comm": the gradient all-reduce} -- created once per device, bound to hardware queues in the
+    order an iteration first uses them, and shared by every trainer built afterwards.  ``sharding.init`` calls this BEFORE it
+    creates the process group: bound behind RCCL's own streams the region stage shares a hardware queue with the trunk (its
+    kernels then wait for the head's backward: +3 ms per iteration, see pipeline.reserve_streams)."""
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    pool = _stream_pools.get(idx)
+    if pool is None:
+        pool = {"geometry": torch.cuda.Stream(dev, priority=-1), "region": torch.cuda.Stream(dev),
+                "capture": torch.cuda.Stream(dev), "comm": torch.cuda.Stream(dev)}
+        for name in ("geometry", "region", "capture", "comm"):
+            _ = pool[name].cuda_stream
+        _stream_pools[idx] = pool
+    return pool
+
+
 class GradientBucket:
     """ONE persistent flat fp32 buffer for the gradients of one or several networks, and ONE gradient all-reduce per step.
 
@@ -126,12 +148,29 @@ class GradientBucket:
             if id(p) in ids:
                 self.touched[i] = True
 
-    def prepare(self):
-        """Replaces ``optimizer.zero_grad()``: one fill, every ``.grad`` a view of the bucket."""
+    def prepare(self, lazy=()):
+        """Replaces ``optimizer.zero_grad()``: one fill, every ``.grad`` a view of the bucket.  Parameters in ``lazy`` get
+        ``grad = None`` instead: autograd then ASSIGNS their gradient (no in-place add kernel per parameter inside the
+        backward) and ``reduce_gradients`` moves what it finds into their slices with one multi-tensor copy -- for networks
+        whose backward is a host-paced chain of small launches on the iteration's critical path (the region network)."""
         self.flat.zero_()
+        skip = {id(p) for p in lazy}
         for p, v in zip(self.params, self.views):
-            p.grad = v
+            p.grad = None if id(p) in skip else v
         self.touched = [False] * len(self.params)
+
+    def _collect_lazy(self):
+        """Gradients autograd assigned outside the bucket (``prepare(lazy=...)``) -> their slices; ``p.grad`` = the slice."""
+        dst, src = [], []
+        for i, (p, v) in enumerate(zip(self.params, self.views)):
+            g = p.grad
+            if g is not None and g.data_ptr() != v.data_ptr():
+                dst.append(v)
+                src.append(g.reshape(v.shape) if g.shape != v.shape else g)
+                p.grad = v
+                self.touched[i] = True
+        if dst:
+            torch._foreach_copy_(dst, src)
 
     def _world(self):
         import torch.distributed as dist
@@ -143,6 +182,7 @@ class GradientBucket:
         """The step's collectives; afterwards ``p.grad`` is the reduced gradient, or None where no rank had one.
         Returns the number of gradient elements reduced (0 without a process group)."""
         dist, world = self._world()
+        self._collect_lazy()
         local = self.touched
         if dist is None:
             for p, t in zip(self.params, local):
@@ -152,7 +192,7 @@ class GradientBucket:
         if self.flat.is_cuda:
             dev = self.flat.device
             if self._comm_stream is None:
-                self._comm_stream = torch.cuda.Stream(dev)
+                self._comm_stream = reserve_streams(dev)["comm"]
                 self._events = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 self._host_flags = torch.empty(len(self.params), dtype=torch.float32).pin_memory()
                 self._local_flags = torch.empty(len(self.params), dtype=torch.float32).pin_memory()
@@ -184,9 +224,8 @@ class GradientBucket:
                 self.flat /= world
             present = self.flags.tolist()
         self.collectives += 1
-        for p, n in zip(self.params, present):
-            if n <= 0:
-                p.grad = None
+        for p, v, n in zip(self.params, self.views, present):
+            p.grad = v if n > 0 else None      # (a lazy parameter only ANOTHER rank touched receives its slice here)
         return self.n_grad
 
     def last_allreduce_ms(self):
@@ -344,7 +383,7 @@ class GeometryPrefetcher:
         """pc (B,N,6) on the GPU -> handle for ``step(..., plan=handle)``.  Enqueue-only, does not block the host."""
         from . import fused
         if self.stream is None:
-            self.stream = torch.cuda.Stream(pc.device, priority=-1)
+            self.stream = reserve_streams(pc.device)["geometry"]
         cur = torch.cuda.current_stream(pc.device)
         self.stream.wait_stream(cur)          # pc may still be in flight on the caller's stream
         with torch.cuda.stream(self.stream):
@@ -414,7 +453,7 @@ class _TrunkGraphs:
         self.pc, self.target = pc.clone(), pc_score.clone()
         self.plan = _clone_plan(plan)
         self.plan_tensors = fused.plan_tensors(self.plan)
-        self.stream = torch.cuda.Stream(dev)
+        self.stream = reserve_streams(dev)["capture"]
         bucket = trainer.bucket
         if bucket is not None:
             bucket.prepare()                 # p.grad = the bucket's views: the captured accumulations are in-place adds
@@ -442,8 +481,12 @@ class _TrunkGraphs:
         trunk = [p for p in self.params if id(p) not in head_ids]
         try:
             self.g_forward, self.g_head, self.g_trunk = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            # capture_error_mode "thread_local": other threads of the process keep making calls a capture forbids -- RCCL's
+            # watchdog polls its collectives' events (hipEventQuery: observed to abort the process under the default, global,
+            # mode), a data loader may allocate; the autograd engine's device thread LAUNCHES into the capturing stream, which
+            # any mode records
             with torch.enable_grad():
-                with torch.cuda.graph(self.g_forward, stream=self.stream):
+                with torch.cuda.graph(self.g_forward, stream=self.stream, capture_error_mode="thread_local"):
                     all_feature, self.score, self.loss = torch.func.functional_call(
                         net, alias, (self.pc, self.target, None), {"plan": self.plan})
                     self.total = self.loss.sum()
@@ -452,7 +495,7 @@ class _TrunkGraphs:
                 feat = grabbed["feat"]
                 before = conv1x1_train.reserve_stream_slots(HEAD_BACKWARD_FREE_SLOTS)
                 try:
-                    with torch.cuda.graph(self.g_head, stream=self.stream, pool=self.g_forward.pool()):
+                    with torch.cuda.graph(self.g_head, stream=self.stream, pool=self.g_forward.pool(), capture_error_mode="thread_local"):
                         grads = torch.autograd.grad(self.total, [feat] + [alias_of[id(p)] for p in self.head], retain_graph=True,
                                                     allow_unused=True)
                         self.g_feat = grads[0]
@@ -464,7 +507,7 @@ class _TrunkGraphs:
                 if not (self.g_feat.is_contiguous() and tuple(self.g_feat.shape) == tuple(feat.shape)):
                     raise RuntimeError("the point feature's gradient is not a contiguous (B, C, N) tensor")
                 self.head_grads = [(p, g) for p, g in zip(self.head, grads[1:]) if g is not None]
-                with torch.cuda.graph(self.g_trunk, stream=self.stream, pool=self.g_forward.pool()):
+                with torch.cuda.graph(self.g_trunk, stream=self.stream, pool=self.g_forward.pool(), capture_error_mode="thread_local"):
                     tgrads = torch.autograd.grad([feat], [alias_of[id(p)] for p in trunk], [self.g_feat], allow_unused=True)
                     if bucket is not None:
                         pairs = [(p.grad, g) for p, g in zip(trunk, tgrads) if g is not None]
@@ -553,6 +596,7 @@ class RefineTrainer:
         self.sched_region = torch.optim.lr_scheduler.StepLR(self.opt_region, step_size=5, gamma=0.5)
         self.geometry = GeometryPrefetcher(score_net)
         self._region_stream = None
+        self._region_params = [p for p in region_net.parameters() if p.requires_grad]
         self._marks = None
         self.graphs = graphs
         self._graphs = None              # _TrunkGraphs of the shape the last iterations had
@@ -640,7 +684,7 @@ class RefineTrainer:
         region_stream = contextlib.nullcontext()
         if forward_done is not None:
             if self._region_stream is None:
-                self._region_stream = torch.cuda.Stream(all_feature.device)
+                self._region_stream = reserve_streams(all_feature.device)["region"]
             self._region_stream.wait_event(forward_done)
             region_stream = torch.cuda.stream(self._region_stream)
             parts["region_stream"] = self._region_stream
@@ -702,7 +746,7 @@ class RefineTrainer:
             for p, g in G.static_grads:      # (an eager iteration in between would have replaced them)
                 p.grad = g
         else:
-            self.bucket.prepare()
+            self.bucket.prepare(lazy=self._region_params)
             for i in G.touched:
                 self.bucket.touched[i] = True
         G.g_forward.replay()
@@ -761,7 +805,7 @@ class RefineTrainer:
             self.opt_score.zero_grad()
             self.opt_region.zero_grad()
         else:
-            self.bucket.prepare()
+            self.bucket.prepare(lazy=self._region_params)
         with torch.enable_grad():
             total, parts = self.forward_losses(pc, pc_score, grasp_records, plan, early_head_backward=EARLY_HEAD_BACKWARD)
             early = parts.pop("early", None)

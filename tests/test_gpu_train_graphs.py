@@ -112,7 +112,7 @@ def test_replayed_training_follows_the_eager_trajectory():
     print("eager", le)
     print("graph", lg)
     for it, (a, b) in enumerate(zip(le, lg)):
-        tol = 2e-3 if it < 4 else 5e-2
+        tol = 2e-3 if it < 3 else 5e-2
         assert abs(a[1] - b[1]) <= tol * abs(a[1]), ("score loss", it, a, b)
         if it < 4:     # (later the region losses sit on different discrete choices: which points pass 0.5, which rows are drawn)
             assert abs(a[0] - b[0]) <= 5e-2 * abs(a[0]), ("total loss", it, a, b)
