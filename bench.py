@@ -73,6 +73,9 @@ def parse():
     ap.add_argument("--single-rank-group", action="store_true",
                     help="--gpus 1 only: initialise a ONE-rank RCCL process group anyway and run what a multi-GPU job runs on it "
                          "(config.collective, the gradient bucket's all-reduce): scripts/scale_driver.sh at N = 1")
+    ap.add_argument("--train-accounting-steps", type=int, default=4,
+                    help="replayed training iterations carry no per-launch events: this many extra EAGER iterations after the "
+                         "timed region give the train roofline its launch durations (0: none, e.g. under a profiler)")
     ap.add_argument("--train-batch", type=int, default=8)
     ap.add_argument("--train-graphs", choices=("auto", "on", "off"), default="auto",
                     help="replay the fixed-shape part of a training iteration as hipGraphs (train_step._TrunkGraphs); auto = the module switch")
@@ -594,10 +597,10 @@ def measure_train(args, rank, world, dev, steps, warmup, batch):
     marks, trainer.phase_marks = trainer.phase_marks, None
     replays = trainer.graph_replays - replays_before
     accounting_steps = 0
-    if replays:
+    if replays and args.train_accounting_steps > 0:
         # the timed iterations replayed hipGraphs: no wrapper ran.  The contractions' launch durations (the `roofline` object)
         # come from a few extra EAGER iterations outside the timed region -- the same launches issued one by one
-        accounting_steps, saved = 4, trainer.graphs
+        accounting_steps, saved = args.train_accounting_steps, trainer.graphs
         trainer.graphs = False
         timer.enabled = True
         for _ in range(accounting_steps):

@@ -17,7 +17,7 @@ dataset's pickled dict or the dict itself (keys ``frame`` + ``antipodal_score``,
 import numpy as np
 import torch
 
-from . import np_random, region_ops
+from . import host_io, np_random, region_ops
 from .pn2_utils import function as _F
 
 
@@ -50,11 +50,11 @@ def get_grasp_allobj(pc, predict_score, params, data_paths, use_theta=True, defe
             labels_pending = _get_center_grasp(center_pc_index, center_pc, data_paths, depth, use_theta, defer_read=True)
         np_random.flush()
         counts = torch.stack((count_s, count_m)).cpu().numpy()
-        pos = torch.from_numpy(np_random.choice_rows(counts[0], group_num, 0)[0]).to(pc.device)
+        pos = host_io.upload(np_random.choice_rows(counts[0], group_num, 0)[0], pc.device)
         pc_group_index, pc_group = region_ops.resample_groups(pc, cand_s, pos)
 
         def large_groups():
-            pos = torch.from_numpy(np_random.choice_rows(counts[1], group_num_more, 0)[0]).to(pc.device)
+            pos = host_io.upload(np_random.choice_rows(counts[1], group_num_more, 0)[0], pc.device)
             return region_ops.resample_groups(pc, cand_m, pos)
 
         if defer_large_groups and DEFER_LARGE_GROUPS and pc.is_cuda:
@@ -136,7 +136,7 @@ def _get_center_grasp(center_pc_index, center_pc, data_paths, depth, use_theta=T
             blob = np.empty((B * Gmax * 19 + B,), dtype=np.float32)
             blob[:B * Gmax * 19] = host.reshape(-1)
             blob[B * Gmax * 19:].view(np.int32)[:] = np.asarray(Gs, dtype=np.int32)
-            packed = torch.from_numpy(blob).to(dev)
+            packed = host_io.upload(blob, dev)
             out = torch.empty((B, Nc, 10), dtype=torch.float32, device=dev)
             wide_row = torch.empty((B * Nc,), dtype=torch.int32, device=dev)
             xyz = center_pc if center_pc.dtype == torch.float32 and center_pc.stride(2) == 1 else center_pc.float().contiguous()
@@ -149,8 +149,8 @@ def _get_center_grasp(center_pc_index, center_pc, data_paths, depth, use_theta=T
                 return out if bool(wide_row.cpu().numpy().any()) else out[:, :, :8].contiguous()
 
             return finish if defer_read else finish()     # (defer_read: the caller makes the one read when it suits it)
-        packed = torch.from_numpy(host).to(dev)
-        valid = torch.from_numpy(np.arange(Gmax)[None, :] < np.asarray(Gs)[:, None]).to(dev)
+        packed = host_io.upload(host, dev)
+        valid = host_io.upload(np.arange(Gmax)[None, :] < np.asarray(Gs)[:, None], dev)
         frames = packed[:, :, :16].view(B, Gmax, 4, 4)
         approach = frames[:, :, :3, 0]
         contact = ((frames[:, :, :3, 3] + approach * depth).float() - approach * depth).float()
@@ -284,7 +284,7 @@ def _select_score_center(pc, pre_score, center_num, score_thre):
         else:
             np_random.flush()
             picks = np.random.choice(N, center_num, replace=False)
-            index[b] = torch.from_numpy(np.asarray(picks, dtype=np.int64)).to(pc.device)
+            index[b] = host_io.upload(np.asarray(picks, dtype=np.int64), pc.device)
     if pc.is_cuda and pc.dtype == torch.float32:
         # rows of the (B, N, C) cloud = gather_points with the roles of the axes swapped (one native launch)
         from . import pn2_ext
@@ -321,7 +321,7 @@ def _draw_positions(counts, group_num, max_count):
     np_random.flush()
     if counts.is_cuda:   # drawn into page-locked memory, copied by DMA behind the draws (1 + 4 MB per batch of 8)
         return np_random.choice_rows_pinned(counts.cpu().numpy(), group_num, 0)[0].to(counts.device, non_blocking=True)
-    return torch.from_numpy(np_random.choice_rows(counts.cpu().numpy(), group_num, 0)[0]).to(counts.device)
+    return host_io.upload(np_random.choice_rows(counts.cpu().numpy(), group_num, 0)[0], counts.device)
 
 
 def _get_group_pc(pc, center_pc, center_pc_index, group_num, width, height, depth, r_time):

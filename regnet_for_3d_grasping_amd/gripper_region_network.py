@@ -22,7 +22,7 @@ import numpy as np
 import torch
 from torch import nn
 
-from . import np_random, region_losses, region_ops
+from . import host_io, np_random, region_losses, region_ops
 from .pointnet2 import PointNet2Refine, PointNet2TwoStage
 
 
@@ -158,7 +158,7 @@ class GripperRegionNetwork(nn.Module):
         per_class = max(int(min(len(mem) for mem in members)), 1)
         np_random.flush()    # host-side draws below: numpy's generator must hold the state the device draws left
         chosen = [mem[np.random.choice(len(mem), per_class, replace=False)] for mem in members if len(mem)]
-        balanced = torch.from_numpy(np.concatenate(chosen).astype(np.int64)).to(dev)
+        balanced = host_io.upload(np.concatenate(chosen).astype(np.int64), dev)
         loss_class = self.criterion_cls(first_cls[balanced], ground_8[balanced].long())
         correct_tuple = ((ground_8 == pick).sum().float(), (ground_8 != pick).sum().float())
 
@@ -194,8 +194,8 @@ class GripperRegionNetwork(nn.Module):
             final_grasp, flags8 = region_ops.refine_decode(next_grasp, next_x_cls, next_x_reg, self.radius,
                                                            self.grasp_score_thre)
             flags = flags8.cpu().numpy().astype(bool)
-            class_select = torch.from_numpy(np.nonzero(flags[0])[0]).to(dev)
-            score_select = torch.from_numpy(np.nonzero(flags[1])[0]).to(dev)
+            class_select = host_io.upload(np.nonzero(flags[0])[0], dev)
+            score_select = host_io.upload(np.nonzero(flags[1])[0], dev)
             return (final_grasp[class_select], final_grasp[score_select], next_grasp[class_select], class_select,
                     score_select, (None, None), (None, None, None, None))
         final_grasp = next_grasp.clone()
@@ -213,8 +213,8 @@ class GripperRegionNetwork(nn.Module):
             same_angle = torch.abs(next_grasp[:, 6] - next_gt[:, 6]) < 1.047
             gt_positive = near & aligned & same_angle
             flags = torch.stack((is_class, is_score, gt_positive)).cpu().numpy()         # ... and the label classes
-        class_select = torch.from_numpy(np.nonzero(flags[0])[0]).to(dev)
-        score_select = torch.from_numpy(np.nonzero(flags[1])[0]).to(dev)
+        class_select = host_io.upload(np.nonzero(flags[0])[0], dev)
+        score_select = host_io.upload(np.nonzero(flags[1])[0], dev)
         sel_class, sel_score = final_grasp[class_select].data, final_grasp[score_select].data
         sel_class_stage2 = next_grasp[class_select].data
         if next_gt is None:
@@ -223,8 +223,8 @@ class GripperRegionNetwork(nn.Module):
 
         gt_class = gt_positive.float()
         pos_np, neg_np = np.nonzero(flags[2])[0], np.nonzero(~flags[2])[0]
-        pos = torch.from_numpy(pos_np).to(dev)
-        neg = torch.from_numpy(neg_np).to(dev)
+        pos = host_io.upload(pos_np, dev)
+        neg = host_io.upload(neg_np, dev)
         num = min(len(neg_np), len(pos_np))
 
         zero = torch.zeros((), device=dev)
@@ -234,7 +234,7 @@ class GripperRegionNetwork(nn.Module):
             np_random.flush()
             idx0 = neg_np[np.random.choice(len(neg_np), num, replace=False)]
             idx1 = pos_np[np.random.choice(len(pos_np), num, replace=False)]
-            index = torch.from_numpy(np.concatenate((idx0, idx1)).astype(np.int64)).to(dev)
+            index = host_io.upload(np.concatenate((idx0, idx1)).astype(np.int64), dev)
             loss_class = self.criterion_cls(next_x_cls.view(-1, 2)[index], gt_class.view(-1)[index].long())
             l_center = sl1(next_x_reg[pos, :3], (next_gt[pos, :3] - next_grasp[pos, :3]) / self.radius, reduction="mean")
             l_axis = sl1(next_x_reg[pos, 3:6], next_gt[pos, 3:6] - next_grasp[pos, 3:6], reduction="mean")
@@ -487,9 +487,9 @@ def get_gripper_region_transform(group_points, group_index, grasp, region_num, g
             pos_t = pos_pinned.to(dev, non_blocking=True)
         else:
             pos, valid = np_random.choice_rows(count.cpu().numpy(), region_num, 1)
-            pos_t = torch.from_numpy(pos).to(dev)
-        valid_t = torch.from_numpy(valid).to(dev)
-        valid_ids = torch.from_numpy(np.nonzero(valid)[0]).to(dev)    # (the host knows which crops are valid: no device nonzero)
+            pos_t = host_io.upload(pos, dev)
+        valid_t = host_io.upload(valid, dev)
+        valid_ids = host_io.upload(np.nonzero(valid)[0], dev)    # (the host knows which crops are valid: no device nonzero)
     if valid_ids is None:
         valid_ids = torch.nonzero(valid_t).view(-1)     # data-dependent length: the one synchronisation of the crop
 

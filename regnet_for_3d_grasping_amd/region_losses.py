@@ -12,7 +12,7 @@ import ctypes
 import numpy as np
 import torch
 
-from . import _lib, np_random
+from . import _lib, host_io, np_random
 
 FUSED = True
 _L = _lib.lib
@@ -80,19 +80,19 @@ class _Stage2Loss(torch.autograd.Function):
             per_class = max(int(min(len(mem) for mem in members)), 1)
             np_random.flush()
             chosen = [mem[np.random.choice(len(mem), per_class, replace=False)] for mem in members if len(mem)]
-            idx = torch.from_numpy(np.concatenate(chosen).astype(np.int64)).to(dev)
+            idx = host_io.upload(np.concatenate(chosen).astype(np.int64), dev)
             nb = int(idx.numel())
             ce_rows = torch.empty((nb,), dtype=torch.float32, device=dev)
             _check(_L.regnet_ce_rows_f32(x_cls.data_ptr(), A, g8.data_ptr(), idx.data_ptr(), rows.data_ptr(), nb, 1.0 / nb,
                                          ce_rows.data_ptr(), dcls.data_ptr(), _stream(x_reg)), "ce_rows")
             sums = terms.sum(0)
             ce = ce_rows.sum()
-            scale = torch.tensor([1.0 / (3 * m), 1.0 / (3 * m), 1.0 / m, 1.0 / (3 * m), 1.0 / (3 * m), 1.0 / m, 1.0 / m,
-                                  1.0 / (3 * m), 1.0, 0.0, 0.0, 0.0], dtype=torch.float32).to(dev, non_blocking=True)
+            scale = host_io.upload(torch.tensor([1.0 / (3 * m), 1.0 / (3 * m), 1.0 / m, 1.0 / (3 * m), 1.0 / (3 * m), 1.0 / m, 1.0 / m,
+                                  1.0 / (3 * m), 1.0, 0.0, 0.0, 0.0], dtype=torch.float32), dev)
             values = sums * scale
             values[9] = m - values[8]
             values[10] = ce / nb
-            mix = torch.tensor([10.0, 5.0, 1.0, 1.0, 0, 0, 0, 0, 0, 0, 1.0, 0], dtype=torch.float32).to(dev, non_blocking=True)
+            mix = host_io.upload(torch.tensor([10.0, 5.0, 1.0, 1.0, 0, 0, 0, 0, 0, 0, 1.0, 0], dtype=torch.float32), dev)
             loss = torch.dot(values, mix)
         ctx.save_for_backward(dreg, dcls)
         ctx.mark_non_differentiable(values, next_grasp, pick, g8, a_gt)
@@ -149,7 +149,7 @@ class _RefineLoss(torch.autograd.Function):
                        + ([1.0 / (3 * ns), 1.0 / ns, 1.0 / ns, 1.0 / (3 * ns)] if ns > 0 else [nan] * 4))
             else:
                 mon = [0.0] * 12
-            scale = torch.tensor(reg_scale + mon + [1.0] * 4, dtype=torch.float32).to(dev, non_blocking=True)
+            scale = host_io.upload(torch.tensor(reg_scale + mon + [1.0] * 4, dtype=torch.float32), dev)
             values = sums * scale
             if nc > 0 and ns == 0:
                 values[12:16] = nan                                    # 0 * nan above is nan already; written for clarity
@@ -158,15 +158,15 @@ class _RefineLoss(torch.autograd.Function):
                 np_random.flush()
                 idx0 = neg_np[np.random.choice(len(neg_np), num, replace=False)]
                 idx1 = pos_np[np.random.choice(len(pos_np), num, replace=False)]
-                idx = torch.from_numpy(np.concatenate((idx0, idx1)).astype(np.int64)).to(dev)
+                idx = host_io.upload(np.concatenate((idx0, idx1)).astype(np.int64), dev)
                 nb = int(idx.numel())
                 target = flags8[2].to(torch.int32)
                 ce_rows = torch.empty((nb,), dtype=torch.float32, device=dev)
                 _check(_L.regnet_ce_rows_f32(next_x_cls.data_ptr(), 2, target.data_ptr(), idx.data_ptr(), None, nb, 1.0 / nb,
                                              ce_rows.data_ptr(), dcls.data_ptr(), _stream(next_x_reg)), "ce_rows")
                 ce = ce_rows.sum() / nb
-                col = torch.tensor(reg_scale[:1] * 3 + reg_scale[1:2] * 3 + reg_scale[2:3] + reg_scale[3:4] * 3,
-                                   dtype=torch.float32).to(dev, non_blocking=True)
+                col = host_io.upload(torch.tensor(reg_scale[:1] * 3 + reg_scale[1:2] * 3 + reg_scale[2:3] + reg_scale[3:4] * 3,
+                                   dtype=torch.float32), dev)
                 dreg = dreg * col
                 loss = ce + values[:4].sum()
             else:
@@ -174,7 +174,7 @@ class _RefineLoss(torch.autograd.Function):
                 loss = torch.zeros((), dtype=torch.float32, device=dev)
         ctx.save_for_backward(dreg, dcls)
         ctx.has_loss = num > 0
-        extras = (values, ce, final, torch.from_numpy(class_np).to(dev), torch.from_numpy(score_np).to(dev))
+        extras = (values, ce, final, host_io.upload(class_np, dev), host_io.upload(score_np, dev))
         ctx.mark_non_differentiable(*extras)
         return (loss,) + extras
 

@@ -8,7 +8,7 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d $OUT/prof_train -o train -- python $REPO/bench.py --train --batch 8 --steps 24 --warmup 6 > $OUT/train_prof.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $OUT/prof_train -o train -- python $REPO/bench.py --train --batch 8 --steps 24 --warmup 6 --train-timeline-steps 0 --train-accounting-steps 0 > $OUT/train_prof.log 2>&1
 cd $REPO
 python scripts/trace_tail.py $OUT/prof_train 600 60 > $OUT/train_steady_state_kernels.txt
 python scripts/trace_gaps.py $OUT/prof_train 600 40 > $OUT/train_steady_state_gaps.txt

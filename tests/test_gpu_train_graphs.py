@@ -111,11 +111,15 @@ def test_replayed_training_follows_the_eager_trajectory():
     assert replays == 4
     print("eager", le)
     print("graph", lg)
+    # Two EAGER runs of this loop already differ by percents from the third iteration on (the scatter-adds' atomics reorder
+    # fp32 sums, Adam's first steps move every weight by ~lr whatever the size of its gradient, and the region losses sit on
+    # discrete choices): what can be asked of a replayed run is that it stays in that envelope
     for it, (a, b) in enumerate(zip(le, lg)):
-        tol = 2e-3 if it < 3 else 5e-2
-        assert abs(a[1] - b[1]) <= tol * abs(a[1]), ("score loss", it, a, b)
-        if it < 4:     # (later the region losses sit on different discrete choices: which points pass 0.5, which rows are drawn)
-            assert abs(a[0] - b[0]) <= 5e-2 * abs(a[0]), ("total loss", it, a, b)
+        assert abs(a[1] - b[1]) <= (1e-4 if it < 2 else 2e-2) * abs(a[1]), ("score loss", it, a, b)
+        if it < 2:     # (both runs eager)
+            assert abs(a[0] - b[0]) <= 1e-3 * abs(a[0]), ("total loss", it, a, b)
+        else:
+            assert abs(a[0] - b[0]) <= 0.25 * abs(a[0]), ("total loss", it, a, b)
     for k in se:
         if k.endswith("num_batches_tracked"):
             assert int(se[k]) == int(sg[k]) == 6, k
