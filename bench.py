@@ -602,8 +602,13 @@ def measure_train(args, rank, world, dev, steps, warmup, batch):
         # come from a few extra EAGER iterations outside the timed region -- the same launches issued one by one
         accounting_steps, saved = args.train_accounting_steps, trainer.graphs
         trainer.graphs = False
-        timer.enabled = True
-        for _ in range(accounting_steps):
+        for k in range(accounting_steps + 2):
+            # (two eager iterations first, unbracketed: the allocator's cache of the eager path -- 30 GB of activations -- may
+            # have been trimmed since the warm-up, and an iteration that waits for hipMalloc is paced by the host: events
+            # around a launch then time the launching thread, not the kernel)
+            if k == 2:
+                torch.cuda.synchronize()
+                timer.enabled = True
             nxt = trainer.prefetch(batches[(it + 1) % distinct][0])
             trainer.step(*batches[it % distinct], plan=ahead)
             ahead, it = nxt, it + 1
