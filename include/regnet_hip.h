@@ -621,6 +621,16 @@ int regnet_conv1x1_smallco_f32(int dir, const float* W, const float* bias, const
  * only), so that small kernels of ANOTHER stream -- the region stage beside the segmentation head's backward -- find CUs to
  * start on instead of advancing one launch per persistent launch.  Process-wide; returns the previous value.            */
 int regnet_conv1x1_stream_reserve_slots(int slots);
+/* EXPERIMENT, not on any default path (conv1x1_train.SPLIT_PRODUCTS): the same forward / input gradient with fp32-faithful
+ * products on the bf16 matrix pipe -- every operand as the exact sum of three bf16 pieces, six of the nine piece products (the
+ * dropped ones are <= 2^-24 relative), fp32 accumulation (csrc/tsplit.hip).  transposed == 0: Y (B, Co, L) = W (Co, Ci) .
+ * X (B, Ci, L), optionally on [relu](bscale[i] X[., i, .] + bshift[i]) (NULL: none; Ci <= 1024); transposed == 1: dX (B, Ci, L) =
+ * W^T . dY (B, Co, L).  Co, Ci multiples of 16.  workspace: regnet_conv1x1_split_workspace_bytes(Co, Ci, transposed) bytes,
+ * 16-byte aligned (the weight's three bf16 planes, rebuilt by every call: the weights move every iteration).             */
+int regnet_conv1x1_split_supported(int64_t Co, int64_t Ci, int64_t L);
+int64_t regnet_conv1x1_split_workspace_bytes(int64_t Co, int64_t Ci, int64_t transposed);
+int regnet_conv1x1_split_f32(int transposed, const float* W, const float* in, float* out, int64_t B, int64_t Co, int64_t Ci,
+                             int64_t L, const float* bscale, const float* bshift, int brelu, void* workspace, void* stream);
 /* ..._bnrelu: the convolution's input is [relu](scale[i] * X[., i, .] + shift[i]) -- a training BatchNorm (+ ReLU) given as
  * its per-channel affine (regnet_bn_train_stats_f32) -- applied to the operand fragments inside the contraction; X itself
  * is the BatchNorm's INPUT.  regnet_conv1x1_bnrelu_supported: train_supported, Ci <= 512 (the affine table lives in LDS),

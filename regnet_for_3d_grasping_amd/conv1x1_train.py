@@ -25,6 +25,9 @@ DEFER_BN = True
 # input channel counts without a native tile (259, 515, 3: [xyz | feature] rows) are zero-padded to the next multiple of 16
 # (at least 32) so that all three contractions stay on csrc/tgemm.hip (_Conv1x1Padded); 0: rocBLAS batched GEMMs for them
 PAD_CHANNELS = True
+# EXPERIMENT, off: forward / input gradient with fp32-faithful products on the bf16 matrix pipe (csrc/tsplit.hip: every
+# operand as three bf16 pieces, six products, fp32 accumulation).  Never a default path; bench.py reports it under its own name.
+SPLIT_PRODUCTS = False
 DEFERRED = {"layers": 0}     # convolutions that consumed a pending BatchNorm since import (tests, bench)
 
 
@@ -33,6 +36,24 @@ def reserve_stream_slots(slots):
     previous value.  ``train_step`` reserves some while the segmentation head's backward runs beside the region stage."""
     from . import _lib
     return int(_lib.lib.regnet_conv1x1_stream_reserve_slots(int(slots)))
+
+
+def _split(transposed, w, x, B, Co, Ci, L, scale=None, shift=None, relu=0):
+    """``regnet_conv1x1_split_f32``: x (B, K, L) -> (B, M, L) with (M, K) = (Co, Ci) forward, (Ci, Co) transposed."""
+    from . import _lib
+    out = torch.empty((B, Ci if transposed else Co, L), dtype=torch.float32, device=x.device)
+    ws = torch.empty((_lib.lib.regnet_conv1x1_split_workspace_bytes(Co, Ci, transposed),), dtype=torch.uint8, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib.regnet_conv1x1_split_f32(transposed, w.data_ptr(), x.data_ptr(), out.data_ptr(), B, Co, Ci, L,
+                                                     scale.data_ptr() if scale is not None else None,
+                                                     shift.data_ptr() if shift is not None else None, int(relu), ws.data_ptr(),
+                                                     _stream(x)), "conv1x1_split")
+    return out
+
+
+def _split_ok(Co, Ci, L, affine=False):
+    from . import _lib
+    return SPLIT_PRODUCTS and bool(_lib.lib.regnet_conv1x1_split_supported(Co, Ci, L)) and (not affine or Ci <= 1024)
 
 
 def _native_ok(B, Co, Ci, L, wgrad=False):
@@ -61,6 +82,8 @@ def native_fwd(x, w):
     from . import _lib
     B, Ci, L = x.shape
     Co = w.shape[0]
+    if _split_ok(Co, Ci, L):
+        return _split(0, w, x, B, Co, Ci, L)
     y = torch.empty((B, Co, L), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
         if STREAM:
@@ -79,6 +102,8 @@ def native_dgrad(w, dy):
     from . import _lib
     B, Co, L = dy.shape
     Ci = w.shape[1]
+    if _split_ok(Co, Ci, L):
+        return _split(1, w, dy, B, Co, Ci, L)
     dx = torch.empty((B, Ci, L), dtype=torch.float32, device=dy.device)
     with torch.cuda.device(dy.device):
         if STREAM:
@@ -113,6 +138,8 @@ def native_fwd_bnrelu(x, w, scale, shift, relu):
     from . import _lib, fused
     B, Ci, L = x.shape
     Co = w.shape[0]
+    if _split_ok(Co, Ci, L, affine=True):
+        return _split(0, w, x, B, Co, Ci, L, scale, shift, relu)
     y = torch.empty((B, Co, L), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
         _lib.check(_lib.lib.regnet_conv1x1_fwd_bnrelu_stream_f32(w.data_ptr(), x.data_ptr(), y.data_ptr(), B, Co, Ci, L,

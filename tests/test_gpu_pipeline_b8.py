@@ -142,7 +142,7 @@ def test_scores_against_the_float64_evaluation():
     """How much of |HIP - reference| is whose rounding: the S8 scenes against a float64 evaluation of the same graph
     (tests/golden/make_fp64_truth.py -> s8_score_fp64.npz; same index tensors, every floating-point op in double).  The
     reference's own fp32 scores sit 4.1e-5 from it; the HIP path must stay within north_star's 1e-4 of it as well (measured
-    6.7e-5; torch's own GPU convolutions on the operator-granular path: 9.4e-5 -- profiles/r03_error_budget.txt)."""
+    6.7e-5; torch's own GPU convolutions on the operator-granular path: 9.4e-5 -- profiles/archive/r03_error_budget.txt)."""
     from regnet_for_3d_grasping_amd import synthetic
     m7, m8 = gu.meta_full(), _meta8()
     cfg = m8["cfg"]
