@@ -89,6 +89,9 @@ def parse():
     ap.add_argument("--real-density-steps", type=int, default=20,
                     help="steps of the extra pass AFTER the timed region over density-matched scenes (synthetic.make_scene(density="
                          "'real'): level-1 neighbourhood sizes like the reference's own clouds) for value_real_density; 0 = skip")
+    ap.add_argument("--split-products-steps", type=int, default=20,
+                    help="steps timed AFTER the timed region with the fenced split-products experiment on (fused.SPLIT_PRODUCTS: the level-1 "
+                         "block on the bf16 matrix pipe, fp32-faithful) for value_split_products; 0 = skip.  Never part of `value`")
     ap.add_argument("--lookahead", type=int, default=3, help="batches whose region stage may be pending (pipeline depth)")
     ap.add_argument("--geometry-ahead", type=int, default=1, help="batches whose ball-query / 3-NN geometry is queued ahead of the feature stage")
     ap.add_argument("--graphs", choices=("auto", "on", "off"), default="auto",
@@ -963,6 +966,44 @@ def main():
         torch.cuda.synchronize()
         no_lookahead = args.batch * args.no_lookahead_steps / (time.perf_counter() - t1)
 
+    split_products = None
+    if world == 1 and args.split_products_steps > 0 and not args.score_only and args.points <= 102400:
+        # The fenced ceiling experiment (DESIGN.md par. 10): the SAME pipeline, scenes and weights with sa_chain_kernel replaced by
+        # csrc/sa_split.hip -- every operand as three bf16 pieces, six products on the bf16 matrix pipe, fp32 accumulation.  After
+        # the timed region; its own value, its own parity figures (the bench scene's scores against the exact path's), never `value`.
+        from regnet_for_3d_grasping_amd import fused as _fused
+        with torch.no_grad():
+            _, score_exact, _ = score_net(pcs[0])
+        _fused.SPLIT_PRODUCTS = True
+        try:
+            with torch.no_grad():
+                _, score_split, _ = score_net(pcs[0])
+            pipe_s = pipeline.ForwardPipeline(score_net, region_net, with_region=not args.score_only, fps_streams=args.fps_streams,
+                                              mlp_streams=args.mlp_streams, fps_group=args.fps_group,
+                                              first_launch_groups=args.first_launch_groups, geometry_ahead=args.geometry_ahead,
+                                              graphs={"auto": "auto", "on": True, "off": False}[args.graphs])
+            was_enabled, timer.enabled = timer.enabled, False
+            for _ in pipe_s.run((pcs[k % distinct] for k in range(max(2, args.warmup))), max_pending_regions=args.lookahead):
+                pass
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in pipe_s.run((pcs[k % distinct] for k in range(args.split_products_steps)), max_pending_regions=args.lookahead):
+                pass
+            torch.cuda.synchronize()
+            dt_s = time.perf_counter() - t1
+            timer.enabled = was_enabled
+        finally:
+            _fused.SPLIT_PRODUCTS = False
+        split_products = {"value": round(args.batch * args.split_products_steps / dt_s, 3), "unit": "scenes/s",
+                          "ms_per_step": round(dt_s / args.split_products_steps * 1e3, 3), "steps": args.split_products_steps,
+                          "what": "fused.SPLIT_PRODUCTS: the level-1 set-abstraction block (32.7 of a scene's 148.3 GFLOP) by "
+                                  "sa_chain_split_kernel (v_mfma_f32_32x32x16_bf16 on three bf16 pieces per operand, six products, fp32 "
+                                  "accumulation); every other kernel the exact-fp32 one",
+                          "score_max_abs_diff_vs_exact_path": float((score_split - score_exact).abs().max()),
+                          "positives_changed": int(((score_split > 0.5) != (score_exact > 0.5)).sum()),
+                          # instruction ceilings measured on this chip (scripts/ablate/split_products.cpp): bf16 1 864 TFLOP/s / 6
+                          "ceiling_tflops_fp32_equivalent": 310.6}
+
     real_density = None
     if world == 1 and args.real_density_steps > 0:
         # SURVEY 8(d) "real-density variant": the SAME pipeline configuration and weights over scenes whose level-1
@@ -1159,6 +1200,9 @@ def main():
             "latency_ms_single_scene": latency_ms,
             # the same pipeline on density-matched scenes (level-1 neighbourhoods like the reference's clouds), after the timed region
             "value_real_density": None if real_density is None else real_density["value"],
+            # EXPERIMENT, never the headline: the same run with the level-1 block on the bf16 matrix pipe (fp32-faithful split products)
+            "value_split_products": None if split_products is None else split_products["value"],
+            "split_products": split_products,
             "real_density": real_density,
             "value_no_lookahead": None if no_lookahead is None else round(no_lookahead, 3),
             "value_no_lookahead_note": None if no_lookahead is None else (

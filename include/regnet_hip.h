@@ -627,6 +627,19 @@ int regnet_conv1x1_stream_reserve_slots(int slots);
  * X (B, Ci, L), optionally on [relu](bscale[i] X[., i, .] + bshift[i]) (NULL: none; Ci <= 1024); transposed == 1: dX (B, Ci, L) =
  * W^T . dY (B, Co, L).  Co, Ci multiples of 16.  workspace: regnet_conv1x1_split_workspace_bytes(Co, Ci, transposed) bytes,
  * 16-byte aligned (the weight's three bf16 planes, rebuilt by every call: the weights move every iteration).             */
+/* ... and regnet_sa_chain3_f32 (the level-1 set-abstraction block in one kernel) the same way: csrc/sa_split.hip, fused.SPLIT_PRODUCTS,
+ * off.  W2 (128 x 128, row stride ldw2) and W3 (C3 x 128, ldw3) are the packed fp32 weights; `planes`
+ * (regnet_sa_chain3_split_plane_bytes(C3) bytes, 16-byte aligned) receives their bf16 pieces when build_planes != 0 and is read as it
+ * is otherwise (the caller caches it per weight version).  ticket: a zeroed int32 (work-queue head of the persistent workgroups).
+ * group == 64, Cf + 3 <= 8, C3 % 64 == 0.                                                                                  */
+int64_t regnet_sa_chain3_split_plane_bytes(int64_t C3);
+int regnet_sa_chain3_split_f32(const float* feat, int64_t fb, int64_t fn, int64_t fc, int64_t Cf, const float* xyz, int64_t xb,
+                               int64_t xc, int64_t xn, const int64_t* nbr, const int64_t* ctr, const int64_t* count,
+                               const int64_t* order, int64_t B, int64_t M, int64_t group,
+                               const float* W1, const float* scale1, const float* shift1, const float* W2, int64_t ldw2,
+                               const float* scale2, const float* shift2, const float* W3, int64_t ldw3, const float* scale3,
+                               const float* shift3, int64_t C3, int relu3, void* planes, int build_planes, float* out, int64_t ldo,
+                               int32_t* ticket, void* stream);
 int regnet_conv1x1_split_supported(int64_t Co, int64_t Ci, int64_t L);
 int64_t regnet_conv1x1_split_workspace_bytes(int64_t Co, int64_t Ci, int64_t transposed);
 int regnet_conv1x1_split_f32(int transposed, const float* W, const float* in, float* out, int64_t B, int64_t Co, int64_t Ci,

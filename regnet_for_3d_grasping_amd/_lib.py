@@ -119,6 +119,9 @@ SIGNATURES = {
     "regnet_conv1x1_wgrad_smallci_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp]),
     "regnet_conv1x1_smallco_f32": (_int, [_int, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp]),
     "regnet_conv1x1_stream_reserve_slots": (_int, [_int]),
+    "regnet_sa_chain3_split_plane_bytes": (_i64, [_i64]),
+    "regnet_sa_chain3_split_f32": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp,
+                                         _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _int, _vp, _int, _vp, _i64, _vp, _vp]),
     "regnet_conv1x1_split_supported": (_int, [_i64, _i64, _i64]),
     "regnet_conv1x1_split_workspace_bytes": (_i64, [_i64, _i64, _i64]),
     "regnet_conv1x1_split_f32": (_int, [_int, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _int, _vp, _vp]),

@@ -27,6 +27,7 @@ SOURCES = [
     ("heads_train.hip", []),
     ("losses.hip", ["-ffp-contract=off"]),
     ("tgemm.hip", []),
+    ("sa_split.hip", ["-fno-slp-vectorize"]),   # experiment, off by default: the level-1 chain on the bf16 pipe (fused.SPLIT_PRODUCTS)
     ("tsplit.hip", []),      # experiment, off by default: split products on the bf16 matrix pipe (conv1x1_train.SPLIT_PRODUCTS)
     ("bn_train.hip", []),
     ("np_random.hip", []),

@@ -276,11 +276,43 @@ def chain3_order(count):
     return torch.argsort((c > 32).to(torch.uint8) + (c > 48).to(torch.uint8), stable=True)
 
 
+# EXPERIMENT, off: the level-1 block with fp32-faithful products on the bf16 matrix pipe (csrc/sa_split.hip).  Never a
+# default path; bench.py reports it under its own name (value_split_products).
+SPLIT_PRODUCTS = False
+_split_planes = {}
+
+
+@_on_tensor_device
+def sa_chain3_split(feature, xyz, nbr, ctr, l1, l2, l3, B, M, group, count=None, order=None):
+    """``sa_chain3`` by ``regnet_sa_chain3_split_f32``; the weights' bf16 pieces are built once per packed-weight tensor pair."""
+    out = torch.empty((B * M, l3.N), dtype=torch.float32, device=xyz.device)
+    if feature is None:
+        fptr, fb, fn, fc, Cf = None, 0, 0, 0, 0
+    else:
+        fptr, (fb, fc, fn), Cf = feature.data_ptr(), feature.stride(), feature.size(1)
+    key = (l2.W.data_ptr(), l2.W._version, l3.W.data_ptr(), l3.W._version)
+    planes = _split_planes.get(key)
+    build = planes is None
+    if build:
+        _split_planes.clear()
+        planes = torch.empty((_L.regnet_sa_chain3_split_plane_bytes(l3.N),), dtype=torch.uint8, device=xyz.device)
+        _split_planes[key] = planes
+    _check(_L.regnet_sa_chain3_split_f32(fptr, fb, fn, fc, Cf, xyz.data_ptr(), *xyz.stride(), nbr.data_ptr(), ctr.data_ptr(),
+                                         None if count is None else count.data_ptr(), None if order is None else order.data_ptr(), B, M,
+                                         group, l1.W8.data_ptr(), l1.scale.data_ptr(), l1.shift.data_ptr(), l2.W.data_ptr(), l2.Kpad,
+                                         l2.scale.data_ptr(), l2.shift.data_ptr(), l3.W.data_ptr(), l3.Kpad, l3.scale.data_ptr(),
+                                         l3.shift.data_ptr(), l3.N, l3.relu, planes.data_ptr(), int(build), out.data_ptr(),
+                                         out.stride(0), _tickets(xyz.device).data_ptr(), _stream(xyz)), "sa_chain3_split")
+    return out
+
+
 @_on_tensor_device
 def sa_chain3(feature, xyz, nbr, ctr, l1, l2, l3, B, M, group, count=None, order=None):
     """Whole narrow-input SA block (gather, three layers, max over the neighbours) in one kernel; -> (B*M, C3).
     ``count`` (B,M) int64: members per neighbourhood (half the work for those with <= 32); ``order`` (B*M,) int64:
     processing order of the neighbourhoods (small ones together)."""
+    if SPLIT_PRODUCTS and group == 64 and l2.Kpad == 128 and l3.Kpad == 128 and l3.N % 32 == 0:
+        return sa_chain3_split(feature, xyz, nbr, ctr, l1, l2, l3, B, M, group, count, order)
     out = torch.empty((B * M, l3.N), dtype=torch.float32, device=xyz.device)
     if feature is None:
         fptr, fb, fn, fc, Cf = None, 0, 0, 0, 0

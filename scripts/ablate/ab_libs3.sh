@@ -6,7 +6,7 @@ cp $LIB /tmp/lib_A.so
 for i in $(seq 1 $R); do
   for v in A "$@"; do
     if [ $v = A ]; then cp /tmp/lib_A.so $LIB; else cp $v $LIB; fi
-    python bench.py --steps $STEPS --warmup 5 --cpu-scenes 0 --latency-runs 0 --train-steps 0 --no-lookahead-steps 0 --real-density-steps 0 2>/dev/null | python -c "
+    python bench.py --steps $STEPS --warmup 5 --cpu-scenes 0 --latency-runs 0 --train-steps 0 --no-lookahead-steps 0 --real-density-steps 0 --split-products-steps 0 2>/dev/null | python -c "
 import json,sys
 j=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=j['roofline']
 print('%-28s %d steps: %.3f ms/step %.1f scenes/s  %s' % ('$v', j['steps'], j['ms_per_step'], j['value'], r['families_ms_per_step']))"

@@ -1,6 +1,6 @@
 # EXPERIMENT: queue CU masks (feature stream off r CUs per XCD, region / sampling streams on them) vs the default
 cd ${GRAFT_REPO_ROOT:-/root/repo}
-COMMON="--steps 20 --warmup 5 --cpu-scenes 0 --latency-runs 0 --train-steps 0 --no-lookahead-steps 0 --real-density-steps 0"
+COMMON="--steps 20 --warmup 5 --cpu-scenes 0 --latency-runs 0 --train-steps 0 --no-lookahead-steps 0 --real-density-steps 0 --split-products-steps 0"
 run() { timeout 300 python bench.py $COMMON "$@" 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); r=d['roofline']
@@ -14,7 +14,7 @@ for rep in 1 2; do
   run --set pipeline.LEVEL_EVENTS=1
 done
 echo "== 200 steps"
-COMMON="--steps 200 --warmup 5 --cpu-scenes 0 --latency-runs 0 --train-steps 0 --no-lookahead-steps 0 --real-density-steps 0"
+COMMON="--steps 200 --warmup 5 --cpu-scenes 0 --latency-runs 0 --train-steps 0 --no-lookahead-steps 0 --real-density-steps 0 --split-products-steps 0"
 run
 run --reserve-cus 1 --reserve-for reg,fps
 run --reserve-cus 1 --reserve-for reg

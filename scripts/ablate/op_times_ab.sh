@@ -3,7 +3,7 @@
 STEPS=${1:-120}; shift
 for v in "$@"; do
   if [ $v = A ]; then unset REGNET_HIP_LIB; else export REGNET_HIP_LIB=$PWD/$v; fi
-  python bench.py --steps $STEPS --warmup 5 --time-every 1 --cpu-scenes 0 --latency-runs 0 --train-steps 0 --no-lookahead-steps 0 --real-density-steps 0 2>/dev/null | python -c "
+  python bench.py --steps $STEPS --warmup 5 --time-every 1 --cpu-scenes 0 --latency-runs 0 --train-steps 0 --no-lookahead-steps 0 --real-density-steps 0 --split-products-steps 0 2>/dev/null | python -c "
 import json,sys
 j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('== $v', j['ms_per_step'], 'late', j['config']['host_late_feature_stages'])
 agg={}

@@ -4,7 +4,7 @@
 #   strm  fused.STREAM_LAYERS=1                     (persistent launch where >= 256 tiles)
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 R=${1:-3}; STEPS=${2:-20}
-COMMON="--steps $STEPS --warmup 5 --cpu-scenes 0 --latency-runs 0 --train-steps 0 --no-lookahead-steps 0 --real-density-steps 0"
+COMMON="--steps $STEPS --warmup 5 --cpu-scenes 0 --latency-runs 0 --train-steps 0 --no-lookahead-steps 0 --real-density-steps 0 --split-products-steps 0"
 for i in $(seq 1 $R); do
   for v in old t8 strm; do
     case $v in

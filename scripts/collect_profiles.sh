@@ -13,9 +13,9 @@ OUT=$REPO/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 python $REPO/bench.py $EXTRA > $OUT/bench.json 2> $OUT/bench.err
-rocprofv3 --kernel-trace --stats -d $OUT/prof -o $TAG -- python $REPO/bench.py $EXTRA --cpu-scenes 0 --exclusive-steps 0 --latency-runs 0 --train-steps 0 --no-lookahead-steps 0 --real-density-steps 0 --steps 32 > $OUT/prof.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o p -- python $REPO/bench.py $EXTRA --cpu-scenes 0 --exclusive-steps 0 --latency-runs 0 --train-steps 0 --no-lookahead-steps 0 --real-density-steps 0 --steps 4 > $OUT/pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o p -- python $REPO/bench.py $EXTRA --cpu-scenes 0 --exclusive-steps 0 --latency-runs 0 --train-steps 0 --no-lookahead-steps 0 --real-density-steps 0 --steps 4 > $OUT/pmc_write.log 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/prof -o $TAG -- python $REPO/bench.py $EXTRA --cpu-scenes 0 --exclusive-steps 0 --latency-runs 0 --train-steps 0 --no-lookahead-steps 0 --real-density-steps 0 --split-products-steps 0 --steps 32 > $OUT/prof.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o p -- python $REPO/bench.py $EXTRA --cpu-scenes 0 --exclusive-steps 0 --latency-runs 0 --train-steps 0 --no-lookahead-steps 0 --real-density-steps 0 --split-products-steps 0 --steps 4 > $OUT/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o p -- python $REPO/bench.py $EXTRA --cpu-scenes 0 --exclusive-steps 0 --latency-runs 0 --train-steps 0 --no-lookahead-steps 0 --real-density-steps 0 --split-products-steps 0 --steps 4 > $OUT/pmc_write.log 2>&1
 cd $REPO
 DB=$(find $OUT/prof -name "*results.db" | head -1)
 # (the workload the trace is of goes into the JSON: bench.py refuses to price another batch / point count with it)

@@ -51,7 +51,7 @@ PY
 }
 for N in $NS; do
   if [ "$N" -gt "$HAVE" ]; then echo "N=$N: only $HAVE GPU(s) here, skipped"; continue; fi
-  line forward     $N --steps 40 --warmup 5 --cpu-scenes 0 --latency-runs 0 --train-steps 0 --no-lookahead-steps 0 --real-density-steps 0
+  line forward     $N --steps 40 --warmup 5 --cpu-scenes 0 --latency-runs 0 --train-steps 0 --no-lookahead-steps 0 --real-density-steps 0 --split-products-steps 0
   line train       $N --train --batch 8 --steps 24 --warmup 5
   line train_51200 $N --train --batch 4 --points 51200 --steps 16 --warmup 4
   if [ "$N" = 2 ] || [ "$N" = 4 ]; then line train_gb16 $N --train --global-batch 16 --steps 24 --warmup 5; fi
