@@ -311,7 +311,8 @@ def sa_chain3(feature, xyz, nbr, ctr, l1, l2, l3, B, M, group, count=None, order
     """Whole narrow-input SA block (gather, three layers, max over the neighbours) in one kernel; -> (B*M, C3).
     ``count`` (B,M) int64: members per neighbourhood (half the work for those with <= 32); ``order`` (B*M,) int64:
     processing order of the neighbourhoods (small ones together)."""
-    if SPLIT_PRODUCTS and group == 64 and l2.Kpad == 128 and l3.Kpad == 128 and l3.N % 32 == 0:
+    if (SPLIT_PRODUCTS and group == 64 and l2.Kpad == 128 and l3.Kpad == 128 and l3.N == 256 and feature is not None
+            and feature.size(1) == 3):      # (the shapes of the level-1 block, the only ones the experiment's kernel is built for)
         return sa_chain3_split(feature, xyz, nbr, ctr, l1, l2, l3, B, M, group, count, order)
     out = torch.empty((B * M, l3.N), dtype=torch.float32, device=xyz.device)
     if feature is None:
