@@ -465,6 +465,17 @@ int regnet_bn_relu_train_bwd_f32(const float* x, const float* y, const float* dy
 int regnet_bn_train_stats_f32(const float* x, int64_t B, int64_t C, int64_t L, const float* gamma, const float* beta, float eps,
                               float momentum, float* running_mean, float* running_var, float* save_mean, float* save_invstd,
                               float* scale, float* shift, void* workspace, void* stream);
+/* ..._from_sums: the same two entry points with the statistics PASS already done -- `workspace` holds, per channel, the sum and
+ * the sum of squares of x over all B L elements (2 C doubles) as regnet_conv1x1_fwd_stats_stream_f32, the convolution that
+ * produced x, accumulated them from its output tiles: x is not read for its statistics (regnet_bn_train_stats_from_sums_f32
+ * does not take it at all).                                                                                            */
+int regnet_bn_relu_train_fwd_from_sums_f32(const float* x, int64_t B, int64_t C, int64_t L, const float* gamma, const float* beta,
+                                           float eps, float momentum, float* running_mean, float* running_var, int relu,
+                                           int64_t pool_group, float* y, int32_t* pool_index, float* save_mean,
+                                           float* save_invstd, void* workspace, void* stream);
+int regnet_bn_train_stats_from_sums_f32(int64_t B, int64_t C, int64_t L, const float* gamma, const float* beta, float eps,
+                                        float momentum, float* running_mean, float* running_var, float* save_mean,
+                                        float* save_invstd, float* scale, float* shift, void* workspace, void* stream);
 
 /* ---- set-abstraction layers 1+2 with layer 1 evaluated per SOURCE point ---------------------------
  * The first SharedMLP layer of a set-abstraction block (pn2_utils/modules.py:44-55: conv over
@@ -653,6 +664,16 @@ int regnet_conv1x1_fwd_bnrelu_stream_f32(const float* W, const float* X, float* 
                                          const float* scale, const float* shift, int relu, int32_t* ticket, void* stream);
 int regnet_conv1x1_wgrad_bnrelu_f32(const float* dY, const float* X, float* dW, int64_t B, int64_t Co, int64_t Ci, int64_t L,
                                     const float* scale, const float* shift, int relu, void* workspace, void* stream);
+/* The forward (plain: scale == NULL; or ..._bnrelu) that also leaves the statistics of the BatchNorm FOLLOWING the convolution:
+ * sums (2 Co doubles, 8-byte aligned; zeroed and filled by the call) = per output channel the sum and the sum of squares of Y
+ * over all B L points, taken from the output tiles while they are in registers -- nn/modules/conv.py:30-36's bn(conv(x)) without
+ * a statistics pass over Y.  Continue with regnet_bn_train_stats_from_sums_f32 / regnet_bn_relu_train_fwd_from_sums_f32.
+ * regnet_conv1x1_fwd_stats_supported: train_supported, Co <= 256 (the fp64 table lives in LDS beside the operand ring);
+ * affine: Ci <= 256, L % 16 == 0.                                                                                       */
+int regnet_conv1x1_fwd_stats_supported(int64_t Co, int64_t Ci, int64_t L, int affine);
+int regnet_conv1x1_fwd_stats_stream_f32(const float* W, const float* X, float* Y, int64_t B, int64_t Co, int64_t Ci, int64_t L,
+                                        const float* scale, const float* shift, int relu, int32_t* ticket, void* sums,
+                                        void* stream);
 int64_t regnet_conv1x1_wgrad_slices(int64_t B, int64_t Co, int64_t Ci, int64_t L);
 int64_t regnet_conv1x1_wgrad_workspace_bytes(int64_t B, int64_t Co, int64_t Ci, int64_t L);
 int regnet_conv1x1_wgrad_f32(const float* dY, const float* X, float* dW, int64_t B, int64_t Co, int64_t Ci, int64_t L,

@@ -83,6 +83,9 @@ SIGNATURES = {
     "regnet_bn_relu_train_bwd_f32": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _int, _i64, _vp, _vp,
                                             _vp, _vp, _vp]),
     "regnet_bn_train_stats_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "regnet_bn_relu_train_fwd_from_sums_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _f32, _f32, _vp, _vp, _int, _i64, _vp, _vp,
+                                                      _vp, _vp, _vp, _vp]),
+    "regnet_bn_train_stats_from_sums_f32": (_int, [_i64, _i64, _i64, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "regnet_pack_rows_f32": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp]),
     "regnet_pack_rows_centred_f32": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _vp]),
     "regnet_gather_points_f32": (_int, [_vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _vp]),
@@ -127,6 +130,8 @@ SIGNATURES = {
     "regnet_conv1x1_split_f32": (_int, [_int, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _int, _vp, _vp]),
     "regnet_conv1x1_bnrelu_supported": (_int, [_i64, _i64, _i64]),
     "regnet_conv1x1_fwd_bnrelu_stream_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _int, _vp, _vp]),
+    "regnet_conv1x1_fwd_stats_supported": (_int, [_i64, _i64, _i64, _int]),
+    "regnet_conv1x1_fwd_stats_stream_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _int, _vp, _vp, _vp]),
     "regnet_conv1x1_wgrad_bnrelu_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _int, _vp, _vp]),
     "regnet_conv1x1_wgrad_slices": (_i64, [_i64, _i64, _i64, _i64]),
     "regnet_conv1x1_wgrad_workspace_bytes": (_i64, [_i64, _i64, _i64, _i64]),

@@ -28,7 +28,11 @@ PAD_CHANNELS = True
 # EXPERIMENT, off: forward / input gradient with fp32-faithful products on the bf16 matrix pipe (csrc/tsplit.hip: every
 # operand as three bf16 pieces, six products, fp32 accumulation).  Never a default path; bench.py reports it under its own name.
 SPLIT_PRODUCTS = False
+# the statistics pass of the BatchNorm that follows a convolution taken from the convolution's output tiles while they are in
+# registers (csrc/tgemm.hip STATS: per-channel sum / sum of squares in fp64), so that bn_train does not read the output for them
+FUSE_STATS = True
 DEFERRED = {"layers": 0}     # convolutions that consumed a pending BatchNorm since import (tests, bench)
+STATS_FUSED = {"layers": 0}  # convolutions that left the following BatchNorm's statistics since import
 
 
 def reserve_stream_slots(slots):
@@ -77,16 +81,36 @@ def supported(conv, x):
 
 
 # ---- thin wrappers of the native kernels (module-level names so bench.py --train can bracket them with events) --------
-def native_fwd(x, w):
-    """x (B, Ci, L) contiguous, w (Co, Ci) contiguous -> Y (B, Co, L) on csrc/tgemm.hip."""
+def stats_ok(Co, Ci, L, affine=False):
+    """The forward of this shape can leave the statistics of the BatchNorm that follows it (``sums`` of native_fwd /
+    native_fwd_bnrelu)."""
+    if not (FUSE_STATS and NATIVE and STREAM) or _split_ok(Co, Ci, L, affine):
+        return False
+    from . import _lib
+    return bool(_lib.lib.regnet_conv1x1_fwd_stats_supported(Co, Ci, L, int(affine)))
+
+
+def new_sums(Co, device):
+    STATS_FUSED["layers"] += 1
+    return torch.empty((2 * Co,), dtype=torch.float64, device=device)
+
+
+def native_fwd(x, w, sums=None):
+    """x (B, Ci, L) contiguous, w (Co, Ci) contiguous -> Y (B, Co, L) on csrc/tgemm.hip.  ``sums`` (2 Co float64, see
+    ``stats_ok``): filled with the per-channel sum and sum of squares of Y."""
     from . import _lib
     B, Ci, L = x.shape
     Co = w.shape[0]
-    if _split_ok(Co, Ci, L):
+    if sums is None and _split_ok(Co, Ci, L):
         return _split(0, w, x, B, Co, Ci, L)
     y = torch.empty((B, Co, L), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
-        if STREAM:
+        if sums is not None:
+            from . import fused
+            _lib.check(_lib.lib.regnet_conv1x1_fwd_stats_stream_f32(w.data_ptr(), x.data_ptr(), y.data_ptr(), B, Co, Ci, L, None,
+                                                                    None, 0, fused._tickets(x.device).data_ptr(),
+                                                                    sums.data_ptr(), _stream(x)), "conv1x1_fwd_stats")
+        elif STREAM:
             from . import fused
             _lib.check(_lib.lib.regnet_conv1x1_fwd_stream_f32(w.data_ptr(), x.data_ptr(), y.data_ptr(), B, Co, Ci, L,
                                                               fused._tickets(x.device).data_ptr(), _stream(x)),
@@ -132,16 +156,22 @@ def native_wgrad(dy, x):
     return dw
 
 
-def native_fwd_bnrelu(x, w, scale, shift, relu):
+def native_fwd_bnrelu(x, w, scale, shift, relu, sums=None):
     """Y = W . [relu](scale * x + shift) (per input channel), x (B, Ci, L) contiguous: the forward of a convolution that
-    consumes a pending training BatchNorm (csrc/tgemm.hip: tgemm_stream_kernel<.., B_AFFINE>)."""
+    consumes a pending training BatchNorm (csrc/tgemm.hip: tgemm_stream_kernel<.., B_AFFINE>).  ``sums``: as native_fwd."""
     from . import _lib, fused
     B, Ci, L = x.shape
     Co = w.shape[0]
-    if _split_ok(Co, Ci, L, affine=True):
+    if sums is None and _split_ok(Co, Ci, L, affine=True):
         return _split(0, w, x, B, Co, Ci, L, scale, shift, relu)
     y = torch.empty((B, Co, L), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
+        if sums is not None:
+            _lib.check(_lib.lib.regnet_conv1x1_fwd_stats_stream_f32(w.data_ptr(), x.data_ptr(), y.data_ptr(), B, Co, Ci, L,
+                                                                    scale.data_ptr(), shift.data_ptr(), relu,
+                                                                    fused._tickets(x.device).data_ptr(), sums.data_ptr(),
+                                                                    _stream(x)), "conv1x1_fwd_bnrelu_stats")
+            return y
         _lib.check(_lib.lib.regnet_conv1x1_fwd_bnrelu_stream_f32(w.data_ptr(), x.data_ptr(), y.data_ptr(), B, Co, Ci, L,
                                                                  scale.data_ptr(), shift.data_ptr(), relu,
                                                                  fused._tickets(x.device).data_ptr(), _stream(x)),
@@ -168,11 +198,11 @@ def native_wgrad_bnrelu(dy, x, scale, shift, relu):
 
 # what bench.py --train brackets: name -> meta(args)
 TIMED_OPS = {
-    "native_fwd_bnrelu": lambda x, w, scale, shift, relu: "B%d Co%d Ci%d L%d flop%d" % (
+    "native_fwd_bnrelu": lambda x, w, scale, shift, relu, sums=None: "B%d Co%d Ci%d L%d flop%d" % (
         x.shape[0], w.shape[0], x.shape[1], x.shape[2], 2 * x.shape[0] * w.shape[0] * x.shape[1] * x.shape[2]),
     "native_wgrad_bnrelu": lambda dy, x, scale, shift, relu: "B%d Co%d Ci%d L%d flop%d" % (
         dy.shape[0], dy.shape[1], x.shape[1], x.shape[2], 2 * dy.shape[0] * dy.shape[1] * x.shape[1] * x.shape[2]),
-    "native_fwd": lambda x, w: "B%d Co%d Ci%d L%d flop%d" % (x.shape[0], w.shape[0], x.shape[1], x.shape[2],
+    "native_fwd": lambda x, w, sums=None: "B%d Co%d Ci%d L%d flop%d" % (x.shape[0], w.shape[0], x.shape[1], x.shape[2],
                                                              2 * x.shape[0] * w.shape[0] * x.shape[1] * x.shape[2]),
     "native_dgrad": lambda w, dy: "B%d Co%d Ci%d L%d flop%d" % (dy.shape[0], w.shape[0], w.shape[1], dy.shape[2],
                                                                 2 * dy.shape[0] * w.shape[0] * w.shape[1] * dy.shape[2]),
@@ -317,13 +347,13 @@ class _Conv1x1Padded(torch.autograd.Function):
 
 class _Conv1x1(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w):
-        """x (B, Ci, L) contiguous, w (Co, Ci) -> (B, Co, L)."""
+    def forward(ctx, x, w, sums=None):
+        """x (B, Ci, L) contiguous, w (Co, Ci) -> (B, Co, L); ``sums``: see native_fwd (the caller checked ``stats_ok``)."""
         ctx.save_for_backward(x, w)
         B, Ci, L = x.shape
         Co = w.shape[0]
         if _native_ok(B, Co, Ci, L):
-            return native_fwd(x, w.contiguous())
+            return native_fwd(x, w.contiguous(), sums)
         if NATIVE and Ci <= 8 and L % 4 == 0 and x.data_ptr() % 16 == 0:
             return native_fwd_smallci(x, w.contiguous())
         # bmm on the expanded weight, NOT torch.matmul: for (2-D, 3-D) operands matmul folds the batch by transposing the
@@ -343,12 +373,12 @@ class _Conv1x1(torch.autograd.Function):
             if ctx.needs_input_grad[1] and _native_ok(B, Co, Ci, L, wgrad=True):
                 dw = native_wgrad(dy, x)
             if dw is not None or not ctx.needs_input_grad[1]:
-                return dx, dw
+                return dx, dw, None
         else:
             dx = torch.bmm(w.t().unsqueeze(0).expand(B, -1, -1), dy) if ctx.needs_input_grad[0] else None
         dw = None
         if ctx.needs_input_grad[1] and NATIVE and Ci <= 8 and L % 4 == 0 and x.data_ptr() % 16 == 0 and dy.data_ptr() % 16 == 0:
-            return dx, native_wgrad_smallci(dy, x)
+            return dx, native_wgrad_smallci(dy, x), None
         if ctx.needs_input_grad[1]:
             S = _chunks(L, ((Co + 127) // 128) * ((Ci + 127) // 128), B)
             Ls = L // S
@@ -358,7 +388,7 @@ class _Conv1x1(torch.autograd.Function):
                 ds = dy[b].view(Co, S, Ls).transpose(0, 1)       # (S, Co, Ls)
                 torch.bmm(ds, xs, out=part[b])
             dw = part.sum((0, 1)) if B * S > 1 else part.view(Co, Ci)
-        return dx, dw
+        return dx, dw, None
 
 
 class _BnReluConv(torch.autograd.Function):
@@ -366,9 +396,9 @@ class _BnReluConv(torch.autograd.Function):
     apply, the ReLU and the convolution; [relu](bn(x)) is never stored."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, w, mean, invstd, scale, shift, relu):
+    def forward(ctx, x, gamma, beta, w, mean, invstd, scale, shift, relu, sums=None):
         w = w.contiguous()
-        y = native_fwd_bnrelu(x, w, scale, shift, relu)
+        y = native_fwd_bnrelu(x, w, scale, shift, relu, sums)
         ctx.save_for_backward(x, gamma, beta, w, mean, invstd, scale, shift)
         ctx.relu = relu
         return y
@@ -381,7 +411,7 @@ class _BnReluConv(torch.autograd.Function):
         dz = native_dgrad(w, dy)
         dw = native_wgrad_bnrelu(dy, x, scale, shift, ctx.relu) if ctx.needs_input_grad[3] else None
         dx, dgamma, dbeta = bn_train.bn_backward(x, dz, gamma, beta, mean, invstd, ctx.relu)
-        return dx, dgamma, dbeta, dw, None, None, None, None, None
+        return dx, dgamma, dbeta, dw, None, None, None, None, None, None
 
 
 def pending_ok(conv, x):
@@ -393,29 +423,44 @@ def pending_ok(conv, x):
     return bool(_lib.lib.regnet_conv1x1_bnrelu_supported(conv.weight.shape[0], Ci, x.numel() // max(B * Ci, 1)))
 
 
-def conv1x1_of_pending(conv, pending, shape):
+def _with_sums(y, sums):
+    """Hands the statistics a convolution left (``sums``) to the BatchNorm that consumes its output: an attribute of the very
+    tensor object the block passes on (bn_train.bn_stats / bn_relu look for it)."""
+    if sums is not None:
+        y._bn_sums = sums
+    return y
+
+
+def conv1x1_of_pending(conv, pending, shape, stats=False):
     """``conv([relu](bn(x)))`` for a bn_train.Pending of that BatchNorm; ``shape``: of x as the stack sees it ((B,C,N) or
-    (B,C,N,K)); check ``pending_ok`` first."""
+    (B,C,N,K)); check ``pending_ok`` first.  ``stats``: a training BatchNorm follows -- leave its statistics with the output."""
     B, Ci = shape[0], shape[1]
     Co = conv.weight.shape[0]
     DEFERRED["layers"] += 1
-    y = _BnReluConv.apply(pending.x.view(B, Ci, -1), pending.gamma, pending.beta, conv.weight.view(Co, Ci), pending.mean,
-                          pending.invstd, pending.scale, pending.shift, pending.relu)
-    return y.view(B, Co, *shape[2:])
+    x = pending.x.view(B, Ci, -1)
+    sums = new_sums(Co, x.device) if stats and stats_ok(Co, Ci, x.shape[2], affine=True) else None
+    y = _BnReluConv.apply(x, pending.gamma, pending.beta, conv.weight.view(Co, Ci), pending.mean,
+                          pending.invstd, pending.scale, pending.shift, pending.relu, sums)
+    return _with_sums(y.view(B, Co, *shape[2:]), sums)
 
 
-def gemm_conv(x, w):
-    """x (B, Ci, L) contiguous, w (Co, Ci) -> (B, Co, L): the autograd GEMM convolution itself."""
+def gemm_conv(x, w, sums=None):
+    """x (B, Ci, L) contiguous, w (Co, Ci) -> (B, Co, L): the autograd GEMM convolution itself (``sums``: see native_fwd; only
+    with a native, unpadded shape that ``stats_ok`` accepts)."""
     B, Ci, L = x.shape
     Cip = _padded_channels(B, w.shape[0], Ci, L) if x.is_cuda and not _native_ok(B, w.shape[0], Ci, L) else 0
     if Cip:
         return _Conv1x1Padded.apply(x, w, Cip)
-    return _Conv1x1.apply(x, w)
+    return _Conv1x1.apply(x, w, sums)
 
 
-def conv1x1(conv, x):
-    """``conv(x)`` for a bias-free kernel-size-1 Conv1d / Conv2d; check ``supported`` first."""
+def conv1x1(conv, x, stats=False):
+    """``conv(x)`` for a bias-free kernel-size-1 Conv1d / Conv2d; check ``supported`` first.  ``stats``: a training BatchNorm
+    follows -- leave its statistics with the output where the kernel can."""
     B, Ci = x.shape[0], x.shape[1]
     Co = conv.weight.shape[0]
-    y = gemm_conv(x.contiguous().view(B, Ci, -1), conv.weight.view(Co, Ci))
-    return y.view(B, Co, *x.shape[2:])
+    xf = x.contiguous().view(B, Ci, -1)
+    L = xf.shape[2]
+    sums = new_sums(Co, x.device) if stats and x.is_cuda and _native_ok(B, Co, Ci, L) and stats_ok(Co, Ci, L) else None
+    y = gemm_conv(xf, conv.weight.view(Co, Ci), sums)
+    return _with_sums(y.view(B, Co, *x.shape[2:]), sums)

@@ -304,10 +304,10 @@ static inline bool bn_dims_ok(int64_t B, int64_t C, int64_t L) {
 
 extern "C" int64_t regnet_bn_workspace_bytes(int64_t C) { return C > 0 ? C * 2 * (int64_t)sizeof(double) : 0; }
 
-extern "C" int regnet_bn_relu_train_fwd_f32(const float* x, int64_t B, int64_t C, int64_t L, const float* gamma,
-                                            const float* beta, float eps, float momentum, float* running_mean,
-                                            float* running_var, int relu, int64_t pool_group, float* y, int32_t* pool_index,
-                                            float* save_mean, float* save_invstd, void* workspace, void* stream) {
+static int bn_relu_train_fwd(const float* x, int64_t B, int64_t C, int64_t L, const float* gamma,
+                             const float* beta, float eps, float momentum, float* running_mean,
+                             float* running_var, int relu, int64_t pool_group, float* y, int32_t* pool_index,
+                             float* save_mean, float* save_invstd, void* workspace, void* stream, bool sums_ready) {
   if (B < 0 || C < 0 || L < 0 || pool_group < 0) return REGNET_ERR_SHAPE;
   if (B == 0 || C == 0 || L == 0) return REGNET_OK;
   if (!x || !gamma || !beta || !y || !save_mean || !save_invstd || !workspace || (pool_group && !pool_index))
@@ -315,11 +315,13 @@ extern "C" int regnet_bn_relu_train_fwd_f32(const float* x, int64_t B, int64_t C
   if (!bn_dims_ok(B, C, L) || (pool_group && !pool_ok(L, pool_group))) return REGNET_ERR_UNSUPPORTED;
   hipStream_t st = as_stream(stream);
   double* sums = static_cast<double*>(workspace);
-  hipError_t e = hipMemsetAsync(sums, 0, regnet_bn_workspace_bytes(C), st);
-  if (e != hipSuccess) return (int)e;
   dim3 grid((unsigned)((L + BN_CHUNK - 1) / BN_CHUNK), (unsigned)C, (unsigned)B);
-  hipLaunchKernelGGL(bn_stats_kernel, dim3((unsigned)((L + BN_STATS_CHUNK - 1) / BN_STATS_CHUNK), (unsigned)C, (unsigned)B), dim3(BN_T), 0, st,
-                     x, (int)C, L, sums);
+  if (!sums_ready) {
+    hipError_t e = hipMemsetAsync(sums, 0, regnet_bn_workspace_bytes(C), st);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(bn_stats_kernel, dim3((unsigned)((L + BN_STATS_CHUNK - 1) / BN_STATS_CHUNK), (unsigned)C, (unsigned)B), dim3(BN_T), 0, st,
+                       x, (int)C, L, sums);
+  }
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((C + 127) / 128)), dim3(128), 0, st, sums, (double)B * (double)L,
                      eps, momentum, (int)C, running_mean, running_var, save_mean, save_invstd);
   if (pool_group)
@@ -329,6 +331,25 @@ extern "C" int regnet_bn_relu_train_fwd_f32(const float* x, int64_t B, int64_t C
     hipLaunchKernelGGL(bn_apply_kernel, grid, dim3(BN_T), 0, st, x, (int)C, L, gamma, beta, save_mean, save_invstd, relu, y);
   REGNET_LAUNCH_CHECK();
   return REGNET_OK;
+}
+
+extern "C" int regnet_bn_relu_train_fwd_f32(const float* x, int64_t B, int64_t C, int64_t L, const float* gamma,
+                                            const float* beta, float eps, float momentum, float* running_mean,
+                                            float* running_var, int relu, int64_t pool_group, float* y, int32_t* pool_index,
+                                            float* save_mean, float* save_invstd, void* workspace, void* stream) {
+  return bn_relu_train_fwd(x, B, C, L, gamma, beta, eps, momentum, running_mean, running_var, relu, pool_group, y, pool_index,
+                           save_mean, save_invstd, workspace, stream, false);
+}
+
+// ... with the statistics pass already done: `workspace` holds the per-channel (sum, sum of squares) of x over all B L elements as
+// regnet_conv1x1_fwd_stats_stream_f32, the convolution that produced x, left them
+extern "C" int regnet_bn_relu_train_fwd_from_sums_f32(const float* x, int64_t B, int64_t C, int64_t L, const float* gamma,
+                                                      const float* beta, float eps, float momentum, float* running_mean,
+                                                      float* running_var, int relu, int64_t pool_group, float* y,
+                                                      int32_t* pool_index, float* save_mean, float* save_invstd, void* workspace,
+                                                      void* stream) {
+  return bn_relu_train_fwd(x, B, C, L, gamma, beta, eps, momentum, running_mean, running_var, relu, pool_group, y, pool_index,
+                           save_mean, save_invstd, workspace, stream, true);
 }
 
 extern "C" int regnet_bn_relu_train_bwd_f32(const float* x, const float* y, const float* dy, const int32_t* pool_index,
@@ -368,22 +389,39 @@ extern "C" int regnet_bn_relu_train_bwd_f32(const float* x, const float* y, cons
 // The statistics half of the forward alone: batch mean / inverse std (+ running statistics), and the normalisation as a
 // per-channel affine (scale = gamma * invstd, shift = beta - mean * scale) for a consumer that applies it itself
 // (regnet_conv1x1_fwd_bnrelu_stream_f32 / regnet_conv1x1_wgrad_bnrelu_f32): the normalised activation is never written.
-extern "C" int regnet_bn_train_stats_f32(const float* x, int64_t B, int64_t C, int64_t L, const float* gamma, const float* beta,
-                                         float eps, float momentum, float* running_mean, float* running_var, float* save_mean,
-                                         float* save_invstd, float* scale, float* shift, void* workspace, void* stream) {
+static int bn_train_stats(const float* x, int64_t B, int64_t C, int64_t L, const float* gamma, const float* beta,
+                          float eps, float momentum, float* running_mean, float* running_var, float* save_mean,
+                          float* save_invstd, float* scale, float* shift, void* workspace, void* stream) {
   if (B < 0 || C < 0 || L < 0) return REGNET_ERR_SHAPE;
   if (B == 0 || C == 0 || L == 0) return REGNET_OK;
-  if (!x || !gamma || !beta || !save_mean || !save_invstd || !scale || !shift || !workspace) return REGNET_ERR_NULL;
+  if (!gamma || !beta || !save_mean || !save_invstd || !scale || !shift || !workspace) return REGNET_ERR_NULL;
   if (!bn_dims_ok(B, C, L)) return REGNET_ERR_UNSUPPORTED;
   hipStream_t st = as_stream(stream);
   double* sums = static_cast<double*>(workspace);
-  hipError_t e = hipMemsetAsync(sums, 0, regnet_bn_workspace_bytes(C), st);
-  if (e != hipSuccess) return (int)e;
-  dim3 grid((unsigned)((L + BN_CHUNK - 1) / BN_CHUNK), (unsigned)C, (unsigned)B);
-  hipLaunchKernelGGL(bn_stats_kernel, dim3((unsigned)((L + BN_STATS_CHUNK - 1) / BN_STATS_CHUNK), (unsigned)C, (unsigned)B), dim3(BN_T), 0, st,
-                     x, (int)C, L, sums);
+  if (x) {      // x == NULL: `workspace` already holds the sums
+    hipError_t e = hipMemsetAsync(sums, 0, regnet_bn_workspace_bytes(C), st);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(bn_stats_kernel, dim3((unsigned)((L + BN_STATS_CHUNK - 1) / BN_STATS_CHUNK), (unsigned)C, (unsigned)B), dim3(BN_T), 0, st,
+                       x, (int)C, L, sums);
+  }
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((C + 127) / 128)), dim3(128), 0, st, sums, (double)B * (double)L,
                      eps, momentum, (int)C, running_mean, running_var, save_mean, save_invstd, gamma, beta, scale, shift);
   REGNET_LAUNCH_CHECK();
   return REGNET_OK;
+}
+
+extern "C" int regnet_bn_train_stats_f32(const float* x, int64_t B, int64_t C, int64_t L, const float* gamma, const float* beta,
+                                         float eps, float momentum, float* running_mean, float* running_var, float* save_mean,
+                                         float* save_invstd, float* scale, float* shift, void* workspace, void* stream) {
+  if (!x && B > 0 && C > 0 && L > 0) return REGNET_ERR_NULL;
+  return bn_train_stats(x, B, C, L, gamma, beta, eps, momentum, running_mean, running_var, save_mean, save_invstd, scale, shift,
+                        workspace, stream);
+}
+
+// ... from per-channel (sum, sum of squares) already in `workspace` (regnet_conv1x1_fwd_stats_stream_f32): the finalize step alone
+extern "C" int regnet_bn_train_stats_from_sums_f32(int64_t B, int64_t C, int64_t L, const float* gamma, const float* beta, float eps,
+                                                   float momentum, float* running_mean, float* running_var, float* save_mean,
+                                                   float* save_invstd, float* scale, float* shift, void* workspace, void* stream) {
+  return bn_train_stats(nullptr, B, C, L, gamma, beta, eps, momentum, running_mean, running_var, save_mean, save_invstd, scale,
+                        shift, workspace, stream);
 }

@@ -50,6 +50,9 @@ struct TgArgs {
   // B_AFFINE: the B operand is used as max(bscale[c] * x + bshift[c], brelu ? 0 : -inf), c = its channel -- the BatchNorm (+ ReLU)
   // between two convolutions of a shared-MLP block applied on the fragment, so that its output is never written (see the ABI)
   const float* bscale; const float* bshift; int brelu;
+  // STATS (tgemm_stream_kernel, forward): per-channel sums of the OUTPUT over all points, sum at stat[2 c], sum of squares at
+  // stat[2 c + 1] (fp64, zeroed by the caller) -- the statistics pass of the training BatchNorm that follows the convolution
+  double* stat;
 };
 
 __device__ __forceinline__ void tg_glds16(const float* gsrc, unsigned lds_dst) {
@@ -251,13 +254,33 @@ __device__ __forceinline__ int tg_ticket_nowait(int* p) {
   return r;
 }
 
+// v + (v of the lane CTRL names within the row of 16; 0 where there is none): one v_add_f32 with a DPP operand
+template <int CTRL> __device__ __forceinline__ float tg_dpp_add(float v) {
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+// the sum over the 32 lanes of a lane half (lanes 0-31 / 32-63), valid in lanes 16-31 / 48-63
+__device__ __forceinline__ float tg_half_sum(float v) {
+  v = tg_dpp_add<0xB1>(v);        // quad_perm [1,0,3,2]
+  v = tg_dpp_add<0x4E>(v);        // quad_perm [2,3,0,1]
+  v = tg_dpp_add<0x141>(v);       // row_half_mirror
+  v = tg_dpp_add<0x140>(v);       // row_mirror: every lane of a row of 16 holds the row's sum
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xa, 0xf, false));   // row_bcast:15 into rows 1, 3
+}
+#define TG_STAT_MAXM 256        // STATS: output channels whose fp64 sums fit the workgroup's LDS table beside the ring
+#define TG_STAT_AFF_MAXK 256    // ... and input channels of a B_AFFINE operand then
+
 // C[M x N] = A[M x K] . B[K x N] per batch with B k-major (the activations / output gradients, points contiguous) and A the
 // weights, row (forward) or k-major (input gradient): tile 128 x 256 x 16 as tgemm_kernel, but persistent -- workgroup w
 // starts with tile w and draws further tiles from a ticket counter (channel tile fastest: the tiles sharing an activation
 // panel run at the same time), treating their k-tiles as ONE sequence through the 3-stage ring.  Tickets, not a fixed
 // stride: in the training iteration the next batch's sampling holds eight CUs for 4 ms at a time; a workgroup that cannot
 // start there must not own tiles (measured with a fixed stride: 5 % faster on an idle chip, 3 % slower in the iteration).
-template <bool A_KMAJ, bool B_AFFINE = false>
+//
+// STATS (forward): the per-channel sum and sum of squares of the output -- the statistics pass of the BatchNorm that follows -- are
+// taken from the accumulators (a lane holds 32 channels of two points: two in-lane adds, a DPP tree over the 32 lanes of a lane
+// half, 64 LDS atomics per wave and tile into an fp64 table, one fp64 global atomic per channel and workgroup at the end), so that
+// the output is not read again (bn_stats_kernel: 1 read of up to 2.7 GB per layer).
+template <bool A_KMAJ, bool B_AFFINE = false, bool STATS = false>
 __global__ __launch_bounds__(TG_THREADS, 4) void tgemm_stream_kernel(const TgArgs p) {
   constexpr int TG_BN = 256, TNI = 2, WN_COLS = 64, NPIECE = 3;
   constexpr int TG_STAGE_FLOATS = (TG_BM + TG_BN) * TG_BK;
@@ -271,11 +294,15 @@ __global__ __launch_bounds__(TG_THREADS, 4) void tgemm_stream_kernel(const TgArg
   const int G = gridDim.x, bid = blockIdx.x;
   if (bid >= total) return;
   __shared__ long long s_next[2];                                 // tiles drawn from the counter, by parity of their number
-  __shared__ __attribute__((aligned(16))) float btab[B_AFFINE ? 2 * TG_AFF_MAXK : 4];   // B_AFFINE: (scale, shift) per channel of K
+  __shared__ __attribute__((aligned(16))) float btab[B_AFFINE ? 2 * (STATS ? TG_STAT_AFF_MAXK : TG_AFF_MAXK) : 4];   // B_AFFINE: (scale, shift) per channel of K
+  __shared__ double stab[STATS ? 2 * TG_STAT_MAXM : 1];
   if (B_AFFINE) {
     for (int i = tid; i < p.K; i += TG_THREADS) { btab[2 * i] = p.bscale[i]; btab[2 * i + 1] = p.bshift[i]; }
-    __syncthreads();
   }
+  if (STATS) {
+    for (int i = tid; i < 2 * p.M; i += TG_THREADS) stab[i] = 0.0;
+  }
+  if (B_AFFINE || STATS) __syncthreads();
   const float blo = (B_AFFINE && !p.brelu) ? -INFINITY : 0.f;
   const int KT = p.K / TG_BK;                                     // >= 2 (launcher)
 
@@ -407,8 +434,12 @@ __global__ __launch_bounds__(TG_THREADS, 4) void tgemm_stream_kernel(const TgArg
             for (int t = 0; t < 4; ++t) b[kk][ni][t] = st[kmB + (8 * kk + t) * TG_BN + 32 * ni];
           }
           if (B_AFFINE) {      // fragment element t is channel 16 kt + 8 kk + 4 fh + t of the operand
-            const float4 c01 = *reinterpret_cast<const float4*>(&btab[2 * (TG_BK * kt + 8 * kk + 4 * fh)]);
-            const float4 c23 = *reinterpret_cast<const float4*>(&btab[2 * (TG_BK * kt + 8 * kk + 4 * fh) + 4]);
+            int fhb = fh;
+            if (STATS) {       // (this instantiation has no register left for the table address: made here, from the hardware's lane number)
+              asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0\n\tv_lshrrev_b32 %0, 5, %0" : "=v"(fhb));
+            }
+            const float4 c01 = *reinterpret_cast<const float4*>(&btab[2 * (TG_BK * kt + 8 * kk + 4 * fhb)]);
+            const float4 c23 = *reinterpret_cast<const float4*>(&btab[2 * (TG_BK * kt + 8 * kk + 4 * fhb) + 4]);
 #pragma unroll
             for (int ni = 0; ni < TNI; ++ni) {
               b[kk][ni][0] = fmaxf(fmaf(b[kk][ni][0], c01.x, c01.y), blo);
@@ -439,6 +470,26 @@ __global__ __launch_bounds__(TG_THREADS, 4) void tgemm_stream_kernel(const TgArg
       const int tn = r0 / p.tiles_m, tm = r0 - tn * p.tiles_m;
       const int m0 = tm * TG_BM, n0 = tn * TG_BN;
       float* Cb = p.C + batch * p.c_batch;
+      if (STATS) {      // (in FRONT of the stores: behind them the allocator spills 48 registers, some inside the k loop)
+        int ln;      // the lane number again, from the hardware: no address of this block is to be kept in a register across the k loop
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+        const int fr_ = ln & 31, fh_ = ln >> 5;
+        const float ok0 = n0 + wn * WN_COLS + fr_ < p.N ? 1.f : 0.f, ok1 = n0 + wn * WN_COLS + 32 + fr_ < p.N ? 1.f : 0.f;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+          const int row0 = m0 + wm * 64 + mi * 32 + 4 * fh_;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float a0 = acc[mi][0][r] * ok0, a1 = acc[mi][1][r] * ok1;
+            const float sv = tg_half_sum(a0 + a1), qv = tg_half_sum(a0 * a0 + a1 * a1);
+            const int row = row0 + (r & 3) + 8 * (r >> 2);
+            if (fr_ == 16 && row < p.M) {
+              unsafeAtomicAdd(&stab[2 * row], (double)sv);
+              unsafeAtomicAdd(&stab[2 * row + 1], (double)qv);
+            }
+          }
+        }
+      }
 #pragma unroll
       for (int ni = 0; ni < TNI; ++ni) {
         const int col = n0 + wn * WN_COLS + ni * 32 + fr;
@@ -458,6 +509,10 @@ __global__ __launch_bounds__(TG_THREADS, 4) void tgemm_stream_kernel(const TgArg
     }
     cur_t = next_t;
     next_t = -1;
+  }
+  if (STATS) {
+    __syncthreads();
+    for (int i = tid; i < 2 * p.M; i += TG_THREADS) unsafeAtomicAdd(&p.stat[i], stab[i]);
   }
 }
 
@@ -497,7 +552,7 @@ extern "C" int regnet_conv1x1_stream_reserve_slots(int slots) {
   return before;
 }
 
-template <bool A_KMAJ, bool B_AFFINE = false>
+template <bool A_KMAJ, bool B_AFFINE = false, bool STATS = false>
 static int tg_launch_stream(TgArgs a, long long batches, int32_t* ticket, hipStream_t st) {
   a.tiles_m = (a.M + TG_BM - 1) / TG_BM;
   a.tiles_n = (a.N + 255) / 256;
@@ -517,7 +572,7 @@ static int tg_launch_stream(TgArgs a, long long batches, int32_t* ticket, hipStr
   }
   const long long open_slots = slots - tg_reserved_slots > slots / 2 ? slots - tg_reserved_slots : slots / 2;
   const unsigned grid = (unsigned)(total < open_slots ? total : open_slots);
-  hipLaunchKernelGGL((tgemm_stream_kernel<A_KMAJ, B_AFFINE>), dim3(grid), dim3(TG_THREADS), 0, st, a);
+  hipLaunchKernelGGL((tgemm_stream_kernel<A_KMAJ, B_AFFINE, STATS>), dim3(grid), dim3(TG_THREADS), 0, st, a);
   REGNET_LAUNCH_CHECK();
   return REGNET_OK;
 }
@@ -768,6 +823,36 @@ extern "C" int regnet_conv1x1_fwd_bnrelu_stream_f32(const float* W, const float*
   a.M = (int)Co; a.N = (int)L; a.K = (int)Ci; a.slices = 1;
   a.bscale = scale; a.bshift = shift; a.brelu = relu;
   return tg_launch_stream<false, true>(a, B, ticket, as_stream(stream));
+}
+
+// The forward with the statistics pass of the BatchNorm that FOLLOWS the convolution taken from the accumulators (STATS): `sums` (2 Co
+// doubles: sum, sum of squares per output channel over all B L points) is zeroed and filled by this call;
+// regnet_bn_train_stats_from_sums_f32 / regnet_bn_relu_train_fwd_from_sums_f32 (bn_train.hip) continue from it.  scale == NULL: the plain
+// forward; otherwise the operand's own BatchNorm (+ ReLU) is applied on the fragment as regnet_conv1x1_fwd_bnrelu_stream_f32 does.
+extern "C" int regnet_conv1x1_fwd_stats_supported(int64_t Co, int64_t Ci, int64_t L, int affine) {
+  if (!regnet_conv1x1_train_supported(Co, Ci, L) || Co > TG_STAT_MAXM) return 0;
+  return affine ? (Ci <= TG_STAT_AFF_MAXK && (L % 16) == 0) : 1;
+}
+
+extern "C" int regnet_conv1x1_fwd_stats_stream_f32(const float* W, const float* X, float* Y, int64_t B, int64_t Co, int64_t Ci,
+                                                   int64_t L, const float* scale, const float* shift, int relu, int32_t* ticket,
+                                                   void* sums, void* stream) {
+  if (B < 0 || !regnet_conv1x1_fwd_stats_supported(Co, Ci, L, scale != nullptr)) return REGNET_ERR_SHAPE;
+  if (B == 0) return REGNET_OK;
+  if (!W || !X || !Y || !ticket || !sums || (scale && !shift)) return REGNET_ERR_NULL;
+  if (!tg_aligned16(W) || !tg_aligned16(X) || !tg_aligned16(Y) || (reinterpret_cast<uintptr_t>(sums) & 7)) return REGNET_ERR_SHAPE;
+  hipStream_t st = as_stream(stream);
+  hipError_t e = hipMemsetAsync(sums, 0, (size_t)Co * 2 * sizeof(double), st);
+  if (e != hipSuccess) return (int)e;
+  TgArgs a = {};
+  a.A = W; a.lda = Ci;
+  a.B = X; a.ldb = L; a.b_batch = Ci * L;
+  a.C = Y; a.ldc = L; a.c_batch = Co * L;
+  a.M = (int)Co; a.N = (int)L; a.K = (int)Ci; a.slices = 1;
+  a.stat = static_cast<double*>(sums);
+  if (!scale) return tg_launch_stream<false, false, true>(a, B, ticket, st);
+  a.bscale = scale; a.bshift = shift; a.brelu = relu;
+  return tg_launch_stream<false, true, true>(a, B, ticket, st);
 }
 
 static int tg_dgrad(const float* W, const float* dY, float* dX, int64_t B, int64_t Co, int64_t Ci, int64_t L, int32_t* ticket,

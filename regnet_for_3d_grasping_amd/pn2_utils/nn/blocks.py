@@ -32,7 +32,9 @@ class _AffineBNReLU(nn.Module):
         affine = getattr(self, self._affine_name)
         if self.training and x.is_cuda and self._affine_name == "conv":
             from ... import conv1x1_train
-            return conv1x1_train.conv1x1(affine, x) if conv1x1_train.supported(affine, x) else affine(x)
+            if conv1x1_train.supported(affine, x):      # (a training BatchNorm follows: its statistics come with the output)
+                return conv1x1_train.conv1x1(affine, x, stats=self.bn is not None)
+            return affine(x)
         return affine(x)
 
     def after_affine(self, x, pool_max=False):
@@ -107,7 +109,7 @@ class _Stack(nn.ModuleList):
             fuse = pool_max and i == last and not dropout
             if pending is not None:
                 from ... import conv1x1_train
-                x = conv1x1_train.conv1x1_of_pending(block.conv, pending[0], pending[1])
+                x = conv1x1_train.conv1x1_of_pending(block.conv, pending[0], pending[1], stats=block.bn is not None)
                 pending = None
             elif not (i == 0 and first_affine_done):
                 x = block.affine_only(x)

@@ -156,6 +156,42 @@ def test_deferred_batchnorm_between_convolutions(shape, channels, pool, deferred
         _close(p.float(), q.float(), 1e-5), _close(p.float(), r.float(), 1e-5)
 
 
+@pytest.mark.parametrize("B,Co,Ci,L,affine", [
+    (2, 128, 128, 19200, False),      # the level-1 block's second layer, scaled down
+    (2, 256, 128, 19200, True),       # its third: two channel tiles, operand with its own BatchNorm + ReLU
+    (3, 160, 64, 4112, True),         # a partial channel tile, L % 256 = 16
+    (1, 64, 256, 1000, False),        # L % 16 != 0 (plain forward only), ragged last point tile
+    (8, 128, 32, 2048 * 64, False)])  # many tiles per workgroup: the fp64 LDS table accumulates ~40 of them
+def test_statistics_left_by_the_convolution(B, Co, Ci, L, affine):
+    """conv1x1_train.FUSE_STATS (csrc/tgemm.hip STATS): the per-channel sum / sum of squares of a convolution's output, taken
+    from its output tiles, against a float64 evaluation -- and the output itself unchanged."""
+    from regnet_for_3d_grasping_amd import conv1x1_train as ct
+    torch.manual_seed(B + Co + L)
+    x = torch.randn((B, Ci, L), device=DEV) * 1.5 + 0.4
+    w = torch.randn((Co, Ci), device=DEV) / Ci ** 0.5
+    assert ct.stats_ok(Co, Ci, L, affine)
+    sums = ct.new_sums(Co, DEV)
+    if affine:
+        scale, shift = torch.rand(Ci, device=DEV) + 0.5, torch.randn(Ci, device=DEV) * 0.3
+        y = ct.native_fwd_bnrelu(x, w, scale, shift, 1, sums)
+        y0 = ct.native_fwd_bnrelu(x, w, scale, shift, 1)
+        a = torch.relu(x.double() * scale.double()[None, :, None] + shift.double()[None, :, None])
+    else:
+        y, y0, a = ct.native_fwd(x, w, sums), ct.native_fwd(x, w), x.double()
+    assert torch.equal(y, y0)
+    ref = torch.einsum("oi,bil->bol", w.double(), a)
+    n = B * L
+    s_ref, q_ref = ref.sum((0, 2)), (ref * ref).sum((0, 2))
+    s, q = sums[0::2], sums[1::2]
+    # the kernel sums ITS fp32 outputs: against the float64 sums of those the error is the summation's alone
+    s_own, q_own = y.double().sum((0, 2)), (y.double() ** 2).sum((0, 2))
+    assert float(((s - s_own).abs() / (q_own * n).sqrt()).max()) < 2e-7
+    assert float(((q - q_own).abs() / q_own).max()) < 2e-7
+    mean, var = s / n, q / n - (s / n) ** 2
+    mean_ref, var_ref = s_ref / n, q_ref / n - (s_ref / n) ** 2
+    assert float((mean - mean_ref).abs().max()) < 1e-5 and float(((var - var_ref).abs() / var_ref).max()) < 1e-4
+
+
 def test_unsupported_inputs_are_rejected_not_silently_wrong():
     from regnet_for_3d_grasping_amd import bn_train
     bn = nn.BatchNorm1d(4).to(DEV).train()

@@ -116,8 +116,11 @@ def test_replayed_training_follows_the_eager_trajectory():
     # discrete choices): what can be asked of a replayed run is that it stays in that envelope
     for it, (a, b) in enumerate(zip(le, lg)):
         assert abs(a[1] - b[1]) <= (1e-4 if it < 2 else 2e-2) * abs(a[1]), ("score loss", it, a, b)
-        if it < 2:     # (both runs eager)
+        if it == 0:    # (both runs eager, same weights)
             assert abs(a[0] - b[0]) <= 1e-3 * abs(a[0]), ("total loss", it, a, b)
+        elif it == 1:  # (both eager, one Adam step in: the score loss still agrees to 1e-4, but one centre changing class under
+            #  the first step's rounding moves the region losses by a discrete 0.8 % -- seen in 3 of 10 runs of this seed)
+            assert abs(a[0] - b[0]) <= 2e-2 * abs(a[0]), ("total loss", it, a, b)
         else:
             assert abs(a[0] - b[0]) <= 0.25 * abs(a[0]), ("total loss", it, a, b)
     for k in se:
