@@ -616,6 +616,12 @@ int regnet_conv1x1_dgrad_stream_f32(const float* W, const float* dY, float* dX, 
  * channel.  L % 4 == 0, X and Y 16-byte aligned, any Co.                                                                */
 int regnet_conv1x1_fwd_smallci_f32(const float* W, const float* X, float* Y, int64_t B, int64_t Co, int64_t Ci, int64_t L,
                                    void* stream);
+/* ..._stats: the same, also leaving sums (2 Co doubles, as regnet_conv1x1_fwd_stats_stream_f32 below) for the BatchNorm that follows.
+ * Y = W X is linear in <= 8 inputs: the sums follow from the first and second moments of X (Ci + Ci (Ci + 1) / 2 numbers, fp64
+ * above 256 points), Y is not read.  workspace: regnet_conv1x1_smallci_stats_workspace_bytes(B, Ci, L) bytes, 8-byte aligned. */
+int64_t regnet_conv1x1_smallci_stats_workspace_bytes(int64_t B, int64_t Ci, int64_t L);
+int regnet_conv1x1_fwd_smallci_stats_f32(const float* W, const float* X, float* Y, int64_t B, int64_t Co, int64_t Ci, int64_t L,
+                                         void* workspace, void* sums, void* stream);
 /* ... and their weight gradient: dW = sum over part's first axis, part (regnet_conv1x1_wgrad_smallci_partials(B, Co, L), Co, Ci)
  * written by the call (one partial matrix per scene and slice of the point axis; the caller's sum fixes the order).     */
 int64_t regnet_conv1x1_wgrad_smallci_partials(int64_t B, int64_t Co, int64_t L);

@@ -118,6 +118,8 @@ SIGNATURES = {
     "regnet_conv1x1_fwd_stream_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
     "regnet_conv1x1_dgrad_stream_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
     "regnet_conv1x1_fwd_smallci_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp]),
+    "regnet_conv1x1_smallci_stats_workspace_bytes": (_i64, [_i64, _i64, _i64]),
+    "regnet_conv1x1_fwd_smallci_stats_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp]),
     "regnet_conv1x1_wgrad_smallci_partials": (_i64, [_i64, _i64, _i64]),
     "regnet_conv1x1_wgrad_smallci_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp]),
     "regnet_conv1x1_smallco_f32": (_int, [_int, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp]),

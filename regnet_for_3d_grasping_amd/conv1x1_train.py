@@ -220,13 +220,25 @@ def _chunks(L, tiles, B):
     return s
 
 
-def native_fwd_smallci(x, w):
-    """x (B, Ci <= 8, L) contiguous, w (Co, Ci) contiguous -> Y (B, Co, L): a store stream (csrc/tgemm.hip: conv_smallci_kernel)."""
+def _smallci_ok(x, Ci, L):
+    return NATIVE and Ci <= 8 and L % 4 == 0 and x.data_ptr() % 16 == 0
+
+
+def native_fwd_smallci(x, w, sums=None):
+    """x (B, Ci <= 8, L) contiguous, w (Co, Ci) contiguous -> Y (B, Co, L): a store stream (csrc/tgemm.hip: conv_smallci_kernel).
+    ``sums`` (2 Co float64): filled with the per-channel sum / sum of squares of Y, from the input's moments."""
     from . import _lib
     B, Ci, L = x.shape
     Co = w.shape[0]
     y = torch.empty((B, Co, L), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
+        if sums is not None:
+            ws = torch.empty((_lib.lib.regnet_conv1x1_smallci_stats_workspace_bytes(B, Ci, L) // 8,), dtype=torch.float64,
+                             device=x.device)
+            _lib.check(_lib.lib.regnet_conv1x1_fwd_smallci_stats_f32(w.data_ptr(), x.data_ptr(), y.data_ptr(), B, Co, Ci, L,
+                                                                     ws.data_ptr(), sums.data_ptr(), _stream(x)),
+                       "conv1x1_fwd_smallci_stats")
+            return y
         _lib.check(_lib.lib.regnet_conv1x1_fwd_smallci_f32(w.data_ptr(), x.data_ptr(), y.data_ptr(), B, Co, Ci, L, _stream(x)),
                    "conv1x1_fwd_smallci")
     return y
@@ -354,8 +366,8 @@ class _Conv1x1(torch.autograd.Function):
         Co = w.shape[0]
         if _native_ok(B, Co, Ci, L):
             return native_fwd(x, w.contiguous(), sums)
-        if NATIVE and Ci <= 8 and L % 4 == 0 and x.data_ptr() % 16 == 0:
-            return native_fwd_smallci(x, w.contiguous())
+        if _smallci_ok(x, Ci, L):
+            return native_fwd_smallci(x, w.contiguous(), sums)
         # bmm on the expanded weight, NOT torch.matmul: for (2-D, 3-D) operands matmul folds the batch by transposing the
         # activation -- a full copy each way
         return torch.bmm(w.unsqueeze(0).expand(x.shape[0], -1, -1), x)
@@ -461,6 +473,11 @@ def conv1x1(conv, x, stats=False):
     Co = conv.weight.shape[0]
     xf = x.contiguous().view(B, Ci, -1)
     L = xf.shape[2]
-    sums = new_sums(Co, x.device) if stats and x.is_cuda and _native_ok(B, Co, Ci, L) and stats_ok(Co, Ci, L) else None
+    sums = None
+    if stats and x.is_cuda and FUSE_STATS:
+        if _native_ok(B, Co, Ci, L):
+            sums = new_sums(Co, x.device) if stats_ok(Co, Ci, L) else None
+        elif _smallci_ok(xf, Ci, L) and not _padded_channels(B, Co, Ci, L):
+            sums = new_sums(Co, x.device)      # (a handful of input channels: from the input's moments, native_fwd_smallci)
     y = gemm_conv(xf, conv.weight.view(Co, Ci), sums)
     return _with_sums(y.view(B, Co, *x.shape[2:]), sums)

@@ -581,16 +581,48 @@ static int tg_launch_stream(TgArgs a, long long batches, int32_t* ticket, hipStr
 // over 8 x 327 680 points, nn/modules/conv.py:60-76): 4 GFLOP against a 1.3 GB output -- a store stream, not a contraction.  A
 // thread keeps four consecutive points of every input channel in registers and writes one float4 per output channel (a wave: 1 KB
 // runs); the weights are wave-uniform scalar loads.  rocBLAS took 0.64 ms for it (2.1 TB/s).
-template <int CI>
+//
+// STATS: the statistics of the BatchNorm that follows, WITHOUT touching the output: y = W x is linear in CI <= 8 inputs, so
+//   sum_p y_c = w_c . (sum_p x_p),     sum_p y_c^2 = w_c^T (sum_p x_p x_p^T) w_c
+// -- the CI sums and CI (CI + 1) / 2 second moments of the INPUT (27 numbers for CI = 6, from the registers the kernel holds anyway:
+// fp32 over a wave's 256 points, fp64 from there on, one partial vector per workgroup, no atomics) give every output channel's
+// pair in fp64 (smallci_stats_finalize_kernel).
+#define SMALLCI_NG(CI) ((CI) + (CI) * ((CI) + 1) / 2)
+template <int CI, bool STATS>
 __global__ __launch_bounds__(256) void conv_smallci_kernel(const float* __restrict__ W, const float* __restrict__ X,
-                                                          float* __restrict__ Y, int Co, long long L) {
+                                                          float* __restrict__ Y, int Co, long long L, double* __restrict__ partials) {
   const long long l = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
-  if (l >= L) return;
+  const bool live = l < L;
+  if (!STATS && !live) return;
   const float* x = X + (long long)blockIdx.y * CI * L + l;
   float* y = Y + (long long)blockIdx.y * Co * L + l;
   float4 v[CI];
 #pragma unroll
-  for (int i = 0; i < CI; ++i) v[i] = *reinterpret_cast<const float4*>(x + (long long)i * L);
+  for (int i = 0; i < CI; ++i) v[i] = live ? *reinterpret_cast<const float4*>(x + (long long)i * L) : make_float4(0.f, 0.f, 0.f, 0.f);
+  if (STATS) {
+    constexpr int NG = SMALLCI_NG(CI);
+    __shared__ double red[4][NG];
+    float g[NG];
+    int n = 0;
+#pragma unroll
+    for (int i = 0; i < CI; ++i) g[n++] = (v[i].x + v[i].y) + (v[i].z + v[i].w);
+#pragma unroll
+    for (int i = 0; i < CI; ++i)
+#pragma unroll
+      for (int j = i; j < CI; ++j) g[n++] = (v[i].x * v[j].x + v[i].y * v[j].y) + (v[i].z * v[j].z + v[i].w * v[j].w);
+#pragma unroll
+    for (int k = 0; k < NG; ++k) {
+      float t = g[k];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+      if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = (double)t;
+    }
+    __syncthreads();
+    if (threadIdx.x < NG)
+      partials[((long long)blockIdx.y * gridDim.x + blockIdx.x) * NG + threadIdx.x] =
+          (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (!live) return;
+  }
   for (int o = 0; o < Co; ++o) {
     const float* w = W + o * CI;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -604,21 +636,77 @@ __global__ __launch_bounds__(256) void conv_smallci_kernel(const float* __restri
   }
 }
 
-extern "C" int regnet_conv1x1_fwd_smallci_f32(const float* W, const float* X, float* Y, int64_t B, int64_t Co, int64_t Ci,
-                                              int64_t L, void* stream) {
+// partials (nblocks x NG) -> sums[2 c] = w_c . S, sums[2 c + 1] = w_c^T G w_c (fp64), one workgroup
+__global__ __launch_bounds__(256) void smallci_stats_finalize_kernel(const double* __restrict__ partials, long long nblocks, int CI,
+                                                                     const float* __restrict__ W, int Co, double* __restrict__ sums) {
+  __shared__ double tot[SMALLCI_NG(8)];
+  __shared__ double red[4];
+  const int NG = SMALLCI_NG(CI);
+  for (int k = 0; k < NG; ++k) {
+    double t = 0.0;
+    for (long long b = threadIdx.x; b < nblocks; b += 256) t += partials[b * NG + k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) tot[k] = (red[0] + red[1]) + (red[2] + red[3]);
+    __syncthreads();
+  }
+  for (int c = threadIdx.x; c < Co; c += 256) {
+    const float* w = W + c * CI;
+    double s = 0.0, q = 0.0;
+    int n = CI;
+    for (int i = 0; i < CI; ++i) s += (double)w[i] * tot[i];
+    for (int i = 0; i < CI; ++i)
+      for (int j = i; j < CI; ++j, ++n) q += (i == j ? 1.0 : 2.0) * (double)w[i] * (double)w[j] * tot[n];
+    sums[2 * c] = s;
+    sums[2 * c + 1] = q;
+  }
+}
+
+static int tg_fwd_smallci(const float* W, const float* X, float* Y, int64_t B, int64_t Co, int64_t Ci, int64_t L, void* workspace,
+                          void* sums, void* stream) {
   if (B < 0 || Co < 1 || Ci < 1 || Ci > 8 || L < 4 || (L % 4) || B >= 65536 || Co >= (1ll << 31)) return REGNET_ERR_SHAPE;
   if (B == 0) return REGNET_OK;
-  if (!W || !X || !Y) return REGNET_ERR_NULL;
+  if (!W || !X || !Y || (sums && !workspace)) return REGNET_ERR_NULL;
   if (!tg_aligned16(X) || !tg_aligned16(Y)) return REGNET_ERR_SHAPE;
+  if (sums && ((reinterpret_cast<uintptr_t>(sums) & 7) || (reinterpret_cast<uintptr_t>(workspace) & 7))) return REGNET_ERR_SHAPE;
   const dim3 grid((unsigned)((L / 4 + 255) / 256), (unsigned)B);
   hipStream_t st = as_stream(stream);
+  double* part = static_cast<double*>(workspace);
   switch (Ci) {
-#define SMALLCI_CASE(n) case n: hipLaunchKernelGGL(conv_smallci_kernel<n>, grid, dim3(256), 0, st, W, X, Y, (int)Co, (long long)L); break;
+#define SMALLCI_CASE(n)                                                                                                             \
+  case n:                                                                                                                           \
+    if (sums) hipLaunchKernelGGL((conv_smallci_kernel<n, true>), grid, dim3(256), 0, st, W, X, Y, (int)Co, (long long)L, part);     \
+    else hipLaunchKernelGGL((conv_smallci_kernel<n, false>), grid, dim3(256), 0, st, W, X, Y, (int)Co, (long long)L, part);         \
+    break;
     SMALLCI_CASE(1) SMALLCI_CASE(2) SMALLCI_CASE(3) SMALLCI_CASE(4) SMALLCI_CASE(5) SMALLCI_CASE(6) SMALLCI_CASE(7) SMALLCI_CASE(8)
 #undef SMALLCI_CASE
   }
+  if (sums)
+    hipLaunchKernelGGL(smallci_stats_finalize_kernel, dim3(1), dim3(256), 0, st, part, (long long)grid.x * grid.y, (int)Ci, W, (int)Co,
+                       static_cast<double*>(sums));
   REGNET_LAUNCH_CHECK();
   return REGNET_OK;
+}
+
+extern "C" int regnet_conv1x1_fwd_smallci_f32(const float* W, const float* X, float* Y, int64_t B, int64_t Co, int64_t Ci,
+                                              int64_t L, void* stream) {
+  return tg_fwd_smallci(W, X, Y, B, Co, Ci, L, nullptr, nullptr, stream);
+}
+
+// ... leaving sums (2 Co doubles: per output channel the sum and the sum of squares of Y over all B L points, from the INPUT's first
+// and second moments) for regnet_bn_train_stats_from_sums_f32 / regnet_bn_relu_train_fwd_from_sums_f32; workspace:
+// regnet_conv1x1_smallci_stats_workspace_bytes(B, Ci, L) bytes, 8-byte aligned
+extern "C" int64_t regnet_conv1x1_smallci_stats_workspace_bytes(int64_t B, int64_t Ci, int64_t L) {
+  if (B <= 0 || Ci < 1 || Ci > 8 || L < 4) return 0;
+  return ((L / 4 + 255) / 256) * B * SMALLCI_NG(Ci) * (int64_t)sizeof(double);
+}
+
+extern "C" int regnet_conv1x1_fwd_smallci_stats_f32(const float* W, const float* X, float* Y, int64_t B, int64_t Co, int64_t Ci,
+                                                    int64_t L, void* workspace, void* sums, void* stream) {
+  if (!sums) return REGNET_ERR_NULL;
+  return tg_fwd_smallci(W, X, Y, B, Co, Ci, L, workspace, sums, stream);
 }
 
 // Weight gradient of the same layers: dW[o][i] = sum_{b,l} dY[b][o][l] X[b][i][l] with CI <= 8 -- a reduction over the 1.3 GB

@@ -192,6 +192,28 @@ def test_statistics_left_by_the_convolution(B, Co, Ci, L, affine):
     assert float((mean - mean_ref).abs().max()) < 1e-5 and float(((var - var_ref).abs() / var_ref).max()) < 1e-4
 
 
+@pytest.mark.parametrize("B,Co,Ci,L", [(2, 128, 6, 128 * 64), (8, 128, 6, 5120 * 64), (3, 64, 3, 1000), (1, 256, 8, 4)])
+def test_statistics_of_a_handful_of_input_channels_come_from_the_input_moments(B, Co, Ci, L):
+    """native_fwd_smallci(..., sums): y = W x with <= 8 input channels -- the per-channel sum / sum of squares of y from the first
+    and second moments of x (csrc/tgemm.hip conv_smallci_kernel<.., STATS>), against float64; the output itself unchanged."""
+    from regnet_for_3d_grasping_amd import conv1x1_train as ct
+    torch.manual_seed(B + Co + L)
+    x = torch.randn((B, Ci, L), device=DEV) * 0.7 + torch.linspace(-1.0, 2.0, Ci, device=DEV)[None, :, None]
+    w = torch.randn((Co, Ci), device=DEV)
+    sums = ct.new_sums(Co, DEV)
+    y = ct.native_fwd_smallci(x, w, sums)
+    assert torch.equal(y, ct.native_fwd_smallci(x, w))
+    ref = torch.einsum("oi,bil->bol", w.double(), x.double())
+    n = B * L
+    s_ref, q_ref = ref.sum((0, 2)), (ref * ref).sum((0, 2))
+    s, q = sums[0::2], sums[1::2]
+    mean, var = s / n, q / n - (s / n) ** 2
+    mean_ref, var_ref = s_ref / n, q_ref / n - (s_ref / n) ** 2
+    assert float((mean - mean_ref).abs().max()) < 2e-6 * (1.0 + float(mean_ref.abs().max()))
+    # (the moments are fp32 products: the variance is a difference of two of them)
+    assert bool(((var - var_ref).abs() <= 2e-5 * var_ref + 2e-6 * q_ref / n).all())
+
+
 def test_unsupported_inputs_are_rejected_not_silently_wrong():
     from regnet_for_3d_grasping_amd import bn_train
     bn = nn.BatchNorm1d(4).to(DEV).train()
