@@ -338,7 +338,7 @@ class _Conv1x1Padded(torch.autograd.Function):
     rocBLAS batched GEMMs (8 launches per layer and scene in the backward)."""
 
     @staticmethod
-    def forward(ctx, x, w, Cip):
+    def forward(ctx, x, w, Cip, sums=None):
         B, Ci, L = x.shape
         xp = torch.zeros((B, Cip, L), dtype=torch.float32, device=x.device)
         xp[:, :Ci].copy_(x)
@@ -346,7 +346,7 @@ class _Conv1x1Padded(torch.autograd.Function):
         wp[:, :Ci].copy_(w)
         ctx.save_for_backward(xp, wp)
         ctx.Ci = Ci
-        return native_fwd(xp, wp)
+        return native_fwd(xp, wp, sums)
 
     @staticmethod
     def backward(ctx, dy):
@@ -354,7 +354,7 @@ class _Conv1x1Padded(torch.autograd.Function):
         dy = dy.contiguous()
         dx = native_dgrad(wp, dy)[:, :ctx.Ci] if ctx.needs_input_grad[0] else None
         dw = native_wgrad(dy, xp)[:, :ctx.Ci] if ctx.needs_input_grad[1] else None
-        return dx, dw, None
+        return dx, dw, None, None
 
 
 class _Conv1x1(torch.autograd.Function):
@@ -462,7 +462,7 @@ def gemm_conv(x, w, sums=None):
     B, Ci, L = x.shape
     Cip = _padded_channels(B, w.shape[0], Ci, L) if x.is_cuda and not _native_ok(B, w.shape[0], Ci, L) else 0
     if Cip:
-        return _Conv1x1Padded.apply(x, w, Cip)
+        return _Conv1x1Padded.apply(x, w, Cip, sums)
     return _Conv1x1.apply(x, w, sums)
 
 
@@ -477,7 +477,9 @@ def conv1x1(conv, x, stats=False):
     if stats and x.is_cuda and FUSE_STATS:
         if _native_ok(B, Co, Ci, L):
             sums = new_sums(Co, x.device) if stats_ok(Co, Ci, L) else None
-        elif _smallci_ok(xf, Ci, L) and not _padded_channels(B, Co, Ci, L):
+        elif _padded_channels(B, Co, Ci, L):
+            sums = new_sums(Co, x.device) if stats_ok(Co, _padded_channels(B, Co, Ci, L), L) else None
+        elif _smallci_ok(xf, Ci, L):
             sums = new_sums(Co, x.device)      # (a handful of input channels: from the input's moments, native_fwd_smallci)
     y = gemm_conv(xf, conv.weight.view(Co, Ci), sums)
     return _with_sums(y.view(B, Co, *x.shape[2:]), sums)
