@@ -50,12 +50,19 @@ def get_grasp_allobj(pc, predict_score, params, data_paths, use_theta=True, defe
             labels_pending = _get_center_grasp(center_pc_index, center_pc, data_paths, depth, use_theta, defer_read=True)
         np_random.flush()
         counts = torch.stack((count_s, count_m)).cpu().numpy()
-        pos = host_io.upload(np_random.choice_rows(counts[0], group_num, 0)[0], pc.device)
+        def drawn(count, size):
+            # on a GPU the positions (1 MB for the small groups of 8 x 64 centres, 8 MB for the large ones) are drawn straight into
+            # page-locked memory and leave by DMA behind the draws; a pageable source costs the launching thread a staging copy
+            # (1 ms for the large groups -- inside the region stage, the host-paced part of a training iteration)
+            if pc.is_cuda:
+                return np_random.choice_rows_pinned(count, size, 0)[0].to(pc.device, non_blocking=True)
+            return host_io.upload(np_random.choice_rows(count, size, 0)[0], pc.device)
+
+        pos = drawn(counts[0], group_num)
         pc_group_index, pc_group = region_ops.resample_groups(pc, cand_s, pos)
 
         def large_groups():
-            pos = host_io.upload(np_random.choice_rows(counts[1], group_num_more, 0)[0], pc.device)
-            return region_ops.resample_groups(pc, cand_m, pos)
+            return region_ops.resample_groups(pc, cand_m, drawn(counts[1], group_num_more))
 
         if defer_large_groups and DEFER_LARGE_GROUPS and pc.is_cuda:
             # (train_step) the large groups are first needed by the refine stage; their draws -- the next ones on numpy's stream
@@ -149,8 +156,7 @@ def _get_center_grasp(center_pc_index, center_pc, data_paths, depth, use_theta=T
                 return out if bool(wide_row.cpu().numpy().any()) else out[:, :, :8].contiguous()
 
             return finish if defer_read else finish()     # (defer_read: the caller makes the one read when it suits it)
-        packed = host_io.upload(host, dev)
-        valid = host_io.upload(np.arange(Gmax)[None, :] < np.asarray(Gs)[:, None], dev)
+        packed, valid = host_io.upload_many((host, np.arange(Gmax)[None, :] < np.asarray(Gs)[:, None]), dev)
         frames = packed[:, :, :16].view(B, Gmax, 4, 4)
         approach = frames[:, :, :3, 0]
         contact = ((frames[:, :, :3, 3] + approach * depth).float() - approach * depth).float()

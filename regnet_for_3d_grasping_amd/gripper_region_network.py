@@ -194,8 +194,7 @@ class GripperRegionNetwork(nn.Module):
             final_grasp, flags8 = region_ops.refine_decode(next_grasp, next_x_cls, next_x_reg, self.radius,
                                                            self.grasp_score_thre)
             flags = flags8.cpu().numpy().astype(bool)
-            class_select = host_io.upload(np.nonzero(flags[0])[0], dev)
-            score_select = host_io.upload(np.nonzero(flags[1])[0], dev)
+            class_select, score_select = host_io.upload_many((np.nonzero(flags[0])[0], np.nonzero(flags[1])[0]), dev)
             return (final_grasp[class_select], final_grasp[score_select], next_grasp[class_select], class_select,
                     score_select, (None, None), (None, None, None, None))
         final_grasp = next_grasp.clone()
@@ -213,8 +212,7 @@ class GripperRegionNetwork(nn.Module):
             same_angle = torch.abs(next_grasp[:, 6] - next_gt[:, 6]) < 1.047
             gt_positive = near & aligned & same_angle
             flags = torch.stack((is_class, is_score, gt_positive)).cpu().numpy()         # ... and the label classes
-        class_select = host_io.upload(np.nonzero(flags[0])[0], dev)
-        score_select = host_io.upload(np.nonzero(flags[1])[0], dev)
+        class_select, score_select = host_io.upload_many((np.nonzero(flags[0])[0], np.nonzero(flags[1])[0]), dev)
         sel_class, sel_score = final_grasp[class_select].data, final_grasp[score_select].data
         sel_class_stage2 = next_grasp[class_select].data
         if next_gt is None:
@@ -223,8 +221,7 @@ class GripperRegionNetwork(nn.Module):
 
         gt_class = gt_positive.float()
         pos_np, neg_np = np.nonzero(flags[2])[0], np.nonzero(~flags[2])[0]
-        pos = host_io.upload(pos_np, dev)
-        neg = host_io.upload(neg_np, dev)
+        pos, neg = host_io.upload_many((pos_np, neg_np), dev)
         num = min(len(neg_np), len(pos_np))
 
         zero = torch.zeros((), device=dev)
@@ -485,11 +482,11 @@ def get_gripper_region_transform(group_points, group_index, grasp, region_num, g
         if count.is_cuda:
             pos_pinned, valid = np_random.choice_rows_pinned(count.cpu().numpy(), region_num, 1)
             pos_t = pos_pinned.to(dev, non_blocking=True)
+            # (the host knows which crops are valid: no device nonzero; flags and ids in one transfer)
+            valid_t, valid_ids = host_io.upload_many((valid, np.nonzero(valid)[0]), dev)
         else:
             pos, valid = np_random.choice_rows(count.cpu().numpy(), region_num, 1)
-            pos_t = host_io.upload(pos, dev)
-        valid_t = host_io.upload(valid, dev)
-        valid_ids = host_io.upload(np.nonzero(valid)[0], dev)    # (the host knows which crops are valid: no device nonzero)
+            pos_t, valid_t, valid_ids = host_io.upload_many((pos, valid, np.nonzero(valid)[0]), dev)
     if valid_ids is None:
         valid_ids = torch.nonzero(valid_t).view(-1)     # data-dependent length: the one synchronisation of the crop
 

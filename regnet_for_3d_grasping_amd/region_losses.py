@@ -80,19 +80,21 @@ class _Stage2Loss(torch.autograd.Function):
             per_class = max(int(min(len(mem) for mem in members)), 1)
             np_random.flush()
             chosen = [mem[np.random.choice(len(mem), per_class, replace=False)] for mem in members if len(mem)]
-            idx = host_io.upload(np.concatenate(chosen).astype(np.int64), dev)
+            # (the picks and the two constant vectors of the reduction below in one transfer)
+            idx, scale, mix = host_io.upload_many((
+                np.concatenate(chosen).astype(np.int64),
+                np.array([1.0 / (3 * m), 1.0 / (3 * m), 1.0 / m, 1.0 / (3 * m), 1.0 / (3 * m), 1.0 / m, 1.0 / m, 1.0 / (3 * m), 1.0,
+                          0.0, 0.0, 0.0], dtype=np.float32),
+                np.array([10.0, 5.0, 1.0, 1.0, 0, 0, 0, 0, 0, 0, 1.0, 0], dtype=np.float32)), dev)
             nb = int(idx.numel())
             ce_rows = torch.empty((nb,), dtype=torch.float32, device=dev)
             _check(_L.regnet_ce_rows_f32(x_cls.data_ptr(), A, g8.data_ptr(), idx.data_ptr(), rows.data_ptr(), nb, 1.0 / nb,
                                          ce_rows.data_ptr(), dcls.data_ptr(), _stream(x_reg)), "ce_rows")
             sums = terms.sum(0)
             ce = ce_rows.sum()
-            scale = host_io.upload(torch.tensor([1.0 / (3 * m), 1.0 / (3 * m), 1.0 / m, 1.0 / (3 * m), 1.0 / (3 * m), 1.0 / m, 1.0 / m,
-                                  1.0 / (3 * m), 1.0, 0.0, 0.0, 0.0], dtype=torch.float32), dev)
             values = sums * scale
             values[9] = m - values[8]
             values[10] = ce / nb
-            mix = host_io.upload(torch.tensor([10.0, 5.0, 1.0, 1.0, 0, 0, 0, 0, 0, 0, 1.0, 0], dtype=torch.float32), dev)
             loss = torch.dot(values, mix)
         ctx.save_for_backward(dreg, dcls)
         ctx.mark_non_differentiable(values, next_grasp, pick, g8, a_gt)
@@ -149,24 +151,29 @@ class _RefineLoss(torch.autograd.Function):
                        + ([1.0 / (3 * ns), 1.0 / ns, 1.0 / ns, 1.0 / (3 * ns)] if ns > 0 else [nan] * 4))
             else:
                 mon = [0.0] * 12
-            scale = host_io.upload(torch.tensor(reg_scale + mon + [1.0] * 4, dtype=torch.float32), dev)
+            # every host array of this loss in ONE transfer: the scale vector, both selections and -- with a class-balanced subset
+            # to draw (numpy's stream, as gripper_region_network.py:262-268) -- its rows and the gradient's column scale
+            hosts = [np.array(reg_scale + mon + [1.0] * 4, dtype=np.float32), class_np, score_np]
+            if num > 0:
+                np_random.flush()
+                idx0 = neg_np[np.random.choice(len(neg_np), num, replace=False)]
+                idx1 = pos_np[np.random.choice(len(pos_np), num, replace=False)]
+                hosts += [np.concatenate((idx0, idx1)).astype(np.int64),
+                          np.array(reg_scale[:1] * 3 + reg_scale[1:2] * 3 + reg_scale[2:3] + reg_scale[3:4] * 3, dtype=np.float32)]
+            up = host_io.upload_many(hosts, dev)
+            scale, class_t, score_t = up[0], up[1], up[2]
             values = sums * scale
             if nc > 0 and ns == 0:
                 values[12:16] = nan                                    # 0 * nan above is nan already; written for clarity
             ce = torch.zeros((), dtype=torch.float32, device=dev)
             if num > 0:
-                np_random.flush()
-                idx0 = neg_np[np.random.choice(len(neg_np), num, replace=False)]
-                idx1 = pos_np[np.random.choice(len(pos_np), num, replace=False)]
-                idx = host_io.upload(np.concatenate((idx0, idx1)).astype(np.int64), dev)
+                idx, col = up[3], up[4]
                 nb = int(idx.numel())
                 target = flags8[2].to(torch.int32)
                 ce_rows = torch.empty((nb,), dtype=torch.float32, device=dev)
                 _check(_L.regnet_ce_rows_f32(next_x_cls.data_ptr(), 2, target.data_ptr(), idx.data_ptr(), None, nb, 1.0 / nb,
                                              ce_rows.data_ptr(), dcls.data_ptr(), _stream(next_x_reg)), "ce_rows")
                 ce = ce_rows.sum() / nb
-                col = host_io.upload(torch.tensor(reg_scale[:1] * 3 + reg_scale[1:2] * 3 + reg_scale[2:3] + reg_scale[3:4] * 3,
-                                   dtype=torch.float32), dev)
                 dreg = dreg * col
                 loss = ce + values[:4].sum()
             else:
@@ -174,7 +181,7 @@ class _RefineLoss(torch.autograd.Function):
                 loss = torch.zeros((), dtype=torch.float32, device=dev)
         ctx.save_for_backward(dreg, dcls)
         ctx.has_loss = num > 0
-        extras = (values, ce, final, host_io.upload(class_np, dev), host_io.upload(score_np, dev))
+        extras = (values, ce, final, class_t, score_t)
         ctx.mark_non_differentiable(*extras)
         return (loss,) + extras
 
