@@ -103,3 +103,26 @@ def test_pinned_position_draws_equal_the_pageable_ones():
         assert got.is_pinned() and np.array_equal(got.numpy(), want) and np.array_equal(valid_g, valid_w)
         assert np.random.get_state()[2] == state_w
         assert torch.equal(got.to(DEV, non_blocking=True).cpu(), torch.from_numpy(want))
+
+
+def test_upload_many_is_one_transfer_with_the_same_values():
+    """host_io.upload_many: arrays of mixed dtypes (int64 ids, bool flags, float32 scales, an empty selection) through ONE pinned
+    slot -- the same values as one ``upload`` each, every result addressable by a kernel (8-byte aligned), and a set too large
+    for a slot falling back to separate transfers."""
+    from regnet_for_3d_grasping_amd import host_io
+    rng = np.random.default_rng(3)
+    hosts = [rng.integers(0, 1 << 40, 37), rng.random(5) < 0.5, rng.random((3, 7)).astype(np.float32),
+             np.zeros((0,), dtype=np.int64), torch.arange(11, dtype=torch.int32)]
+    before = host_io._upload_ring.at if host_io._upload_ring.slots is not None else 0
+    outs = host_io.upload_many(hosts, "cuda:0")
+    assert host_io._upload_ring.at - before == 1
+    torch.cuda.synchronize()
+    for h, o in zip(hosts, outs):
+        want = torch.from_numpy(h) if isinstance(h, np.ndarray) else h
+        assert o.is_cuda and o.dtype == want.dtype and tuple(o.shape) == tuple(want.shape)
+        assert torch.equal(o.cpu(), want)
+        assert o.numel() == 0 or o.data_ptr() % 8 == 0
+    big = [np.arange(6000, dtype=np.int64), np.arange(6000, dtype=np.int64)]       # 96 KB: not one slot
+    for h, o in zip(big, host_io.upload_many(big, "cuda:0")):
+        assert torch.equal(o.cpu(), torch.from_numpy(h))
+    assert all(torch.equal(o, torch.from_numpy(h)) for h, o in zip(big, host_io.upload_many(big, "cpu")))
