@@ -254,17 +254,26 @@ __device__ __forceinline__ int tg_ticket_nowait(int* p) {
   return r;
 }
 
-// v + (v of the lane CTRL names within the row of 16; 0 where there is none): one v_add_f32 with a DPP operand
-template <int CTRL> __device__ __forceinline__ float tg_dpp_add(float v) {
-  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+// the value lane (i ^ MASK) holds, MASK = 1, 2, 4, 8 (DPP moves inside the row of 16), 16 (one ds_bpermute)
+template <int MASK> __device__ __forceinline__ float tg_xor_lane(float v) {
+  const int x = __builtin_bit_cast(int, v);
+  if (MASK == 1) return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xf, 0xf, true));     // quad_perm [1,0,3,2]
+  if (MASK == 2) return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xf, 0xf, true));     // quad_perm [2,3,0,1]
+  if (MASK == 4) {      // banks 0, 2 (lanes with bit 2 clear) read lane i + 4, banks 1, 3 lane i - 4
+    const int t = __builtin_amdgcn_update_dpp(0, x, 0x104, 0xf, 0x5, false);                                     // row_shl:4
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(t, x, 0x114, 0xf, 0xa, false));                 // row_shr:4
+  }
+  if (MASK == 8) {
+    const int t = __builtin_amdgcn_update_dpp(0, x, 0x108, 0xf, 0x3, false);                                     // row_shl:8
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(t, x, 0x118, 0xf, 0xc, false));                 // row_shr:8
+  }
+  return __shfl_xor(v, 16);
 }
-// the sum over the 32 lanes of a lane half (lanes 0-31 / 32-63), valid in lanes 16-31 / 48-63
-__device__ __forceinline__ float tg_half_sum(float v) {
-  v = tg_dpp_add<0xB1>(v);        // quad_perm [1,0,3,2]
-  v = tg_dpp_add<0x4E>(v);        // quad_perm [2,3,0,1]
-  v = tg_dpp_add<0x141>(v);       // row_half_mirror
-  v = tg_dpp_add<0x140>(v);       // row_mirror: every lane of a row of 16 holds the row's sum
-  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xa, 0xf, false));   // row_bcast:15 into rows 1, 3
+// One step of a HALVING reduction over lanes: the lane pair (i, i ^ MASK) holds two values each and wants their two sums; the lane
+// with `side` clear ends up with lo + partner's lo, the other with hi + partner's hi -- one exchange and one add for two sums.
+template <int MASK> __device__ __forceinline__ float tg_halve(float lo, float hi, bool side) {
+  const float keep = side ? hi : lo, give = side ? lo : hi;
+  return keep + tg_xor_lane<MASK>(give);
 }
 #define TG_STAT_MAXM 256        // STATS: output channels whose fp64 sums fit the workgroup's LDS table beside the ring
 #define TG_STAT_AFF_MAXK 256    // ... and input channels of a B_AFFINE operand then
@@ -277,9 +286,9 @@ __device__ __forceinline__ float tg_half_sum(float v) {
 // start there must not own tiles (measured with a fixed stride: 5 % faster on an idle chip, 3 % slower in the iteration).
 //
 // STATS (forward): the per-channel sum and sum of squares of the output -- the statistics pass of the BatchNorm that follows -- are
-// taken from the accumulators (a lane holds 32 channels of two points: two in-lane adds, a DPP tree over the 32 lanes of a lane
-// half, 64 LDS atomics per wave and tile into an fp64 table, one fp64 global atomic per channel and workgroup at the end), so that
-// the output is not read again (bn_stats_kernel: 1 read of up to 2.7 GB per layer).
+// taken from the accumulators (a lane holds 32 channels of two points: two in-lane adds, a halving reduction over the 32 lanes of a
+// lane half that leaves every lane ONE channel's number, one LDS atomic per lane into an fp64 table, one fp64 global atomic per
+// channel and workgroup at the end), so that the output is not read again (bn_stats_kernel: 1 read of up to 2.7 GB per layer).
 template <bool A_KMAJ, bool B_AFFINE = false, bool STATS = false>
 __global__ __launch_bounds__(TG_THREADS, 4) void tgemm_stream_kernel(const TgArgs p) {
   constexpr int TG_BN = 256, TNI = 2, WN_COLS = 64, NPIECE = 3;
@@ -477,17 +486,28 @@ __global__ __launch_bounds__(TG_THREADS, 4) void tgemm_stream_kernel(const TgArg
         const float ok0 = n0 + wn * WN_COLS + fr_ < p.N ? 1.f : 0.f, ok1 = n0 + wn * WN_COLS + 32 + fr_ < p.N ? 1.f : 0.f;
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
-          const int row0 = m0 + wm * 64 + mi * 32 + 4 * fh_;
+          // A lane holds 16 channels (registers r) x 2 points of this row tile: 32 numbers (sum, sum of squares per channel) to be
+          // added over the 32 lanes of its half.  Five halving steps (lane bits 0 .. 4 against: which quantity, register bits
+          // 3 .. 0) leave every lane with ONE finished number -- 16 + 8 + 4 + 2 + 1 exchanges instead of 32 x 5, and one LDS
+          // atomic per lane instead of 32 from one.
+          float w[16];
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const float a0 = acc[mi][0][r] * ok0, a1 = acc[mi][1][r] * ok1;
-            const float sv = tg_half_sum(a0 + a1), qv = tg_half_sum(a0 * a0 + a1 * a1);
-            const int row = row0 + (r & 3) + 8 * (r >> 2);
-            if (fr_ == 16 && row < p.M) {
-              unsafeAtomicAdd(&stab[2 * row], (double)sv);
-              unsafeAtomicAdd(&stab[2 * row + 1], (double)qv);
-            }
+            w[r] = tg_halve<1>(a0 + a1, a0 * a0 + a1 * a1, (ln & 1) != 0);
           }
+          float x8[8], x4[4], x2[2];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) x8[j] = tg_halve<2>(w[j], w[j + 8], (ln & 2) != 0);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) x4[j] = tg_halve<4>(x8[j], x8[j + 4], (ln & 4) != 0);
+#pragma unroll
+          for (int j = 0; j < 2; ++j) x2[j] = tg_halve<8>(x4[j], x4[j + 2], (ln & 8) != 0);
+          const float total = tg_halve<16>(x2[0], x2[1], (ln & 16) != 0);
+          // this lane's number: quantity = lane bit 0, register r = lane bits 1 .. 4 (most significant first)
+          const int r = ((ln >> 1) & 1) * 8 + ((ln >> 2) & 1) * 4 + ((ln >> 3) & 1) * 2 + ((ln >> 4) & 1);
+          const int row = m0 + wm * 64 + mi * 32 + 4 * fh_ + (r & 3) + 8 * (r >> 2);
+          if (row < p.M) unsafeAtomicAdd(&stab[2 * row + (ln & 1)], (double)total);
         }
       }
 #pragma unroll
