@@ -79,6 +79,12 @@ def _distributed():
 _stream_pools = {}
 
 
+# The region stage is the iteration's critical path between the forward and the trunk's backward (5.7 ms, host-paced; the head's
+# backward beside it takes 4.1 and has the slack): its stream is of the high-priority class, so that its kernels are dispatched ahead
+# of the head's whenever both wait for a CU (priority 0: 45.7-46.6 ms per iteration and 2.0-2.9 ms of waiting, -1: 45.1-45.2 / 1.7-1.8)
+REGION_STREAM_PRIORITY = -1
+
+
 def reserve_streams(device):
     """The side streams of a training iteration on ``device`` -- {"geometry": the next batch's sampling / grouping (low
     priority... the same ``priority=-1`` class the pipeline uses), "region": the region stage beside the head's backward,
@@ -90,7 +96,7 @@ def reserve_streams(device):
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
     pool = _stream_pools.get(idx)
     if pool is None:
-        pool = {"geometry": torch.cuda.Stream(dev, priority=-1), "region": torch.cuda.Stream(dev),
+        pool = {"geometry": torch.cuda.Stream(dev, priority=-1), "region": torch.cuda.Stream(dev, priority=REGION_STREAM_PRIORITY),
                 "capture": torch.cuda.Stream(dev), "comm": torch.cuda.Stream(dev)}
         for name in ("geometry", "region", "capture", "comm"):
             _ = pool[name].cuda_stream
