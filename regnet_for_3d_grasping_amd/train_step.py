@@ -79,10 +79,12 @@ def _distributed():
 _stream_pools = {}
 
 
-# The region stage is the iteration's critical path between the forward and the trunk's backward (5.7 ms, host-paced; the head's
-# backward beside it takes 4.1 and has the slack): its stream is of the high-priority class, so that its kernels are dispatched ahead
-# of the head's whenever both wait for a CU (priority 0: 45.7-46.6 ms per iteration and 2.0-2.9 ms of waiting, -1: 45.1-45.2 / 1.7-1.8)
-REGION_STREAM_PRIORITY = -1
+# Priority class of the region stage's stream.  The stage is the iteration's critical path between the forward and the trunk's backward
+# (5.7 ms, host-paced; the head's backward beside it takes 4.1 and has the slack), and -1 (the high-priority class) shortens an
+# iteration of a process that runs NOTHING ELSE by 0.3-0.5 ms -- but in a process that has also created an inference pipeline's
+# streams (bench.py's default line: the `train` object after the forward measurement) it costs 15 ms: 45.6 -> 60.3 ms per iteration,
+# every phase of the trunk stream 1.3-1.45x slower (stream -> hardware-queue binding again, see pipeline.reserve_streams).  Stays 0.
+REGION_STREAM_PRIORITY = 0
 
 
 def reserve_streams(device):
